@@ -1,0 +1,50 @@
+"""Build recipe for libellhip.so (hipcc, gfx950 only, in-tree)."""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(PKG_DIR, "csrc")
+LIB_PATH = os.path.join(PKG_DIR, "libellhip.so")
+REPO_ROOT = os.path.dirname(PKG_DIR)
+
+SOURCES = ["ellhip_capi.hip"]
+HEADERS = ["ell_kernels.hpp", "ellstable_kernels.hpp", "ellcalc_device.hpp"]
+
+# -ffp-contract=off: the reference never fuses a*b+c (two roundings per multiply-add); keeping
+# that makes the rank-1 pass bit-identical to the CPU arithmetic for the same gt.
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
+               "-Wall", "-Wno-unused-function"]
+
+
+def _hipcc() -> str:
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found: cannot build libellhip.so")
+
+
+def needs_build() -> bool:
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS] + [os.path.join(REPO_ROOT, "include", "ellhip.h")]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """Compile the HIP engine for gfx950 into ellalgo-rs_amd/libellhip.so."""
+    if not force and not needs_build():
+        return LIB_PATH
+    cmd = [_hipcc()] + HIPCC_FLAGS + ["-I", os.path.join(REPO_ROOT, "include"), "-o", LIB_PATH] + \
+          [os.path.join(CSRC, f) for f in SOURCES]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    print(build(force=True, verbose=True))

@@ -1,0 +1,97 @@
+"""ctypes binding of include/ellhip.h (libellhip.so).
+
+Loading fails loudly: there is no Python or CPU implementation of the update behind this module.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+from . import build as _build
+
+SUCCESS, NOSOLN, NOEFFECT, UNKNOWN = 0, 1, 2, 3
+CUT_BIAS, CUT_CENTRAL, CUT_Q = 0, 1, 2
+SPACE_ELL, SPACE_ELL_STABLE = 0, 1
+E_INVALID, E_HIP, E_NODEVICE, E_NOMEM, E_STATE = -1, -2, -3, -4, -5
+NKERNEL_CLASSES = 6
+KERNEL_CLASS_NAMES = ("gemv", "scalar", "rank1", "stable_fwd", "stable_bwd", "stable_factor")
+
+# every symbol include/ellhip.h declares
+EXPORTS = [
+    "ellhip_create", "ellhip_create_shard", "ellhip_clone", "ellhip_destroy", "ellhip_update", "ellhip_tsq",
+    "ellhip_get_xc", "ellhip_set_xc", "ellhip_kappa", "ellhip_ndim", "ellhip_get_mq",
+    "ellhip_set_no_defer_trick", "ellhip_set_use_parallel_cut", "ellhip_calc", "ellhip_update_begin",
+    "ellhip_update_end", "ellhip_gt_dev", "ellhip_set_gt_dev", "ellhip_queue_upload", "ellhip_queue_run",
+    "ellhip_queue_begin", "ellhip_queue_end", "ellhip_queue_results", "ellhip_set_stream",
+    "ellhip_synchronize", "ellhip_profile_enable", "ellhip_profile_read", "ellhip_device_count",
+    "ellhip_last_error", "ellhip_version",
+]
+
+
+class EllHipError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib_path() -> str:
+    return _build.LIB_PATH
+
+
+def load():
+    """dlopen libellhip.so (built in-tree by ellalgo-rs_amd/build.py) and type its entry points."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = lib_path()
+    if not os.path.exists(path):
+        raise EllHipError(f"{path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(the ellipsoid engine has no CPU fallback)")
+    L = C.CDLL(path, mode=C.RTLD_GLOBAL)
+    vp, dbl, i32, i64 = C.c_void_p, C.c_double, C.c_int, C.c_int64
+    sig = {
+        "ellhip_create": (i32, [C.POINTER(vp), i32, i64, dbl, vp, vp, vp, i32]),
+        "ellhip_create_shard": (i32, [C.POINTER(vp), i64, i64, i64, dbl, vp, vp, vp, i32]),
+        "ellhip_clone": (i32, [vp, C.POINTER(vp)]),
+        "ellhip_destroy": (None, [vp]),
+        "ellhip_update": (i32, [vp, i32, vp, dbl, i32, dbl]),
+        "ellhip_tsq": (dbl, [vp]),
+        "ellhip_get_xc": (i32, [vp, vp]),
+        "ellhip_set_xc": (i32, [vp, vp]),
+        "ellhip_kappa": (dbl, [vp]),
+        "ellhip_ndim": (i64, [vp]),
+        "ellhip_get_mq": (i32, [vp, vp]),
+        "ellhip_set_no_defer_trick": (i32, [vp, i32]),
+        "ellhip_set_use_parallel_cut": (i32, [vp, i32]),
+        "ellhip_calc": (i32, [i64, i32, i32, dbl, i32, dbl, dbl, vp, i32]),
+        "ellhip_update_begin": (i32, [vp, i32, vp, dbl, i32, dbl]),
+        "ellhip_update_end": (i32, [vp]),
+        "ellhip_gt_dev": (vp, [vp]),
+        "ellhip_set_gt_dev": (i32, [vp, vp]),
+        "ellhip_queue_upload": (i32, [vp, i64, vp, vp, vp, vp, vp]),
+        "ellhip_queue_run": (i32, [vp, i64, i64]),
+        "ellhip_queue_begin": (i32, [vp, i64]),
+        "ellhip_queue_end": (i32, [vp, i64]),
+        "ellhip_queue_results": (i32, [vp, vp, vp]),
+        "ellhip_set_stream": (i32, [vp, vp]),
+        "ellhip_synchronize": (i32, [vp]),
+        "ellhip_profile_enable": (i32, [vp, i32]),
+        "ellhip_profile_read": (i32, [vp, vp, vp]),
+        "ellhip_device_count": (i32, []),
+        "ellhip_last_error": (C.c_char_p, []),
+        "ellhip_version": (C.c_char_p, []),
+    }
+    for name in EXPORTS:
+        fn = getattr(L, name)  # AttributeError if the library does not export it
+        fn.restype, fn.argtypes = sig[name]
+    _lib = L
+    return L
+
+
+def check(rc: int, what: str = "") -> int:
+    """Raise on a library failure (negative code); pass CutStatus / 0 through."""
+    if rc < 0:
+        msg = load().ellhip_last_error().decode(errors="replace")
+        raise EllHipError(f"{what or 'ellhip'} failed with code {rc}: {msg}")
+    return rc

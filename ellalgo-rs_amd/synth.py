@@ -1,0 +1,74 @@
+"""Synthetic cut sequences for the benchmark configurations.
+
+Deterministic and self-contained: a splitmix64 counter stream + Box-Muller written here in numpy
+(no dependence on a library's Gaussian sampler), so the CPU oracle, the GPU engine and every rank of
+a multi-GPU run see bit-identical inputs.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+_MASK = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+
+def _splitmix64(seed: int, count: int) -> np.ndarray:
+    """count 64-bit outputs of splitmix64 started at `seed` (vectorised: counter based)."""
+    with np.errstate(over="ignore"):
+        z = (np.uint64(seed) + np.arange(1, count + 1, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15)) & _MASK
+        z = ((z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)) & _MASK
+        z = ((z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)) & _MASK
+        return z ^ (z >> np.uint64(31))
+
+
+def uniform01(seed: int, count: int) -> np.ndarray:
+    """Uniforms in (0, 1): top 53 bits, offset by half an ulp so 0 never occurs."""
+    return ((_splitmix64(seed, count) >> np.uint64(11)).astype(np.float64) + 0.5) * (1.0 / 9007199254740992.0)
+
+
+def unit_gaussian(seed: int, n: int) -> np.ndarray:
+    """n iid N(0,1) draws (Box-Muller) normalised to unit 2-norm."""
+    m = (n + 1) // 2
+    u = uniform01(seed, 2 * m)
+    r = np.sqrt(-2.0 * np.log(u[:m]))
+    t = 2.0 * np.pi * u[m:]
+    g = np.empty(2 * m, dtype=np.float64)
+    g[0::2] = r * np.cos(t)
+    g[1::2] = r * np.sin(t)
+    g = g[:n]
+    return g / np.sqrt(np.dot(g, g))
+
+
+SEED0 = 0x5EED0000
+
+
+def deep_cuts(n: int, k: int, seed0: int = SEED0):
+    """Config 2/4/5: update_bias_cut(SingleCut(beta_k)), beta_k ~ U[0, 0.1)."""
+    grads = np.empty((k, n), dtype=np.float64)
+    for i in range(k):
+        grads[i] = unit_gaussian(seed0 + i, n)
+    beta0 = 0.1 * uniform01(seed0 ^ 0xBE7A, k)
+    kinds = np.zeros(k, dtype=np.int32)  # CUT_BIAS
+    beta1 = np.full(k, np.nan)
+    return kinds, grads, beta0, beta1
+
+
+def parallel_cuts(n: int, k: int, seed0: int = SEED0):
+    """Config 3: alternate update_central_cut(ParallelCut(0, Some(b1))), b1 ~ U[0.05, 0.5) and
+    update_bias_cut(ParallelCut(b0, Some(b1))), b0 ~ U[0, 0.05), b1 = b0 + U[0.05, 0.45)."""
+    grads = np.empty((k, n), dtype=np.float64)
+    for i in range(k):
+        grads[i] = unit_gaussian(seed0 + i, n)
+    u = uniform01(seed0 ^ 0xBE7A, 2 * k)
+    kinds = np.empty(k, dtype=np.int32)
+    beta0 = np.empty(k, dtype=np.float64)
+    beta1 = np.empty(k, dtype=np.float64)
+    for i in range(k):
+        if i % 2 == 0:
+            kinds[i] = 1  # CUT_CENTRAL
+            beta0[i] = 0.0
+            beta1[i] = 0.05 + 0.45 * u[2 * i]
+        else:
+            kinds[i] = 0  # CUT_BIAS
+            beta0[i] = 0.05 * u[2 * i]
+            beta1[i] = beta0[i] + 0.05 + 0.40 * u[2 * i + 1]
+    return kinds, grads, beta0, beta1

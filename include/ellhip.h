@@ -1,0 +1,172 @@
+/*
+ * ellhip.h -- C ABI of the MI355X ellipsoid-update engine (libellhip.so).
+ *
+ * This is the drop-in boundary for ONE path of luk036/ellalgo-rs 0.1.7: the search-space update
+ * behind `trait SearchSpace` (src/cutting_plane.rs:154-182), i.e. Ell::update_core
+ * (src/ell.rs:97-137) and EllStable::update_core (src/ell_stable.rs:52-125) together with the
+ * EllCalc coefficient stage (src/ell_calc.rs:627-931).  The reference has no FFI today (it is
+ * safe single-threaded Rust); these entry points are what a Rust `impl SearchSpace for EllHip`
+ * binds (see INTEGRATION.md for the `extern "C"` block and the impl).
+ *
+ * Conventions
+ *   - Plain pointers and sizes only.  Every `const double*` / `double*` argument is a HOST buffer
+ *     owned by the caller unless its name ends in `_dev`; the library copies in/out and keeps no
+ *     reference after the call returns.  Device memory is owned by the handle.
+ *   - Matrices are n*n row-major f64, exactly `Arr{data, rows, cols}` (src/arr.rs:12-16).
+ *   - Return value of the update calls: 0..3 = CutStatus in the reference's declaration order
+ *     (src/cutting_plane.rs:31-37); negative = library failure (ELLHIP_E_*), which a binding maps
+ *     to CutStatus::Unknown.  All other int-returning calls: 0 = ok, negative = ELLHIP_E_*.
+ *   - State contract on a non-Success cut (src/ell.rs:105-109): tsq is updated, Q / xc / kappa
+ *     are untouched (EllStable additionally has its scratch triangle rewritten,
+ *     src/ell_stable.rs:66).
+ *   - One handle is used from one host thread at a time (`&mut self` in the reference).  All work
+ *     of a handle is issued on one HIP stream (ellhip_set_stream; default: a stream the handle
+ *     owns).  ellhip_update / ellhip_update_end are synchronous at return, like the reference.
+ *   - There is NO CPU fallback: with no HIP device every call that needs one fails with
+ *     ELLHIP_E_NODEVICE.
+ */
+#ifndef ELLHIP_H
+#define ELLHIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* CutStatus, src/cutting_plane.rs:31-37 */
+#define ELLHIP_SUCCESS 0
+#define ELLHIP_NOSOLN 1
+#define ELLHIP_NOEFFECT 2
+#define ELLHIP_UNKNOWN 3
+
+/* library failures */
+#define ELLHIP_E_INVALID (-1)   /* bad argument (NULL, n mismatch, ...); replaces Arr's shape assert!s (src/arr.rs:427-429) */
+#define ELLHIP_E_HIP (-2)       /* a HIP runtime call failed; see ellhip_last_error() */
+#define ELLHIP_E_NODEVICE (-3)  /* no usable HIP device */
+#define ELLHIP_E_NOMEM (-4)
+#define ELLHIP_E_STATE (-5)     /* call sequence violated (e.g. update_end without update_begin) */
+
+/* which SearchSpace method is being served (src/cutting_plane.rs:161-179) */
+#define ELLHIP_CUT_BIAS 0     /* update_bias_cut    -> CutType::call_bias_cut    (src/ell.rs:189-191,201-203) */
+#define ELLHIP_CUT_CENTRAL 1  /* update_central_cut -> CutType::call_central_cut (src/ell.rs:192-194,204-206) */
+#define ELLHIP_CUT_Q 2        /* update_q           -> CutType::call_q_cut       (src/ell.rs:195-197,207-209) */
+
+/* search-space variant */
+#define ELLHIP_SPACE_ELL 0         /* struct Ell,       src/ell.rs:9-16 */
+#define ELLHIP_SPACE_ELL_STABLE 1  /* struct EllStable, src/ell_stable.rs:9-15 */
+
+typedef struct ellhip_space ellhip_space; /* opaque */
+
+/* ---- lifetime -------------------------------------------------------------------------------
+ * ellhip_create replaces Ell::new_with_matrix / new / new_with_scalar / from_covariance
+ * (src/ell.rs:31-78) and the EllStable constructors (src/ell_stable.rs:18-35):
+ *   mq != NULL            : copy of the n*n matrix            (new_with_matrix, from_covariance)
+ *   mq == NULL, diag != 0 : diag(diag[0..n))                  (new:             kappa = 1)
+ *   both NULL             : identity                          (new_with_scalar: kappa = val)
+ * xc == NULL means the zero vector.  device < 0 = current device.
+ * Ell requires the matrix it is given to be symmetric only in the sense the reference does: after
+ * the first successful update the upper triangle is a copy of the lower one (src/ell.rs:124-126);
+ * the engine reproduces exactly that (it reads Q[c][r] for c > r on the first update of a matrix
+ * that was supplied by the caller and never again).
+ */
+int ellhip_create(ellhip_space **out, int variant, int64_t n, double kappa, const double *mq,
+                  const double *diag, const double *xc, int device);
+
+/* Row-block shard of an n*n Ell for the multi-GPU schedule: this handle owns rows
+ * [row0, row0 + nrows) of Q (mq, if given, is the nrows*n block).  Vectors are full length. */
+int ellhip_create_shard(ellhip_space **out, int64_t n, int64_t row0, int64_t nrows, double kappa,
+                        const double *mq_rows, const double *diag, const double *xc, int device);
+
+/* `#[derive(Clone)]` on Ell / EllStable (src/ell.rs:8, src/ell_stable.rs:8), used by
+ * BSearchAdaptor::assess_bs (src/cutting_plane.rs:410).  Device-to-device copy. */
+int ellhip_clone(const ellhip_space *src, ellhip_space **out);
+/* Rust Drop. */
+void ellhip_destroy(ellhip_space *s);
+
+/* ---- the SearchSpace methods ---------------------------------------------------------------- */
+
+/* update_bias_cut / update_central_cut / update_q (src/ell.rs:153-175, src/ell_stable.rs:139-161).
+ * SingleCut(b) -> beta0 = b, has_beta1 = 0.  ParallelCut(b0, Some(b1)) -> has_beta1 = 1.
+ * ParallelCut(b0, None) -> has_beta1 = 0 (same arithmetic, src/ell_calc.rs:677-681).
+ * grad: n doubles.  Returns CutStatus (0..3) or ELLHIP_E_*. */
+int ellhip_update(ellhip_space *s, int kind, const double *grad, double beta0, int has_beta1,
+                  double beta1);
+/* SearchSpace::tsq (src/ell.rs:149-151). */
+double ellhip_tsq(const ellhip_space *s);
+/* SearchSpace::xc (src/ell.rs:144-146): owned copy out, n doubles. */
+int ellhip_get_xc(const ellhip_space *s, double *xc_out);
+/* SearchSpace::set_xc (src/ell.rs:177-179). */
+int ellhip_set_xc(ellhip_space *s, const double *xc);
+
+/* ---- public fields of Ell (src/ell.rs:10-15) and parity observability ----------------------- */
+double ellhip_kappa(const ellhip_space *s);
+int64_t ellhip_ndim(const ellhip_space *s);
+/* Local row block of the matrix (whole n*n for an unsharded handle), row-major. */
+int ellhip_get_mq(const ellhip_space *s, double *mq_out);
+/* Ell.no_defer_trick (src/ell.rs:10,132-135).  Ell only. */
+int ellhip_set_no_defer_trick(ellhip_space *s, int flag);
+/* EllCalc.use_parallel_cut (src/ell_calc.rs:630); the reference fixes it to true for Ell. */
+int ellhip_set_use_parallel_cut(ellhip_space *s, int flag);
+
+/* ---- EllCalc on the device (src/ell_calc.rs:671-931) ----------------------------------------
+ * Runs the same device routine the update kernels use on one lane and returns
+ * (status, rho, sigma, delta) for dimension n; out3 = {rho, sigma, delta}. */
+int ellhip_calc(int64_t n, int use_parallel_cut, int kind, double beta0, int has_beta1,
+                double beta1, double tsq, double *out3, int device);
+
+/* ---- two-phase update for the row-partitioned (multi-GPU) schedule --------------------------
+ * begin: uploads grad, runs the local GEMV gt[row0..row0+nrows) = Q_rows * grad into the handle's
+ *        full-length gt buffer (device), asynchronously on the handle's stream.
+ * The caller then assembles the full gt across ranks IN PLACE on that buffer (RCCL all-gather of
+ * nrows doubles per rank; ellhip_gt_dev gives the pointer) on the same stream or one ordered
+ * after it.
+ * end:   every rank redundantly runs the scalar stage (omega, tsq, EllCalc, xc, kappa) and then the
+ *        rank-1 update of its own rows; synchronous at return; returns CutStatus. */
+int ellhip_update_begin(ellhip_space *s, int kind, const double *grad, double beta0,
+                        int has_beta1, double beta1);
+int ellhip_update_end(ellhip_space *s);
+/* Device pointer of the full-length (n doubles) gt buffer. */
+double *ellhip_gt_dev(ellhip_space *s);
+/* Use caller-provided device memory (n doubles) as the gt buffer, e.g. a tensor a collective
+ * library already knows.  NULL restores the handle's own buffer. */
+int ellhip_set_gt_dev(ellhip_space *s, double *gt_dev);
+
+/* ---- device-resident cut queue (benchmarks, replay of recorded cut sequences) ---------------
+ * Uploads k cuts once; run/begin/end then execute them without touching host memory, stopping
+ * (all later cuts become no-ops with status ELLHIP_UNKNOWN) at the first non-Success one, like the
+ * drivers do (src/cutting_plane.rs:222,308).  grads: k*n doubles. */
+int ellhip_queue_upload(ellhip_space *s, int64_t k, const int32_t *kinds, const double *grads,
+                        const double *beta0, const int32_t *has_beta1, const double *beta1);
+/* Enqueue cuts [first, first+count) on the stream; asynchronous. */
+int ellhip_queue_run(ellhip_space *s, int64_t first, int64_t count);
+/* Two-phase form of one queued cut (multi-GPU); both asynchronous. */
+int ellhip_queue_begin(ellhip_space *s, int64_t index);
+int ellhip_queue_end(ellhip_space *s, int64_t index);
+/* Waits for the stream, then copies per-cut status (int32) and tsq (double) for all k cuts. */
+int ellhip_queue_results(ellhip_space *s, int32_t *status_out, double *tsq_out);
+
+/* ---- streams, sync, timing ------------------------------------------------------------------ */
+/* hipStream_t to issue on (NULL = the handle's own stream). */
+int ellhip_set_stream(ellhip_space *s, void *hip_stream);
+int ellhip_synchronize(ellhip_space *s);
+/* Per-kernel HIP-event timing: when enabled every kernel launch is bracketed by events on the
+ * launch stream.  ellhip_profile_read waits for them and returns accumulated milliseconds and
+ * launch counts per kernel class, then resets.  Classes: 0 = GEMV (Q*g), 1 = scalar stage,
+ * 2 = rank-1 shrink, 3 = EllStable forward, 4 = EllStable backward, 5 = EllStable factor update. */
+#define ELLHIP_NKERNEL_CLASSES 6
+int ellhip_profile_enable(ellhip_space *s, int flag);
+int ellhip_profile_read(ellhip_space *s, double *ms_out, int64_t *count_out);
+
+/* ---- misc ----------------------------------------------------------------------------------- */
+/* Number of HIP devices visible (0 if none / no driver). */
+int ellhip_device_count(void);
+/* Text of the last failure on this thread (never NULL). */
+const char *ellhip_last_error(void);
+/* "ellhip <version> gfx950" */
+const char *ellhip_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

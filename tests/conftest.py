@@ -1,0 +1,38 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def _gpu_count():
+    try:
+        import ellalgo_rs_amd as pkg
+        return pkg.capi.load().ellhip_device_count()
+    except Exception:
+        return 0
+
+
+@pytest.fixture(scope="session")
+def gpu():
+    """The product package, with a hard requirement that a HIP device and the HIP library exist."""
+    import ellalgo_rs_amd as pkg
+    lib = pkg.capi.load()  # raises if libellhip.so is missing -- no fallback
+    if lib.ellhip_device_count() <= 0:
+        pytest.fail("test is marked gpu but no HIP device is visible")
+    return pkg
+
+
+@pytest.fixture(scope="session")
+def orc():
+    """The CPU oracle (test infrastructure)."""
+    from oracle import oracle
+    oracle.lib()
+    return oracle

@@ -1,0 +1,75 @@
+"""Shared helpers for the parity tests."""
+import numpy as np
+
+TOL = 1e-10  # BASELINE.json north_star: (xc, Q, kappa) within 1e-10 relative
+
+
+def rel_inf(a, b):
+    """max|a-b| / max|b| (inf-norm relative); exact 0 when both are all-zero."""
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    d = np.max(np.abs(a - b)) if a.size else 0.0
+    s = np.max(np.abs(b)) if b.size else 0.0
+    if d == 0.0:
+        return 0.0
+    return d / s if s > 0 else np.inf
+
+
+def assert_state_close(gpu_space, orc_space, tol=TOL, what=""):
+    """SURVEY 8d parity check: Q, xc (relative inf-norm, abs fallback when xc ~ 0), kappa, tsq."""
+    q_err = rel_inf(gpu_space.mq, orc_space.mq)
+    assert q_err <= tol, f"{what} Q rel err {q_err}"
+    xg, xo = gpu_space.xc(), np.array(orc_space.xc)
+    x_abs = np.max(np.abs(xg - xo)) if xo.size else 0.0
+    assert x_abs <= tol * np.max(np.abs(xo)) + 1e-300, f"{what} xc abs err {x_abs}"
+    ko = orc_space.kappa
+    assert abs(gpu_space.kappa - ko) <= tol * abs(ko), f"{what} kappa {gpu_space.kappa} vs {ko}"
+    to = orc_space.tsq
+    assert abs(gpu_space.tsq() - to) <= tol * abs(to) + 1e-300, f"{what} tsq {gpu_space.tsq()} vs {to}"
+
+
+def mixed_cut(i, g, tau, rng):
+    """Cut number i of a sequence that exercises every EllCalc entry point; beta is scaled by the
+    current tau = sqrt(kappa * g'Qg) so the sequence stays well-posed while the ellipsoid shrinks.
+    Returns (kind, b0, b1_or_None)."""
+    sel = i % 8
+    if sel == 0:
+        return 0, 0.3 * tau * rng.random(), None                       # bias, SingleCut
+    if sel == 1:
+        return 1, 0.0, None                                            # central, SingleCut
+    if sel == 2:
+        b0 = 0.1 * tau * rng.random()
+        return 0, b0, b0 + tau * (0.1 + 0.5 * rng.random())            # bias, ParallelCut
+    if sel == 3:
+        return 1, 0.0, tau * (0.1 + 0.6 * rng.random())                # central, ParallelCut
+    if sel == 4:
+        return 2, 0.2 * tau * rng.random(), None                       # q, SingleCut
+    if sel == 5:
+        b0 = 0.1 * tau * rng.random()
+        return 2, b0, b0 + tau * (0.1 + 0.5 * rng.random())            # q, ParallelCut
+    if sel == 6:
+        return 0, -0.1 * tau * rng.random(), tau * (1.0 + rng.random())  # parallel falls back to deep cut
+    return 0, 1.5 * tau, None                                          # NoSoln: state must stay intact
+
+
+def run_mixed(gpu_space, orc_space, k, seed, g_scale=1.0, check_every=0, tol=TOL):
+    """Drive both engines with the same adaptive cut sequence; statuses must agree at every step."""
+    n = orc_space.n
+    rng = np.random.default_rng(seed)
+    nsucc = 0
+    for i in range(k):
+        g = rng.standard_normal(n)
+        g *= g_scale / np.linalg.norm(g)
+        tau = float(np.sqrt(max(orc_space.kappa * (g @ (orc_space.mq @ g)), 0.0)))
+        kind, b0, b1 = mixed_cut(i, g, tau, rng)
+        so = orc_space.update(kind, g, b0, b1)
+        sg = gpu_space._update(kind, (g, beta_of(b0, b1)))
+        assert int(sg) == int(so), f"step {i}: status gpu={int(sg)} oracle={so}"
+        nsucc += int(so == 0)
+        if check_every and (i + 1) % check_every == 0:
+            assert_state_close(gpu_space, orc_space, tol, what=f"step {i}")
+    return nsucc
+
+
+def beta_of(b0, b1):
+    return float(b0) if b1 is None else (float(b0), float(b1))
