@@ -1,0 +1,260 @@
+#!/usr/bin/env python3
+"""bench.py -- ellipsoid updates/sec on MI355X (BASELINE.json metric), one JSON line on stdout.
+
+A "step" is one ellipsoid update (Ell::update_core, src/ell.rs:97-137) = GEMV pass + scalar stage +
+rank-1 pass over the n*n f64 matrix, driven from a device-resident queue of synthetic cuts
+(SURVEY.md 8d), so all inputs are in HBM when the timed region starts.
+
+  python bench.py --gpus 1 --steps 200 --warmup 20
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+         --master-port P bench.py --gpus N --steps K --warmup W
+
+N > 1: Q is row-block partitioned over the ranks (same n: strong scaling); every update does one
+in-place RCCL all-gather of the n-vector Q*g between the two passes.
+
+Besides the contract fields the line carries
+  roofline     : HBM roofline of the dominant kernel (k_rank1, 16*n^2 algorithmic bytes per launch),
+                 its duration measured with HIP events on the launch stream; per-kernel and
+                 whole-update (24*n^2 B) figures alongside.
+  cpu_baseline : the CPU oracle (reference loop order, 1 thread) timed on this box, rank 0, N = 1.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+WORKLOADS = {
+    # name: (n, variant, cut generator, description)
+    "n16384-parallel": (16384, "ell", "parallel", "config 3: n=16384 Ell, alternating parallel-central / parallel-bias cuts"),
+    "n16384-deep": (16384, "ell", "deep", "n=16384 Ell, deep cuts beta~U[0,0.1)"),
+    "n4096-deep": (4096, "ell", "deep", "config 2: n=4096 Ell, deep cuts (Q=128 MiB fits the 256 MiB Infinity Cache)"),
+    "n8192-deep": (8192, "ell", "deep", "n=8192 Ell, deep cuts"),
+    "n32768-deep": (32768, "ell", "deep", "config 4: n=32768 Ell, deep cuts (8 GiB Q)"),
+    "n16384-ellstable": (16384, "ellstable", "deep", "config 5: n=16384 EllStable, deep cuts"),
+    "n4096-ellstable": (4096, "ellstable", "deep", "n=4096 EllStable, deep cuts"),
+}
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def cpu_baseline(n: int, variant: str, kinds, grads, b0, b1, budget_s: float = 20.0):
+    """Time the oracle (1 thread, reference loop order incl. the strided mirror stores) on a bounded
+    sample of the same cut stream."""
+    from oracle import oracle
+    cls = oracle.OracleEll if variant == "ell" else oracle.OracleEllStable
+    t0 = time.perf_counter()
+    o = cls.new_with_scalar(1.0, np.zeros(n))
+    t_init = time.perf_counter() - t0
+    done, t_used = 0, 0.0
+    while done < len(kinds) and (done < 2 or t_used < budget_s):
+        i = done
+        t1 = time.perf_counter()
+        st = o.update(int(kinds[i]), grads[i], float(b0[i]), None if np.isnan(b1[i]) else float(b1[i]))
+        t_used += time.perf_counter() - t1
+        assert st == 0, f"oracle cut {i} status {st}"
+        done += 1
+        if t_used / done * (done + 1) > budget_s and done >= 2:
+            break
+    return {
+        "value": done / t_used,
+        "unit": "updates/s",
+        "cores": 1,
+        "kind": "port",
+        "sample": f"{done} updates at n={n} ({variant}), same cut stream, oracle/ell_oracle.c -O3 -ffp-contract=off, "
+                  f"{t_used:.1f} s (+{t_init:.1f} s init)",
+        "host_cpus": os.cpu_count(),
+    }
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default=os.environ.get("ELLHIP_BENCH_WORKLOAD", "n16384-parallel"),
+                    choices=sorted(WORKLOADS))
+    ap.add_argument("--profile-steps", type=int, default=40, help="extra steps with per-kernel HIP events")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=20.0)
+    ap.add_argument("--host-path-steps", type=int, default=20,
+                    help="extra synchronous ellhip_update() calls from host buffers (PCIe-inclusive rate)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+        raise SystemExit(f"WORLD_SIZE={world} does not match --gpus {args.gpus}")
+
+    import torch
+    import torch.distributed as dist
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device: the engine has no CPU path")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    import ellalgo_rs_amd as pkg
+    from ellalgo_rs_amd import synth
+
+    lib = pkg.capi.load()
+    n, variant, cutgen, desc = WORKLOADS[args.workload]
+    K, W, P = args.steps, args.warmup, args.profile_steps
+    H = args.host_path_steps if world == 1 else 0
+    total = W + K + P + H
+    if world > 1 and variant != "ell":
+        raise SystemExit("EllStable does not shard: replicas only (see DESIGN.md)")
+    if n % world:
+        raise SystemExit(f"n={n} is not divisible by {world} ranks")
+
+    t_gen = time.perf_counter()
+    kinds, grads, b0, b1 = (synth.parallel_cuts if cutgen == "parallel" else synth.deep_cuts)(n, total)
+    log(f"[rank {rank}] generated {total} cuts for {args.workload} in {time.perf_counter() - t_gen:.1f}s")
+
+    # ---- build the search space (Q0 = I, xc0 = 0, kappa0 = 1)
+    nrows = n // world
+    row0 = rank * nrows
+    if world == 1:
+        space = (pkg.Ell if variant == "ell" else pkg.EllStable).new_with_scalar(1.0, np.zeros(n), device=local_rank)
+        h = space._h
+    else:
+        from ellalgo_rs_amd.sharded import ShardedEll
+        space = ShardedEll.new_with_scalar(1.0, np.zeros(n), device=local_rank)
+        h = space._h
+    nq = W + K + P
+    space.queue_upload(kinds[:nq], grads[:nq], b0[:nq], b1[:nq])
+
+    def run(first: int, count: int) -> None:
+        space.queue_run(first, count)
+
+    def fence() -> None:
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    # ---- warm-up, then the timed region: EXACTLY K steps between two fences
+    run(0, W)
+    fence()
+    t0 = time.perf_counter()
+    run(W, K)
+    fence()
+    t1 = time.perf_counter()
+    elapsed = t1 - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- per-kernel durations with HIP events on the launch stream (outside the timed region)
+    prof = None
+    if P > 0:
+        space.profile_enable(True)
+        run(W + K, P)
+        space.synchronize()
+        prof = space.profile_read()
+        space.profile_enable(False)
+
+    status, tsqs = space.queue_results()
+    ran = W + K + P
+    ok = bool(np.all(status[:ran] == 0))
+    if not ok:
+        bad = int(np.argmax(status[:ran] != 0))
+        raise SystemExit(f"cut {bad} did not succeed (status {int(status[bad])}): benchmark invalid")
+    if cutgen == "parallel":
+        # the true parallel branch must have been taken: tsq > beta1^2 (src/ell_calc.rs:761,840)
+        assert bool(np.all(tsqs[:ran] > b1[:ran] ** 2)), "a parallel cut fell back to a single cut"
+
+    # ---- synchronous host-buffer path (PCIe-inclusive), N = 1 only
+    host_path = None
+    if H > 0:
+        t2 = time.perf_counter()
+        for i in range(nq, nq + H):
+            st = space._update(int(kinds[i]), (grads[i], (b0[i], None if np.isnan(b1[i]) else b1[i])))
+            assert int(st) == 0
+        host_path = {"updates_per_s": H / (time.perf_counter() - t2), "steps": H,
+                     "note": "ellhip_update() per call: pageable host grad in, status out, synchronous"}
+
+    if rank != 0:
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    bytes_update = 24.0 * n * n / world  # per GPU
+    ms_per_step = elapsed / K * 1e3
+    value = K / elapsed
+    roofline = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None}
+    per_kernel = {}
+    if prof:
+        alg = {"gemv": 8.0 * n * n / world, "rank1": 16.0 * n * n / world,
+               "stable_fwd": 8.0 * n * n, "stable_bwd": 4.0 * n * n, "stable_factor": 12.0 * n * n}
+        for name, (ms, cnt) in prof.items():
+            if cnt:
+                avg_ms = ms / cnt
+                e = {"avg_ms": avg_ms, "launches": cnt}
+                if name in alg:
+                    e["alg_bytes"] = alg[name]
+                    e["GBps"] = alg[name] / (avg_ms * 1e-3) / 1e9
+                per_kernel[name] = e
+        dom = "rank1" if variant == "ell" else max((k for k in per_kernel if k in alg), key=lambda k: per_kernel[k]["avg_ms"])
+        if dom in per_kernel:
+            roofline.update({"kernel": "k_" + dom, "achieved": per_kernel[dom]["GBps"],
+                             "frac": per_kernel[dom]["GBps"] / HBM_PEAK_GBS,
+                             "alg_bytes_per_launch": per_kernel[dom]["alg_bytes"],
+                             "avg_launch_ms": per_kernel[dom]["avg_ms"]})
+    upd_gbps = bytes_update / (ms_per_step * 1e-3) / 1e9
+    roofline["per_kernel"] = per_kernel
+    roofline["whole_update"] = {"alg_bytes_per_gpu": bytes_update, "GBps_per_gpu": upd_gbps,
+                                "frac": upd_gbps / HBM_PEAK_GBS}
+    if "achieved" not in roofline:
+        roofline.update({"kernel": "whole_update", "achieved": upd_gbps, "frac": upd_gbps / HBM_PEAK_GBS})
+
+    out = {
+        "metric": "ellipsoid updates/sec at n=%d; achieved HBM GB/s vs peak" % n,
+        "value": value,
+        "unit": "updates/s",
+        "n_gpus": world,
+        "steps": K,
+        "warmup": W,
+        "ms_per_step": ms_per_step,
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {"workload": args.workload, "n": n, "space": variant, "cuts": cutgen,
+                   "description": desc, "partition": f"row-block x{world}" if world > 1 else "none",
+                   "q_bytes_per_gpu": 8.0 * n * n / world},
+        "roofline": roofline,
+    }
+    if host_path:
+        out["host_call_path"] = host_path
+    if world == 1 and not args.no_cpu_baseline:
+        log("[rank 0] timing the CPU oracle (bounded sample) ...")
+        out["cpu_baseline"] = cpu_baseline(n, variant, kinds, grads, b0, b1, args.cpu_budget)
+    print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

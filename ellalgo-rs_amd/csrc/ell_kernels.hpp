@@ -74,6 +74,18 @@ struct VecT<2> {
     }
 };
 
+// Streaming accesses: NT selects the non-temporal (`nt`) cache policy for the once-touched Q stream.
+template <bool NT, typename V>
+__device__ __forceinline__ V ld_stream(const double* p) {
+    if constexpr (NT) return __builtin_nontemporal_load(reinterpret_cast<const V*>(p));
+    else return *reinterpret_cast<const V*>(p);
+}
+template <bool NT, typename V>
+__device__ __forceinline__ void st_stream(double* p, const V& v) {
+    if constexpr (NT) __builtin_nontemporal_store(v, reinterpret_cast<V*>(p));
+    else *reinterpret_cast<V*>(p) = v;
+}
+
 __device__ __forceinline__ double wave_allreduce_sum(double v) {
     // fixed xor butterfly over the 64 lanes: every lane ends with the same bits
 #pragma unroll
@@ -83,7 +95,7 @@ __device__ __forceinline__ double wave_allreduce_sum(double v) {
 
 // ------------------------------------------------------------------------------------ k_gemv ---
 // gt_out[r] = sum_c Q[r*ld + c] * g[c], r in [0, nrows).  grid.x = ceil(nrows / (4*RW)).
-template <int RW, int UNR, int VEC>
+template <int RW, int UNR, int VEC, bool NT = false>
 __global__ __launch_bounds__(256) void k_gemv(const double* __restrict__ Q, long long ld, long long n,
                                               long long nrows, const double* __restrict__ g,
                                               double* __restrict__ gt_out,
@@ -116,7 +128,7 @@ __global__ __launch_bounds__(256) void k_gemv(const double* __restrict__ Q, long
         for (int u = 0; u < UNR; ++u) {
             gv[u] = *reinterpret_cast<const V*>(g + c + u * STEP);
 #pragma unroll
-            for (int r = 0; r < RW; ++r) qv[u][r] = *reinterpret_cast<const V*>(rp[r] + c + u * STEP);
+            for (int r = 0; r < RW; ++r) qv[u][r] = ld_stream<NT, V>(rp[r] + c + u * STEP);
         }
 #pragma unroll
         for (int u = 0; u < UNR; ++u)
@@ -130,7 +142,7 @@ __global__ __launch_bounds__(256) void k_gemv(const double* __restrict__ Q, long
         const V gv = *reinterpret_cast<const V*>(g + c);
 #pragma unroll
         for (int r = 0; r < RW; ++r) {
-            const V qv = *reinterpret_cast<const V*>(rp[r] + c);
+            const V qv = ld_stream<NT, V>(rp[r] + c);
 #pragma unroll
             for (int v = 0; v < VEC; ++v) acc[r] += VecT<VEC>::get(qv, v) * VecT<VEC>::get(gv, v);
         }
@@ -210,11 +222,12 @@ __global__ __launch_bounds__(1024) void k_scalar(long long n, const double* __re
 }
 
 // ----------------------------------------------------------------------------------- k_rank1 ---
-// Q[r][c] -= (ratio*gt[hi])*gt[lo] (then * scale if SCALE) for the local rows; row0 = global index
+// Qout[r][c] = Q[r][c] - (ratio*gt[hi])*gt[lo] (then * scale if SCALE) for the local rows (Qout may be
+// Q itself: every element is read and written by the same lane); row0 = global index
 // of local row 0 (row-partitioned multi-GPU).  grid.x = ceil(nrows / (4*RW)); tiles are walked in
 // reverse block order (see header comment).
-template <int RW, int UNR, int VEC, bool SCALE>
-__global__ __launch_bounds__(256) void k_rank1(double* __restrict__ Q, long long ld, long long n,
+template <int RW, int UNR, int VEC, bool SCALE, bool NT = false, bool REVERSE = true>
+__global__ __launch_bounds__(256) void k_rank1(const double* Q, double* Qout, long long ld, long long n,
                                                long long nrows, long long row0,
                                                const double* __restrict__ gt,
                                                const DevState* __restrict__ st) {
@@ -224,11 +237,12 @@ __global__ __launch_bounds__(256) void k_rank1(double* __restrict__ Q, long long
     const double scale = st->scale;
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    const long long tile = (long long)gridDim.x - 1 - blockIdx.x;
+    const long long tile = REVERSE ? (long long)gridDim.x - 1 - blockIdx.x : (long long)blockIdx.x;
     const long long row_base = (tile * 4 + wave) * RW;
     if (row_base >= nrows) return;
 
-    double* rp[RW];
+    const double* rp[RW];
+    double* wp[RW];
     long long grow[RW];
     double gtr[RW], rgr[RW];
     bool valid[RW];
@@ -238,6 +252,7 @@ __global__ __launch_bounds__(256) void k_rank1(double* __restrict__ Q, long long
         valid[r] = rr < nrows;
         if (!valid[r]) rr = nrows - 1;
         rp[r] = Q + rr * ld;
+        wp[r] = Qout + rr * ld;
         grow[r] = row0 + rr;
         gtr[r] = gt[grow[r]];
         rgr[r] = ratio * gtr[r];  // r_qg of src/ell.rs:119
@@ -253,7 +268,7 @@ __global__ __launch_bounds__(256) void k_rank1(double* __restrict__ Q, long long
         for (int u = 0; u < UNR; ++u) {
             gv[u] = *reinterpret_cast<const V*>(gt + c + u * STEP);
 #pragma unroll
-            for (int r = 0; r < RW; ++r) qv[u][r] = *reinterpret_cast<const V*>(rp[r] + c + u * STEP);
+            for (int r = 0; r < RW; ++r) qv[u][r] = ld_stream<NT, V>(rp[r] + c + u * STEP);
         }
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {
@@ -269,7 +284,7 @@ __global__ __launch_bounds__(256) void k_rank1(double* __restrict__ Q, long long
                     if (SCALE) x = x * scale;                       // src/ell.rs:133
                     VecT<VEC>::set(o, v, x);
                 }
-                if (valid[r]) *reinterpret_cast<V*>(rp[r] + c + u * STEP) = o;
+                if (valid[r]) st_stream<NT, V>(wp[r] + c + u * STEP, o);
             }
         }
     }
@@ -277,7 +292,7 @@ __global__ __launch_bounds__(256) void k_rank1(double* __restrict__ Q, long long
         const V gv = *reinterpret_cast<const V*>(gt + c);
 #pragma unroll
         for (int r = 0; r < RW; ++r) {
-            const V qv = *reinterpret_cast<const V*>(rp[r] + c);
+            const V qv = ld_stream<NT, V>(rp[r] + c);
             V o;
 #pragma unroll
             for (int v = 0; v < VEC; ++v) {
@@ -288,7 +303,7 @@ __global__ __launch_bounds__(256) void k_rank1(double* __restrict__ Q, long long
                 if (SCALE) x = x * scale;
                 VecT<VEC>::set(o, v, x);
             }
-            if (valid[r]) *reinterpret_cast<V*>(rp[r] + c) = o;
+            if (valid[r]) st_stream<NT, V>(wp[r] + c, o);
         }
     }
 }

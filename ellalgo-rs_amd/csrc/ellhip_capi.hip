@@ -96,6 +96,7 @@ struct ellhip_space {
 
     // launch shape (tunable through the environment for experiments)
     int rw_gemv = 0, unr_gemv = 0, rw_rank1 = 0, unr_rank1 = 0;
+    int nt_gemv = 0, nt_rank1 = 0;  // non-temporal cache policy on the Q stream
 };
 
 namespace {
@@ -154,28 +155,37 @@ struct ProfScope {
 };
 
 // ---- launch-shape selection ------------------------------------------------------------------
-// A workgroup covers 4*RW rows.  Aim for >= ~4 workgroups per CU (1024 on 256 CUs) so every CU
-// keeps 16 waves of 16-byte loads in flight; below that, shrink RW and unroll deeper instead.
+// A workgroup covers 4*RW rows; each lane keeps RW*UNR 16-byte loads in flight.  Defaults come from
+// in-process A/B sweeps on MI355X (tools/tune_ell.hip, numbers in DESIGN.md):
+//   * local Q block fits the 256 MiB Infinity Cache (n = 4096: 128 MiB): keep the default cache
+//     policy so the other pass finds Q on-die, 4 rows per workgroup, deep unroll;
+//   * larger: the Q stream is touched once per pass, so use the non-temporal policy (GEMV 4.8 ->
+//     6.3 TB/s at n = 16384) and more rows per wave.
 void pick_shape(ellhip_space* s) {
-    const long long nr = s->nrows;
-    int rw = 4;
-    if (nr < 16384) rw = 2;
-    if (nr < 8192) rw = 1;
-    int unr = (rw == 4) ? 2 : (rw == 2 ? 4 : 4);
-    s->rw_gemv = env_int("ELLHIP_GEMV_RW", rw);
-    s->unr_gemv = env_int("ELLHIP_GEMV_UNR", unr);
-    s->rw_rank1 = env_int("ELLHIP_RANK1_RW", rw);
+    const double q_bytes = (double)s->nrows * (double)s->ld * 8.0;
+    const bool fits_mall = q_bytes <= 200.0 * 1024 * 1024;
+    int rwg, ung, rwr, unr, ntg, ntr;
+    if (fits_mall) {
+        rwg = 1; ung = 4; rwr = 1; unr = 8; ntg = 0; ntr = 0;
+    } else {
+        rwg = 4; ung = 4; rwr = 2; unr = 4; ntg = 1; ntr = 1;
+    }
+    s->rw_gemv = env_int("ELLHIP_GEMV_RW", rwg);
+    s->unr_gemv = env_int("ELLHIP_GEMV_UNR", ung);
+    s->rw_rank1 = env_int("ELLHIP_RANK1_RW", rwr);
     s->unr_rank1 = env_int("ELLHIP_RANK1_UNR", unr);
+    s->nt_gemv = env_int("ELLHIP_GEMV_NT", ntg);
+    s->nt_rank1 = env_int("ELLHIP_RANK1_NT", ntr);
 }
 
-template <int VEC>
+template <int VEC, bool NT>
 int launch_gemv_v(ellhip_space* s, const double* g, double* gt_out) {
     const long long nr = s->nrows;
     const int rw = s->rw_gemv, unr = s->unr_gemv;
     const unsigned grid = (unsigned)((nr + 4LL * rw - 1) / (4LL * rw));
 #define GEMV_CASE(RW, UNR)                                                                       \
     if (rw == RW && unr == UNR) {                                                                \
-        hipLaunchKernelGGL((k_gemv<RW, UNR, VEC>), dim3(grid), dim3(256), 0, s->stream, s->d_Q,  \
+        hipLaunchKernelGGL((k_gemv<RW, UNR, VEC, NT>), dim3(grid), dim3(256), 0, s->stream, s->d_Q,  \
                            s->ld, s->n, nr, g, gt_out, s->d_st);                                 \
         return 0;                                                                                \
     }
@@ -190,21 +200,25 @@ int launch_gemv_v(ellhip_space* s, const double* g, double* gt_out) {
 int launch_gemv(ellhip_space* s, const double* g) {
     ProfScope ps(s, 0);
     double* gt_out = s->d_gt + s->row0;
-    int rc = (s->n % 2 == 0) ? launch_gemv_v<2>(s, g, gt_out) : launch_gemv_v<1>(s, g, gt_out);
+    int rc;
+    if (s->n % 2 == 0)
+        rc = s->nt_gemv ? launch_gemv_v<2, true>(s, g, gt_out) : launch_gemv_v<2, false>(s, g, gt_out);
+    else
+        rc = launch_gemv_v<1, false>(s, g, gt_out);
     if (rc) return rc;
     HIPCHK(hipGetLastError());
     return 0;
 }
 
-template <int VEC, bool SCALE>
+template <int VEC, bool SCALE, bool NT>
 int launch_rank1_v(ellhip_space* s) {
     const long long nr = s->nrows;
     const int rw = s->rw_rank1, unr = s->unr_rank1;
     const unsigned grid = (unsigned)((nr + 4LL * rw - 1) / (4LL * rw));
 #define RANK1_CASE(RW, UNR)                                                                          \
     if (rw == RW && unr == UNR) {                                                                    \
-        hipLaunchKernelGGL((k_rank1<RW, UNR, VEC, SCALE>), dim3(grid), dim3(256), 0, s->stream,      \
-                           s->d_Q, s->ld, s->n, nr, s->row0, s->d_gt, s->d_st);                      \
+        hipLaunchKernelGGL((k_rank1<RW, UNR, VEC, SCALE, NT>), dim3(grid), dim3(256), 0, s->stream,      \
+                           s->d_Q, s->d_Q, s->ld, s->n, nr, s->row0, s->d_gt, s->d_st);              \
         return 0;                                                                                    \
     }
     RANK1_CASE(1, 1) RANK1_CASE(1, 2) RANK1_CASE(1, 4) RANK1_CASE(1, 8)
@@ -225,10 +239,13 @@ int launch_rank1(ellhip_space* s) {
     ProfScope ps(s, 2);
     int rc;
     const bool even = s->n % 2 == 0;
+    const bool nt = even && s->nt_rank1;
     if (s->no_defer_trick)
-        rc = even ? launch_rank1_v<2, true>(s) : launch_rank1_v<1, true>(s);
+        rc = even ? (nt ? launch_rank1_v<2, true, true>(s) : launch_rank1_v<2, true, false>(s))
+                  : launch_rank1_v<1, true, false>(s);
     else
-        rc = even ? launch_rank1_v<2, false>(s) : launch_rank1_v<1, false>(s);
+        rc = even ? (nt ? launch_rank1_v<2, false, true>(s) : launch_rank1_v<2, false, false>(s))
+                  : launch_rank1_v<1, false, false>(s);
     if (rc) return rc;
     HIPCHK(hipGetLastError());
     return 0;
@@ -341,7 +358,9 @@ int create_impl(ellhip_space** out, int variant, long long n, long long row0, lo
     // Leading dimension: keep 16-byte row alignment for even n; break the power-of-two row pitch
     // (all rows of a tile on one HBM channel group) with one extra 128-byte line per row.
     s->ld = n;
-    if (n >= 1024 && (n % 512) == 0 && env_int("ELLHIP_PAD", 0)) s->ld = n + 16;
+    if ((n % 512) == 0 && (double)nrows * (double)n * 8.0 > 200.0 * 1024 * 1024) s->ld = n + 16;
+    s->ld = n + env_int("ELLHIP_PAD", (int)(s->ld - n));
+    if ((n % 2) == 0 && (s->ld % 2) != 0) s->ld += 1;
     pick_shape(s);
 
     DeviceGuard guard(device);
@@ -498,6 +517,8 @@ int ellhip_clone(const ellhip_space* src, ellhip_space** out) {
     s->unr_gemv = src->unr_gemv;
     s->rw_rank1 = src->rw_rank1;
     s->unr_rank1 = src->unr_rank1;
+    s->nt_gemv = src->nt_gemv;
+    s->nt_rank1 = src->nt_rank1;
     DeviceGuard guard(s->device);
     int rc = alloc_common(s);
     if (rc) {

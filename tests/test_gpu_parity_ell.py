@@ -189,11 +189,11 @@ def test_mixed_sequence_matches_oracle(gpu, orc, n):
     assert_state_close(g, o, what=f"n={n} final")
 
 
-@pytest.mark.parametrize("n", [2048, 4096])
+@pytest.mark.parametrize("n", [2048, 4096, 8192])
 def test_deep_cuts_large_matches_oracle(gpu, orc, n):
     """Config-2 style deep cuts at a size where a Q row spans many wave steps."""
     from ellalgo_rs_amd import synth
-    kinds, grads, b0, _ = synth.deep_cuts(n, 6)
+    kinds, grads, b0, _ = synth.deep_cuts(n, 6)   # n = 8192 exercises the padded leading dimension + nt policy
     g = gpu.Ell.new_with_scalar(1.0, np.zeros(n))
     o = orc.OracleEll.new_with_scalar(1.0, np.zeros(n))
     for i in range(6):
