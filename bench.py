@@ -220,6 +220,14 @@ def main() -> None:
                              "frac": per_kernel[dom]["GBps"] / HBM_PEAK_GBS,
                              "alg_bytes_per_launch": per_kernel[dom]["alg_bytes"],
                              "avg_launch_ms": per_kernel[dom]["avg_ms"]})
+    try:  # measured HBM traffic per launch (PMC counters, collected separately under rocprofv3)
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            pmc = json.load(f).get(args.workload)
+        if pmc and world == 1 and roofline.get("kernel", "").startswith("k_"):
+            roofline["traffic"] = pmc.get(roofline["kernel"][2:])
+            roofline["traffic_source"] = pmc.get("source")
+    except OSError:
+        pass
     upd_gbps = bytes_update / (ms_per_step * 1e-3) / 1e9
     roofline["per_kernel"] = per_kernel
     roofline["whole_update"] = {"alg_bytes_per_gpu": bytes_update, "GBps_per_gpu": upd_gbps,
