@@ -1,0 +1,40 @@
+"""GPU: the same end-to-end cases through the C++ host drivers with the MI355X engine as the search
+space (C ABI); iteration counts must equal the reference's pins and solutions must match the
+oracle-backed run."""
+import numpy as np
+import pytest
+
+import pins
+from cpp_build import build_runner, run_json_lines
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def results(gpu):
+    return run_json_lines(build_runner("pins_runner.cpp", "hip"))
+
+
+@pytest.fixture(scope="module")
+def results_oracle():
+    return run_json_lines(build_runner("pins_runner.cpp", "oracle"))
+
+
+@pytest.mark.parametrize("case", sorted(pins.PINNED))
+def test_pinned_case_hip_backend(results, case):
+    pins.check_case(case, results[case])
+
+
+def test_pinned_extra_assertions(results):
+    pins.check_extra(results)
+
+
+def test_solutions_match_oracle_backend(results, results_oracle):
+    for case, want in results_oracle.items():
+        got = results[case]
+        assert got["niter"] == want["niter"], case
+        assert got["has_x"] == want["has_x"] and got["flag"] == want["flag"], case
+        if want["x"]:
+            np.testing.assert_allclose(got["x"], want["x"], rtol=1e-9, atol=1e-12, err_msg=case)
+        if want["gamma"]:
+            assert abs(got["gamma"] - want["gamma"]) <= 1e-9 * abs(want["gamma"]), case
