@@ -80,6 +80,12 @@ def cpu_baseline(n: int, variant: str, kinds, grads, b0, b1, budget_s: float = 2
 
 
 def main() -> None:
+    # The contract is ONE JSON line on stdout.  Native libraries (RCCL prints a version banner) write to
+    # fd 1 directly, so park the real stdout and point fd 1 at stderr for the rest of the run.
+    sys.stdout.flush()
+    real_stdout = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
@@ -91,6 +97,8 @@ def main() -> None:
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     ap.add_argument("--host-path-steps", type=int, default=20,
                     help="extra synchronous ellhip_update() calls from host buffers (PCIe-inclusive rate)")
+    ap.add_argument("--force-sharded", action="store_true",
+                    help="run the row-partitioned (multi-GPU) code path even with one rank (rehearsal)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -107,9 +115,12 @@ def main() -> None:
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the engine has no CPU path")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    sharded = world > 1 or args.force_sharded
+    if sharded:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        os.environ.setdefault("MASTER_PORT", "29531")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
 
     import ellalgo_rs_amd as pkg
     from ellalgo_rs_amd import synth
@@ -117,9 +128,9 @@ def main() -> None:
     lib = pkg.capi.load()
     n, variant, cutgen, desc = WORKLOADS[args.workload]
     K, W, P = args.steps, args.warmup, args.profile_steps
-    H = args.host_path_steps if world == 1 else 0
+    H = args.host_path_steps if not sharded else 0
     total = W + K + P + H
-    if world > 1 and variant != "ell":
+    if sharded and variant != "ell":
         raise SystemExit("EllStable does not shard: replicas only (see DESIGN.md)")
     if n % world:
         raise SystemExit(f"n={n} is not divisible by {world} ranks")
@@ -131,13 +142,11 @@ def main() -> None:
     # ---- build the search space (Q0 = I, xc0 = 0, kappa0 = 1)
     nrows = n // world
     row0 = rank * nrows
-    if world == 1:
+    if not sharded:
         space = (pkg.Ell if variant == "ell" else pkg.EllStable).new_with_scalar(1.0, np.zeros(n), device=local_rank)
-        h = space._h
     else:
         from ellalgo_rs_amd.sharded import ShardedEll
         space = ShardedEll.new_with_scalar(1.0, np.zeros(n), device=local_rank)
-        h = space._h
     nq = W + K + P
     space.queue_upload(kinds[:nq], grads[:nq], b0[:nq], b1[:nq])
 
@@ -146,7 +155,7 @@ def main() -> None:
 
     def fence() -> None:
         torch.cuda.synchronize()
-        if world > 1:
+        if sharded:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -158,7 +167,7 @@ def main() -> None:
     fence()
     t1 = time.perf_counter()
     elapsed = t1 - t0
-    if world > 1:
+    if sharded:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -193,9 +202,8 @@ def main() -> None:
                      "note": "ellhip_update() per call: pageable host grad in, status out, synchronous"}
 
     if rank != 0:
-        if world > 1:
-            dist.barrier()
-            dist.destroy_process_group()
+        dist.barrier()
+        dist.destroy_process_group()
         return
 
     bytes_update = 24.0 * n * n / world  # per GPU
@@ -258,8 +266,8 @@ def main() -> None:
     if world == 1 and not args.no_cpu_baseline:
         log("[rank 0] timing the CPU oracle (bounded sample) ...")
         out["cpu_baseline"] = cpu_baseline(n, variant, kinds, grads, b0, b1, args.cpu_budget)
-    print(json.dumps(out), flush=True)
-    if world > 1:
+    print(json.dumps(out), file=real_stdout, flush=True)
+    if sharded:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -261,10 +261,53 @@ int launch_scalar(ellhip_space* s, const double* g, const CutParams* cp, int que
     return 0;
 }
 
+// EllStable::update_core as a fixed sequence of launches (ellstable_kernels.hpp).
 int ellstable_issue(ellhip_space* s, const double* g_dev, const CutParams* cp_dev, int queue_mode, int* qst,
                     double* qtsq) {
-    (void)s; (void)g_dev; (void)cp_dev; (void)queue_mode; (void)qst; (void)qtsq;
-    return fail(ELLHIP_E_INVALID, "EllStable kernels not built yet");
+    const long long n = s->n, ld = s->ld;
+    const long long nb = (n + SB - 1) / SB;
+    double* w = s->d_work;
+    double* z = w + n;
+    double* gg = z + n;
+    double* q = gg + n;
+    double* beta2 = q + n;
+    hipStream_t st = s->stream;
+    {
+        ProfScope ps(s, 3);
+        HIPCHK(hipMemcpyAsync(w, g_dev, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, st));
+        hipLaunchKernelGGL(k_st_fwd_first, dim3(1), dim3(64), 0, st, s->d_Q, ld, n, g_dev, w, z, gg, s->d_st);
+        for (long long kb = 0; kb + 1 < nb; ++kb) {
+            const long long rest = n - (kb + 1) * SB;
+            const unsigned grid = (unsigned)((rest + SPANEL - 1) / SPANEL);
+            hipLaunchKernelGGL(k_st_fwd_step, dim3(grid), dim3(256), 0, st, s->d_Q, ld, n, kb, w, z, gg, s->d_st);
+        }
+        HIPCHK(hipGetLastError());
+    }
+    {
+        ProfScope ps(s, 1);
+        EllCalcDev calc = EllCalcDev::make(n, s->use_parallel_cut);
+        hipLaunchKernelGGL(k_st_mid, dim3(1), dim3(1024), 0, st, s->d_Q, ld, n, z, gg, q, beta2, s->d_st, calc,
+                           cp_dev, queue_mode, qst, qtsq);
+        HIPCHK(hipGetLastError());
+    }
+    {
+        ProfScope ps(s, 4);
+        hipLaunchKernelGGL(k_st_bwd_last, dim3(1), dim3(64), 0, st, s->d_Q, ld, n, nb - 1, q, s->d_st);
+        for (long long kb = nb - 1; kb >= 1; --kb) {
+            const unsigned grid = (unsigned)((kb * SB + SPANEL - 1) / SPANEL);
+            hipLaunchKernelGGL(k_st_bwd_step, dim3(grid), dim3(256), 0, st, s->d_Q, ld, n, kb, q, s->d_st);
+        }
+        const unsigned gx = (unsigned)((n + 255) / 256);
+        hipLaunchKernelGGL(k_st_xc, dim3(gx < 256 ? gx : 256), dim3(256), 0, st, n, q, s->d_xc, s->d_st);
+        HIPCHK(hipGetLastError());
+    }
+    {
+        ProfScope ps(s, 5);
+        hipLaunchKernelGGL(k_st_factor, dim3((unsigned)nb, (unsigned)nb), dim3(256), 0, st, s->d_Q, ld, n, beta2,
+                           s->d_st);
+        HIPCHK(hipGetLastError());
+    }
+    return 0;
 }
 
 // ---- one cut, phase 1 / phase 2, for either variant ------------------------------------------
@@ -361,6 +404,7 @@ int create_impl(ellhip_space** out, int variant, long long n, long long row0, lo
     if ((n % 512) == 0 && (double)nrows * (double)n * 8.0 > 200.0 * 1024 * 1024) s->ld = n + 16;
     s->ld = n + env_int("ELLHIP_PAD", (int)(s->ld - n));
     if ((n % 2) == 0 && (s->ld % 2) != 0) s->ld += 1;
+    if (variant == ELLHIP_SPACE_ELL_STABLE) s->ld = n + (n & 1);  // 16-byte aligned rows for the 2-column lanes
     pick_shape(s);
 
     DeviceGuard guard(device);

@@ -4,65 +4,152 @@ One process per GPU (`torch.distributed`, backend "nccl" = RCCL over xGMI).  Ran
 [r*n/P, (r+1)*n/P) of Q; every rank keeps full copies of g, gt = Q*g, xc and the scalars.  One
 update is
 
-    phase 1  local GEMV                gt[R_r] = Q[R_r, :] * g            (ellhip_*_begin)
+    phase 1  local GEMV                gt[R_r] = Q[R_r, :] * g            (engine.begin)
     exchange in-place all-gather of gt (n/P doubles per rank)             (the ONLY collective)
     phase 2  redundant scalar stage (omega, tsq, EllCalc, xc, kappa: identical bits on every rank,
-             fixed reduction shapes) + rank-1 update of the local rows    (ellhip_*_end)
+             fixed reduction shapes) + rank-1 update of the local rows    (engine.end)
 
-The exchange primitive is injected (`exchange(gt_tensor, row0, nrows)`), so the orchestration is the
-same code over RCCL on GPUs and in the world_size-2 gloo tests.  All HIP work and the collective
-are issued on one non-default torch stream, so they are ordered without host synchronisation.
+The per-rank engine and the exchange primitive are injected, so the orchestration below is the same
+code over the HIP engine + RCCL on GPUs and in the world_size-2 gloo tests on CPU (where the tests
+supply an oracle-backed engine; this module itself never imports the oracle and its default engine
+is the HIP library, which fails loudly without a GPU).
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
 
 import numpy as np
 
 from . import capi
-from .ell import CutStatus, _SpaceBase, _f64, _p, _split
+from .ell import CutStatus, _f64, _p, _split
 
 
 def partition(n: int, world: int, rank: int):
     """Contiguous equal row blocks; n must divide evenly so the all-gather is uniform."""
+    if world < 1 or not (0 <= rank < world):
+        raise ValueError(f"bad rank {rank} of {world}")
     if n % world:
         raise ValueError(f"n={n} is not divisible by world size {world}")
     nrows = n // world
     return rank * nrows, nrows
 
 
-def _rccl_exchange(gt, row0, nrows):
+def allgather_in_place(gt, row0: int, nrows: int) -> None:
+    """Assemble the full gt on every rank: rank r contributes gt[row0:row0+nrows] (its own rows).
+    With the nccl backend this is one ncclAllGather over xGMI, in place (send = recv + rank*count)."""
     import torch.distributed as dist
     dist.all_gather_into_tensor(gt, gt[row0:row0 + nrows])
 
 
-class ShardedEll(_SpaceBase):
-    """`Ell` whose matrix is spread over the ranks of the default process group."""
+class HipShardEngine:
+    """One rank's row block in HBM, driven through the two-phase C ABI (include/ellhip.h)."""
 
-    def __init__(self, kappa, mq_rows, xc, *, diag=None, device=-1, exchange=None, rank=None, world=None):
+    def __init__(self, n, row0, nrows, kappa, mq_rows, diag, xc, device=-1):
         import torch
-        import torch.distributed as dist
         self._lib = capi.load()
-        self.rank = dist.get_rank() if rank is None else rank
-        self.world = dist.get_world_size() if world is None else world
-        xc = _f64(xc)
-        self.n = int(xc.size)
-        self.row0, self.nrows = partition(self.n, self.world, self.rank)
-        mq_rows = None if mq_rows is None else _f64(mq_rows, self.nrows * self.n)
-        diag = None if diag is None else _f64(diag, self.n)
+        self.n, self.row0, self.nrows = n, row0, nrows
         h = C.c_void_p()
-        capi.check(self._lib.ellhip_create_shard(C.byref(h), self.n, self.row0, self.nrows, float(kappa),
-                                                 _p(mq_rows), _p(diag), _p(xc), device), "ellhip_create_shard")
-        self._h = h
+        capi.check(self._lib.ellhip_create_shard(C.byref(h), n, row0, nrows, float(kappa), _p(mq_rows), _p(diag),
+                                                 _p(xc), device), "ellhip_create_shard")
+        self.h = h
         self._torch = torch
         dev = torch.device("cuda", torch.cuda.current_device() if device < 0 else device)
-        # the gt buffer lives in a tensor the collective library can address
-        self._gt = torch.zeros(self.n, dtype=torch.float64, device=dev)
-        self._stream = torch.cuda.Stream(device=dev)
+        # gt lives in a tensor the collective library can address; all HIP work and the collective are
+        # issued on one non-default torch stream, so they are ordered without host synchronisation
+        self.gt = torch.zeros(n, dtype=torch.float64, device=dev)
+        self.stream = torch.cuda.Stream(device=dev)
         torch.cuda.synchronize(dev)
-        capi.check(self._lib.ellhip_set_gt_dev(self._h, C.c_void_p(self._gt.data_ptr())))
-        capi.check(self._lib.ellhip_set_stream(self._h, C.c_void_p(self._stream.cuda_stream)))
-        self._exchange = exchange or _rccl_exchange
+        capi.check(self._lib.ellhip_set_gt_dev(h, C.c_void_p(self.gt.data_ptr())))
+        capi.check(self._lib.ellhip_set_stream(h, C.c_void_p(self.stream.cuda_stream)))
+
+    def issue(self):
+        return self._torch.cuda.stream(self.stream)
+
+    def begin(self, kind, g, b0, has1, b1):
+        capi.check(self._lib.ellhip_update_begin(self.h, kind, _p(g), b0, has1, b1), "ellhip_update_begin")
+
+    def end(self) -> int:
+        return capi.check(self._lib.ellhip_update_end(self.h), "ellhip_update_end")
+
+    def queue_upload(self, k, kinds, grads, b0, has1, b1):
+        capi.check(self._lib.ellhip_queue_upload(self.h, k, _p(kinds), _p(grads), _p(b0), _p(has1), _p(b1)),
+                   "ellhip_queue_upload")
+
+    def queue_begin(self, i):
+        capi.check(self._lib.ellhip_queue_begin(self.h, i), "ellhip_queue_begin")
+
+    def queue_end(self, i):
+        capi.check(self._lib.ellhip_queue_end(self.h, i), "ellhip_queue_end")
+
+    def queue_results(self, k):
+        st = np.empty(k, dtype=np.int32)
+        ts = np.empty(k, dtype=np.float64)
+        capi.check(self._lib.ellhip_queue_results(self.h, _p(st), _p(ts)), "ellhip_queue_results")
+        return st, ts
+
+    def xc(self):
+        out = np.empty(self.n, dtype=np.float64)
+        capi.check(self._lib.ellhip_get_xc(self.h, _p(out)))
+        return out
+
+    def set_xc(self, x):
+        capi.check(self._lib.ellhip_set_xc(self.h, _p(x)))
+
+    def mq_rows(self):
+        out = np.empty((self.nrows, self.n), dtype=np.float64)
+        capi.check(self._lib.ellhip_get_mq(self.h, _p(out)))
+        return out
+
+    def kappa(self):
+        return self._lib.ellhip_kappa(self.h)
+
+    def tsq(self):
+        return self._lib.ellhip_tsq(self.h)
+
+    def synchronize(self):
+        capi.check(self._lib.ellhip_synchronize(self.h))
+
+    def profile_enable(self, flag):
+        capi.check(self._lib.ellhip_profile_enable(self.h, int(flag)))
+
+    def profile_read(self):
+        ms = np.zeros(capi.NKERNEL_CLASSES, dtype=np.float64)
+        cnt = np.zeros(capi.NKERNEL_CLASSES, dtype=np.int64)
+        capi.check(self._lib.ellhip_profile_read(self.h, _p(ms), _p(cnt)))
+        return {name: (float(ms[i]), int(cnt[i])) for i, name in enumerate(capi.KERNEL_CLASS_NAMES)}
+
+    def close(self):
+        h, self.h = self.h, None
+        if h:
+            self._lib.ellhip_destroy(h)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class ShardedEll:
+    """`Ell` (src/ell.rs) whose matrix is spread by row blocks over the ranks of a process group.
+    Same SearchSpace surface as ellalgo_rs_amd.Ell; every rank must make the same calls."""
+
+    def __init__(self, kappa, mq_rows, xc, *, diag=None, device=-1, rank=None, world=None,
+                 engine_factory=None, exchange=None):
+        if rank is None or world is None:
+            import torch.distributed as dist
+            rank, world = dist.get_rank(), dist.get_world_size()
+        self.rank, self.world = rank, world
+        xc = _f64(xc)
+        self.n = int(xc.size)
+        self.row0, self.nrows = partition(self.n, world, rank)
+        mq_rows = None if mq_rows is None else _f64(mq_rows, self.nrows * self.n)
+        diag = None if diag is None else _f64(diag, self.n)
+        factory = engine_factory or (lambda *a: HipShardEngine(*a, device=device))
+        self.engine = factory(self.n, self.row0, self.nrows, float(kappa), mq_rows, diag, xc)
+        self._exchange = exchange or allgather_in_place
+        self._qk = 0
 
     @classmethod
     def new_with_scalar(cls, val, xc, **kw):
@@ -72,35 +159,83 @@ class ShardedEll(_SpaceBase):
     def new(cls, val, xc, **kw):
         return cls(1.0, None, xc, diag=val, **kw)
 
-    def clone(self):
-        raise NotImplementedError("clone a sharded space rank by rank with ellhip_clone")
+    @classmethod
+    def new_with_matrix(cls, kappa, mq_rows, xc, **kw):
+        """mq_rows: THIS rank's row block (nrows x n) of a symmetric matrix."""
+        return cls(kappa, mq_rows, xc, **kw)
 
+    def _issue(self):
+        return self.engine.issue() if hasattr(self.engine, "issue") else contextlib.nullcontext()
+
+    # ---- SearchSpace
     def _update(self, kind, cut) -> CutStatus:
         grad, beta = cut
         g = _f64(grad, self.n)
         b0, has1, b1 = _split(beta)
-        torch = self._torch
-        with torch.cuda.stream(self._stream):
-            capi.check(self._lib.ellhip_update_begin(self._h, kind, _p(g), b0, has1, b1), "ellhip_update_begin")
-            self._exchange(self._gt, self.row0, self.nrows)
-            return CutStatus(capi.check(self._lib.ellhip_update_end(self._h), "ellhip_update_end"))
+        with self._issue():
+            self.engine.begin(kind, g, b0, has1, b1)
+            self._exchange(self.engine.gt, self.row0, self.nrows)
+            return CutStatus(self.engine.end())
 
-    def queue_run(self, first: int, count: int) -> None:
-        torch = self._torch
-        lib, h = self._lib, self._h
-        with torch.cuda.stream(self._stream):
-            for i in range(first, first + count):
-                capi.check(lib.ellhip_queue_begin(h, i), "ellhip_queue_begin")
-                self._exchange(self._gt, self.row0, self.nrows)
-                capi.check(lib.ellhip_queue_end(h, i), "ellhip_queue_end")
+    def update_bias_cut(self, cut):
+        return self._update(capi.CUT_BIAS, cut)
+
+    def update_central_cut(self, cut):
+        return self._update(capi.CUT_CENTRAL, cut)
+
+    def update_q(self, cut):
+        return self._update(capi.CUT_Q, cut)
+
+    def xc(self):
+        return self.engine.xc()
+
+    def set_xc(self, x):
+        self.engine.set_xc(_f64(x, self.n))
+
+    def tsq(self):
+        return self.engine.tsq()
+
+    @property
+    def kappa(self):
+        return self.engine.kappa()
 
     @property
     def mq_rows(self) -> np.ndarray:
         """This rank's row block of Q."""
-        out = np.empty((self.nrows, self.n), dtype=np.float64)
-        capi.check(self._lib.ellhip_get_mq(self._h, _p(out)), "ellhip_get_mq")
-        return out
+        return self.engine.mq_rows()
 
-    @property
-    def mq(self):
-        raise AttributeError("a sharded space holds only mq_rows; gather them on the host if needed")
+    # ---- device-resident cut queue (every rank uploads the same cuts)
+    def queue_upload(self, kinds, grads, beta0, beta1=None) -> int:
+        grads = _f64(grads)
+        k = grads.size // self.n
+        kinds = np.ascontiguousarray(kinds, dtype=np.int32)
+        beta0 = _f64(beta0, k)
+        if beta1 is None:
+            has1, b1 = np.zeros(k, dtype=np.int32), np.zeros(k, dtype=np.float64)
+        else:
+            b1 = _f64(beta1, k).copy()
+            has1 = (~np.isnan(b1)).astype(np.int32)
+            b1[np.isnan(b1)] = 0.0
+        self.engine.queue_upload(k, kinds, grads, beta0, has1, b1)
+        self._qk = k
+        return k
+
+    def queue_run(self, first: int, count: int) -> None:
+        eng, ex, row0, nrows = self.engine, self._exchange, self.row0, self.nrows
+        with self._issue():
+            for i in range(first, first + count):
+                eng.queue_begin(i)
+                ex(eng.gt, row0, nrows)
+                eng.queue_end(i)
+
+    def queue_results(self):
+        return self.engine.queue_results(self._qk)
+
+    def synchronize(self):
+        self.engine.synchronize()
+
+    def profile_enable(self, flag):
+        self.engine.profile_enable(flag)
+
+    def profile_read(self):
+        return self.engine.profile_read()

@@ -1,0 +1,85 @@
+"""TEST DOUBLE for the per-rank engine of ellalgo_rs_amd.sharded.ShardedEll: the row-block pieces of
+the update computed with the CPU oracle / exact numpy elementwise arithmetic, so the multi-rank
+orchestration (partition, in-place all-gather, redundant scalar stage, local rank-1) can be checked
+for bit-equality against the single-process oracle with the gloo backend and no GPU."""
+import numpy as np
+import torch
+
+from oracle import oracle
+
+
+class OracleShardEngine:
+    def __init__(self, n, row0, nrows, kappa, mq_rows, diag, xc):
+        self.n, self.row0, self.nrows = n, row0, nrows
+        if mq_rows is not None:
+            self.Q = np.array(mq_rows, dtype=np.float64).reshape(nrows, n)
+        else:
+            self.Q = np.zeros((nrows, n))
+            for r in range(nrows):
+                self.Q[r, row0 + r] = 1.0 if diag is None else diag[row0 + r]
+        self.xcv = np.array(xc, dtype=np.float64)
+        self.kap, self.tsqv = float(kappa), 0.0
+        self.gt = torch.zeros(n, dtype=torch.float64)
+        self.gt_np = self.gt.numpy()  # shares memory with the tensor the collective fills
+        self.calc = oracle.Calc(n)
+        self.cut = None
+        self.q = None
+        self.halted = False
+
+    # ---- phase 1 / phase 2 (mirror of ellhip_update_begin / ellhip_update_end)
+    def begin(self, kind, g, b0, has1, b1):
+        self.cut = (kind, np.array(g, dtype=np.float64), b0, b1 if has1 else None)
+        oracle.rows_gemv(self.n, self.row0, self.nrows, self.Q, self.cut[1], self.gt_np)
+
+    def end(self) -> int:
+        kind, g, b0, b1 = self.cut
+        gt = self.gt_np
+        omega = 0.0
+        for a, b in zip(g, gt):          # Arr::dot: left fold (src/arr.rs:443-451)
+            omega += float(a) * float(b)
+        self.tsqv = self.kap * omega
+        st, (rho, sigma, delta) = self.calc.dispatch(kind, b0, b1, self.tsqv)
+        if st != 0:
+            return st
+        self.xcv -= (rho / omega) * gt   # every rank updates its full copy identically
+        ratio = sigma / omega
+        rows = self.row0 + np.arange(self.nrows)[:, None]
+        cols = np.arange(self.n)[None, :]
+        lower = (ratio * gt[rows]) * gt[cols]      # (ratio*gt[i])*gt[j], j <= i   (src/ell.rs:119-121)
+        upper = (ratio * gt[cols]) * gt[rows]      # mirrored element (i, j) = (col, row)
+        self.Q -= np.where(cols <= rows, lower, upper)
+        self.kap *= delta
+        return st
+
+    # ---- queue
+    def queue_upload(self, k, kinds, grads, b0, has1, b1):
+        self.q = (kinds.copy(), grads.reshape(k, self.n).copy(), b0.copy(), has1.copy(), b1.copy())
+        self.qstatus = np.full(k, -1, dtype=np.int32)
+        self.qtsq = np.zeros(k)
+        self.halted = False
+
+    def queue_begin(self, i):
+        if self.halted:
+            return
+        kinds, grads, b0, has1, b1 = self.q
+        self.begin(int(kinds[i]), grads[i], float(b0[i]), int(has1[i]), float(b1[i]))
+
+    def queue_end(self, i):
+        if self.halted:
+            self.qstatus[i] = 3
+            return
+        st = self.end()
+        self.qstatus[i], self.qtsq[i] = st, self.tsqv
+        if st != 0:
+            self.halted = True
+
+    def queue_results(self, k):
+        self.halted = False
+        return self.qstatus.copy(), self.qtsq.copy()
+
+    def xc(self): return self.xcv.copy()
+    def set_xc(self, x): self.xcv = np.array(x, dtype=np.float64)
+    def mq_rows(self): return self.Q.copy()
+    def kappa(self): return self.kap
+    def tsq(self): return self.tsqv
+    def synchronize(self): pass
