@@ -13,16 +13,17 @@ SUCCESS, NOSOLN, NOEFFECT, UNKNOWN = 0, 1, 2, 3
 CUT_BIAS, CUT_CENTRAL, CUT_Q = 0, 1, 2
 SPACE_ELL, SPACE_ELL_STABLE = 0, 1
 E_INVALID, E_HIP, E_NODEVICE, E_NOMEM, E_STATE = -1, -2, -3, -4, -5
-NKERNEL_CLASSES = 6
-KERNEL_CLASS_NAMES = ("gemv", "scalar", "rank1", "stable_fwd", "stable_bwd", "stable_factor")
+NKERNEL_CLASSES = 7
+KERNEL_CLASS_NAMES = ("gemv", "scalar", "rank1", "stable_fwd", "stable_bwd", "stable_factor", "fused")
 
 # every symbol include/ellhip.h declares
 EXPORTS = [
     "ellhip_create", "ellhip_create_shard", "ellhip_clone", "ellhip_destroy", "ellhip_update", "ellhip_tsq",
     "ellhip_get_xc", "ellhip_set_xc", "ellhip_kappa", "ellhip_ndim", "ellhip_get_mq",
     "ellhip_set_no_defer_trick", "ellhip_set_use_parallel_cut", "ellhip_calc", "ellhip_update_begin",
-    "ellhip_update_end", "ellhip_gt_dev", "ellhip_set_gt_dev", "ellhip_queue_upload", "ellhip_queue_run",
-    "ellhip_queue_begin", "ellhip_queue_end", "ellhip_queue_results", "ellhip_set_stream",
+    "ellhip_update_end", "ellhip_gt_dev", "ellhip_set_gt_dev", "ellhip_prime", "ellhip_cut", "ellhip_commit",
+    "ellhip_queue_upload", "ellhip_queue_run", "ellhip_queue_run_fused", "ellhip_queue_begin", "ellhip_queue_end",
+    "ellhip_queue_prime", "ellhip_queue_cut", "ellhip_queue_commit", "ellhip_queue_results", "ellhip_set_stream",
     "ellhip_synchronize", "ellhip_profile_enable", "ellhip_profile_read", "ellhip_device_count",
     "ellhip_last_error", "ellhip_version",
 ]
@@ -68,7 +69,14 @@ def load():
         "ellhip_update_begin": (i32, [vp, i32, vp, dbl, i32, dbl]),
         "ellhip_update_end": (i32, [vp]),
         "ellhip_gt_dev": (vp, [vp]),
-        "ellhip_set_gt_dev": (i32, [vp, vp]),
+        "ellhip_set_gt_dev": (i32, [vp, vp, vp]),
+        "ellhip_prime": (i32, [vp, vp]),
+        "ellhip_cut": (i32, [vp, i32, dbl, i32, dbl]),
+        "ellhip_commit": (i32, [vp, vp]),
+        "ellhip_queue_run_fused": (i32, [vp, i64, i64]),
+        "ellhip_queue_prime": (i32, [vp, i64]),
+        "ellhip_queue_cut": (i32, [vp, i64]),
+        "ellhip_queue_commit": (i32, [vp, i64, i64]),
         "ellhip_queue_upload": (i32, [vp, i64, vp, vp, vp, vp, vp]),
         "ellhip_queue_run": (i32, [vp, i64, i64]),
         "ellhip_queue_begin": (i32, [vp, i64]),

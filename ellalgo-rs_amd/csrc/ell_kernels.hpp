@@ -2,23 +2,25 @@
 //
 // One update = two streaming passes over Q with a scalar stage in between:
 //
-//   k_gemv    gt[r] = sum_c Q[r][c] * g[c]                 reads  8*n^2 B     (src/arr.rs:426-442)
-//   k_scalar  omega = g.gt ; tsq = kappa*omega ; EllCalc ; xc -= (rho/omega) gt ; kappa *= delta
+//   k_sweep<GV>  gt[r] = sum_c Q[r][c] * g[c]              reads  8*n^2 B     (src/arr.rs:426-442)
+//   k_scalar     omega = g.gt ; tsq = kappa*omega ; EllCalc ; xc -= (rho/omega) gt ; kappa *= delta
 //                                                          O(n)   (src/ell.rs:103-115,130-135)
-//   k_rank1   Q[r][c] = (Q[r][c] - (ratio*gt[max(r,c)])*gt[min(r,c)]) [* kappa_new]
+//   k_sweep<R1>  Q[r][c] = (Q[r][c] - (ratio*gt[max(r,c)])*gt[min(r,c)]) [* kappa_new]
 //                                                          reads 8*n^2 B, writes 8*n^2 B
 //                                                          (src/ell.rs:117-128,132-135)
+//   k_sweep<R1,GV> both at once for consecutive updates (pipelined schedule, 16*n^2 B per update)
 //
 // This is BLAS-2: 4*n^2 flop against 24*n^2 bytes, i.e. HBM-bound by a factor ~60 on MI355X, so no
 // MFMA; what matters is 16-byte-per-lane coalesced streams, enough bytes in flight per CU, and no
 // wasted re-reads.  Layout and mapping:
 //   * Q is row-major with leading dimension ld (>= n, multiple of 2 when n is even) in HBM.
-//   * a 256-thread workgroup = 4 wave64s; each wave owns RW consecutive rows and sweeps them
-//     left to right, 64 lanes x 16 B = 1 KiB of one row per load instruction, RW*UNR loads in
-//     flight per lane.  The vector operand (g or gt) is loaded once per column step and reused
-//     for the RW rows (it lives in L2; a Q element is touched exactly once per pass).
-//   * per-row dot products are reduced with a fixed xor-butterfly of wave shuffles, so the result
-//     depends only on (n, VEC): the same bits for any grid size, row partition or GPU count.
+//   * a 256-thread workgroup = 4 wave64s owns RW consecutive rows and sweeps them left to right,
+//     4 KiB of each row per step (16 B per lane), RW*UNR loads in flight per lane.  The vector
+//     operand (g or gt) is loaded once per column step and reused for the RW rows (it lives in
+//     L2; a Q element is touched exactly once per pass).
+//   * per-row dot products: per-thread sequential accumulation, fixed xor-butterfly of wave
+//     shuffles, fixed order across the 4 waves, so the result depends only on (n, VEC): the same
+//     bits for any grid size, row partition or GPU count.
 //   * the rank-1 pass walks the row tiles in the opposite direction to the GEMV pass, so the tail
 //     of each pass is still in the 256 MiB Infinity Cache when the next pass starts there.
 //   * the symmetric update is evaluated per element as (ratio*gt[hi])*gt[lo], hi = max(r,c):
@@ -93,64 +95,147 @@ __device__ __forceinline__ double wave_allreduce_sum(double v) {
     return v;
 }
 
-// ------------------------------------------------------------------------------------ k_gemv ---
-// gt_out[r] = sum_c Q[r*ld + c] * g[c], r in [0, nrows).  grid.x = ceil(nrows / (4*RW)).
-template <int RW, int UNR, int VEC, bool NT = false>
-__global__ __launch_bounds__(256) void k_gemv(const double* __restrict__ Q, long long ld, long long n,
-                                              long long nrows, const double* __restrict__ g,
-                                              double* __restrict__ gt_out,
-                                              const DevState* __restrict__ st) {
-    if (st->halted) return;
+// ----------------------------------------------------------------------------------- k_sweep ---
+// ONE streaming pass over the local rows of Q, in up to two roles at once:
+//   R1 (rank-1 shrink)   Qout[r][c] = (Q[r][c] - (ratio*gt[hi])*gt[lo]) [* scale]     src/ell.rs:117-135
+//   GV (GEMV)            gv_out[r]  = sum_c Qout[r][c] * gvec[c]                       src/arr.rs:426-442
+//   R1 only  = the second pass of an update            (16 n^2 bytes: 8 read + 8 write)
+//   GV only  = the first pass of an update             ( 8 n^2 bytes read)
+//   R1 + GV  = "fused": the shrink of update k and the GEMV of update k+1 in one pass (16 n^2 bytes
+//              for what the two-pass schedule moves 24 n^2 for); legal because the next gradient only
+//              depends on xc_{k+1}, which the scalar stage of update k has already produced.
+// Mapping ("column split"): a 256-thread workgroup owns RW consecutive rows; its 4 waves interleave
+// 1 KiB column chunks, so one step of the workgroup touches 4 KiB contiguous of each row, 16 B per
+// lane, RW*UNR loads in flight per lane.  A row's dot product is accumulated per thread in ascending
+// column order (thread t: columns VEC*t + 256*VEC*k), reduced inside each wave by a fixed xor
+// butterfly and across the 4 waves as ((s0+s1)+s2)+s3: the bits depend only on (n, VEC), not on RW,
+// UNR, the grid, the row partition or the number of GPUs, and are the same in every role.
+// `reverse` flips the order in which row tiles are visited (consecutive passes run in opposite
+// directions, so a pass starts where the previous one ended: Infinity-Cache reuse).
+template <int RW, int UNR, int VEC, bool NT, bool R1, bool GV, bool SCALE>
+__device__ __forceinline__ void sweep_rows(const double* Q, double* Qout, long long ld, long long n,
+                                           long long nrows, long long row0, long long row_base,
+                                           const double* __restrict__ gt, const double* __restrict__ gvec,
+                                           double* __restrict__ gv_out, double ratio, double scale,
+                                           double (*red)[RW]) {
     using V = typename VecT<VEC>::type;
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    const long long row_base = ((long long)blockIdx.x * 4 + wave) * RW;
-    if (row_base >= nrows) return;
-
     const double* rp[RW];
+    double* wp[RW];
+    long long grow[RW];
+    double gtr[RW], rgr[RW], acc[RW];
+    bool valid[RW];
 #pragma unroll
     for (int r = 0; r < RW; ++r) {
         long long rr = row_base + r;
-        if (rr > nrows - 1) rr = nrows - 1;  // clamp: harmless duplicate read, result not stored
+        valid[r] = rr < nrows;
+        if (!valid[r]) rr = nrows - 1;  // clamp: harmless duplicate read, nothing stored
         rp[r] = Q + rr * ld;
+        wp[r] = Qout + rr * ld;
+        grow[r] = row0 + rr;
+        acc[r] = 0.0;
+        if (R1) {
+            gtr[r] = gt[grow[r]];
+            rgr[r] = ratio * gtr[r];  // r_qg of src/ell.rs:119
+        }
     }
-    double acc[RW];
-#pragma unroll
-    for (int r = 0; r < RW; ++r) acc[r] = 0.0;
-
-    constexpr long long STEP = 64 * VEC;
-    long long c = (long long)lane * VEC;
+    constexpr long long STEP = 256 * VEC;
+    long long c = (long long)threadIdx.x * VEC;
     const long long n_main = n - (n % (STEP * UNR));  // columns covered by full unrolled steps
+
+    auto element = [&](int r, long long col, double qx, double gc) -> double {
+        // (ratio*gt[hi])*gt[lo], hi = max(row, col): the reference's lower-triangle value, mirrored
+        const double upd = (col <= grow[r]) ? rgr[r] * gc : (ratio * gc) * gtr[r];
+        double x = qx - upd;      // src/ell.rs:121-123 (two roundings: no FMA)
+        if (SCALE) x = x * scale;  // src/ell.rs:133
+        return x;
+    };
+
     for (; c < n_main; c += STEP * UNR) {
-        V gv[UNR];
+        V gv[UNR], hv[UNR];
         V qv[UNR][RW];
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {
-            gv[u] = *reinterpret_cast<const V*>(g + c + u * STEP);
+            if (R1) gv[u] = *reinterpret_cast<const V*>(gt + c + u * STEP);
+            if (GV) hv[u] = *reinterpret_cast<const V*>(gvec + c + u * STEP);
 #pragma unroll
             for (int r = 0; r < RW; ++r) qv[u][r] = ld_stream<NT, V>(rp[r] + c + u * STEP);
         }
 #pragma unroll
-        for (int u = 0; u < UNR; ++u)
+        for (int u = 0; u < UNR; ++u) {
 #pragma unroll
-            for (int r = 0; r < RW; ++r)
+            for (int r = 0; r < RW; ++r) {
+                V o = qv[u][r];
+                if (R1) {
 #pragma unroll
-                for (int v = 0; v < VEC; ++v)
-                    acc[r] += VecT<VEC>::get(qv[u][r], v) * VecT<VEC>::get(gv[u], v);
-    }
-    for (; c < n; c += STEP) {  // tail steps; n % VEC == 0 so a lane's VEC columns are all valid
-        const V gv = *reinterpret_cast<const V*>(g + c);
+                    for (int v = 0; v < VEC; ++v)
+                        VecT<VEC>::set(o, v, element(r, c + u * STEP + v, VecT<VEC>::get(qv[u][r], v),
+                                                     VecT<VEC>::get(gv[u], v)));
+                    if (valid[r]) st_stream<NT, V>(wp[r] + c + u * STEP, o);
+                }
+                if (GV) {
 #pragma unroll
-        for (int r = 0; r < RW; ++r) {
-            const V qv = ld_stream<NT, V>(rp[r] + c);
-#pragma unroll
-            for (int v = 0; v < VEC; ++v) acc[r] += VecT<VEC>::get(qv, v) * VecT<VEC>::get(gv, v);
+                    for (int v = 0; v < VEC; ++v) acc[r] += VecT<VEC>::get(o, v) * VecT<VEC>::get(hv[u], v);
+                }
+            }
         }
     }
+    for (; c < n; c += STEP) {  // tail steps; n % VEC == 0 so a thread's VEC columns are all valid
+        V gv, hv;
+        if (R1) gv = *reinterpret_cast<const V*>(gt + c);
+        if (GV) hv = *reinterpret_cast<const V*>(gvec + c);
 #pragma unroll
-    for (int r = 0; r < RW; ++r) {
-        const double s = wave_allreduce_sum(acc[r]);
-        if (lane == 0 && row_base + r < nrows) gt_out[row_base + r] = s;
+        for (int r = 0; r < RW; ++r) {
+            V o = ld_stream<NT, V>(rp[r] + c);
+            if (R1) {
+                const V qin = o;
+#pragma unroll
+                for (int v = 0; v < VEC; ++v)
+                    VecT<VEC>::set(o, v, element(r, c + v, VecT<VEC>::get(qin, v), VecT<VEC>::get(gv, v)));
+                if (valid[r]) st_stream<NT, V>(wp[r] + c, o);
+            }
+            if (GV) {
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) acc[r] += VecT<VEC>::get(o, v) * VecT<VEC>::get(hv, v);
+            }
+        }
+    }
+    if (GV) {
+#pragma unroll
+        for (int r = 0; r < RW; ++r) {
+            const double s = wave_allreduce_sum(acc[r]);
+            if (lane == 0) red[wave][r] = s;
+        }
+        __syncthreads();
+        if (threadIdx.x < RW && row_base + threadIdx.x < nrows) {
+            const int r = threadIdx.x;
+            gv_out[row_base + r] = ((red[0][r] + red[1][r]) + red[2][r]) + red[3][r];
+        }
+    }
+}
+
+// grid.x = ceil(nrows / RW).  gv_out already points at this shard's first row.
+template <int RW, int UNR, int VEC, bool NT, bool R1, bool GV, bool SCALE>
+__global__ __launch_bounds__(256) void k_sweep(const double* Q, double* Qout, long long ld, long long n,
+                                               long long nrows, long long row0,
+                                               const double* __restrict__ gt,
+                                               const double* __restrict__ gvec,
+                                               double* __restrict__ gv_out,
+                                               const DevState* __restrict__ st, int reverse) {
+    __shared__ double red[4][RW];
+    if (st->halted) return;  // queue mode: a previous cut failed, nothing further runs
+    const bool apply = R1 && st->apply != 0;
+    if (!GV && !apply) return;  // failed cut: Q stays untouched (src/ell.rs:107-109)
+    const long long tile = reverse ? (long long)gridDim.x - 1 - blockIdx.x : (long long)blockIdx.x;
+    const long long row_base = tile * RW;
+    if (row_base >= nrows) return;
+    if (R1 && apply) {
+        sweep_rows<RW, UNR, VEC, NT, true, GV, SCALE>(Q, Qout, ld, n, nrows, row0, row_base, gt, gvec, gv_out,
+                                                      st->ratio, st->scale, red);
+    } else if (GV) {
+        sweep_rows<RW, UNR, VEC, NT, false, true, false>(Q, Qout, ld, n, nrows, row0, row_base, gt, gvec, gv_out,
+                                                         0.0, 1.0, red);
     }
 }
 
@@ -160,9 +245,9 @@ __global__ __launch_bounds__(256) void k_gemv(const double* __restrict__ Q, long
 __global__ __launch_bounds__(1024) void k_scalar(long long n, const double* __restrict__ g,
                                                  const double* __restrict__ gt, double* __restrict__ xc,
                                                  DevState* __restrict__ st, EllCalcDev calc,
-                                                 const CutParams* __restrict__ cp, int no_defer_trick,
-                                                 int queue_mode, int* __restrict__ q_status,
-                                                 double* __restrict__ q_tsq) {
+                                                 const CutParams* __restrict__ cp_dev, CutParams cp_val,
+                                                 int no_defer_trick, int queue_mode,
+                                                 int* __restrict__ q_status, double* __restrict__ q_tsq) {
     __shared__ double red[16];
     __shared__ double bc_roo;
     __shared__ int bc_status;
@@ -186,7 +271,8 @@ __global__ __launch_bounds__(1024) void k_scalar(long long n, const double* __re
         const double kappa = st->kappa;
         const double tsq = kappa * omega;  // src/ell.rs:105
         Coef cf;
-        const int status = calc.dispatch(cp->kind, cp->b0, cp->has_b1, cp->b1, tsq, cf);  // :106
+        const CutParams cp = cp_dev ? *cp_dev : cp_val;  // queued cuts live in HBM, direct ones arrive by value
+        const int status = calc.dispatch(cp.kind, cp.b0, cp.has_b1, cp.b1, tsq, cf);  // :106
         st->tsq = tsq;
         st->omega = omega;
         st->status = status;
@@ -219,93 +305,6 @@ __global__ __launch_bounds__(1024) void k_scalar(long long n, const double* __re
     if (bc_status != ST_SUCCESS) return;
     const double roo = bc_roo;
     for (long long i = tid; i < n; i += 1024) xc[i] = xc[i] - roo * gt[i];  // :113-115
-}
-
-// ----------------------------------------------------------------------------------- k_rank1 ---
-// Qout[r][c] = Q[r][c] - (ratio*gt[hi])*gt[lo] (then * scale if SCALE) for the local rows (Qout may be
-// Q itself: every element is read and written by the same lane); row0 = global index
-// of local row 0 (row-partitioned multi-GPU).  grid.x = ceil(nrows / (4*RW)); tiles are walked in
-// reverse block order (see header comment).
-template <int RW, int UNR, int VEC, bool SCALE, bool NT = false, bool REVERSE = true>
-__global__ __launch_bounds__(256) void k_rank1(const double* Q, double* Qout, long long ld, long long n,
-                                               long long nrows, long long row0,
-                                               const double* __restrict__ gt,
-                                               const DevState* __restrict__ st) {
-    if (!st->apply) return;
-    using V = typename VecT<VEC>::type;
-    const double ratio = st->ratio;
-    const double scale = st->scale;
-    const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
-    const long long tile = REVERSE ? (long long)gridDim.x - 1 - blockIdx.x : (long long)blockIdx.x;
-    const long long row_base = (tile * 4 + wave) * RW;
-    if (row_base >= nrows) return;
-
-    const double* rp[RW];
-    double* wp[RW];
-    long long grow[RW];
-    double gtr[RW], rgr[RW];
-    bool valid[RW];
-#pragma unroll
-    for (int r = 0; r < RW; ++r) {
-        long long rr = row_base + r;
-        valid[r] = rr < nrows;
-        if (!valid[r]) rr = nrows - 1;
-        rp[r] = Q + rr * ld;
-        wp[r] = Qout + rr * ld;
-        grow[r] = row0 + rr;
-        gtr[r] = gt[grow[r]];
-        rgr[r] = ratio * gtr[r];  // r_qg of src/ell.rs:119
-    }
-
-    constexpr long long STEP = 64 * VEC;
-    long long c = (long long)lane * VEC;
-    const long long n_main = n - (n % (STEP * UNR));
-    for (; c < n_main; c += STEP * UNR) {
-        V gv[UNR];
-        V qv[UNR][RW];
-#pragma unroll
-        for (int u = 0; u < UNR; ++u) {
-            gv[u] = *reinterpret_cast<const V*>(gt + c + u * STEP);
-#pragma unroll
-            for (int r = 0; r < RW; ++r) qv[u][r] = ld_stream<NT, V>(rp[r] + c + u * STEP);
-        }
-#pragma unroll
-        for (int u = 0; u < UNR; ++u) {
-#pragma unroll
-            for (int r = 0; r < RW; ++r) {
-                V o;
-#pragma unroll
-                for (int v = 0; v < VEC; ++v) {
-                    const long long col = c + u * STEP + v;
-                    const double gc = VecT<VEC>::get(gv[u], v);
-                    const double upd = (col <= grow[r]) ? rgr[r] * gc : (ratio * gc) * gtr[r];
-                    double x = VecT<VEC>::get(qv[u][r], v) - upd;  // src/ell.rs:121-123
-                    if (SCALE) x = x * scale;                       // src/ell.rs:133
-                    VecT<VEC>::set(o, v, x);
-                }
-                if (valid[r]) st_stream<NT, V>(wp[r] + c + u * STEP, o);
-            }
-        }
-    }
-    for (; c < n; c += STEP) {
-        const V gv = *reinterpret_cast<const V*>(gt + c);
-#pragma unroll
-        for (int r = 0; r < RW; ++r) {
-            const V qv = ld_stream<NT, V>(rp[r] + c);
-            V o;
-#pragma unroll
-            for (int v = 0; v < VEC; ++v) {
-                const long long col = c + v;
-                const double gc = VecT<VEC>::get(gv, v);
-                const double upd = (col <= grow[r]) ? rgr[r] * gc : (ratio * gc) * gtr[r];
-                double x = VecT<VEC>::get(qv, v) - upd;
-                if (SCALE) x = x * scale;
-                VecT<VEC>::set(o, v, x);
-            }
-            if (valid[r]) st_stream<NT, V>(wp[r] + c, o);
-        }
-    }
 }
 
 // -------------------------------------------------------------------------- small helpers ----

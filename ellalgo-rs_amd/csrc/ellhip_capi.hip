@@ -4,6 +4,12 @@
 // host vectors through pinned memory, issues the kernels of ell_kernels.hpp / ellstable_kernels.hpp
 // on one HIP stream and reads the scalar state back.  No torch types, no CPU compute path: if there
 // is no HIP device every entry point that needs one fails (ELLHIP_E_NODEVICE).
+//
+// Every update is built from three primitives (see include/ellhip.h, "pipelined update"):
+//   prime   GEMV pass            gt[slot] = Q * g
+//   cut     scalar stage         omega, tsq, EllCalc, xc, kappa   (EllStable: the whole update)
+//   commit  rank-1 pass, optionally fused with the GEMV pass of the next gradient
+// ellhip_update = prime + cut + commit(NULL); the two-phase multi-GPU form splits it after prime.
 #include "../../include/ellhip.h"
 
 #include <hip/hip_runtime.h>
@@ -34,9 +40,9 @@ int fail(int code, const char* what, hipError_t e = hipSuccess) {
     return code;
 }
 
-#define HIPCHK(expr)                                              \
-    do {                                                          \
-        hipError_t _e = (expr);                                   \
+#define HIPCHK(expr)                                                \
+    do {                                                            \
+        hipError_t _e = (expr);                                     \
         if (_e != hipSuccess) return fail(ELLHIP_E_HIP, #expr, _e); \
     } while (0)
 
@@ -50,6 +56,12 @@ int env_int(const char* name, int dflt) {
     return (s && *s) ? atoi(s) : dflt;
 }
 
+enum : int { CLS_GEMV = 0, CLS_SCALAR = 1, CLS_RANK1 = 2, CLS_ST_FWD = 3, CLS_ST_BWD = 4, CLS_ST_FACTOR = 5, CLS_FUSED = 6 };
+
+struct Shape {
+    int rw = 0, unr = 0, nt = 0;
+};
+
 }  // namespace
 
 struct ellhip_space {
@@ -58,16 +70,16 @@ struct ellhip_space {
     int device = 0;
     bool sharded = false;
 
-    double* d_Q = nullptr;       // nrows * ld
-    double* d_xc = nullptr;      // n
-    double* d_stage = nullptr;   // n doubles (grad) + CutParams
-    double* d_gt_own = nullptr;  // n
-    double* d_gt = nullptr;      // gt buffer in use (own or caller's)
-    double* d_work = nullptr;    // EllStable vectors: w, z, gg, q (4n)
+    double* d_Q = nullptr;           // nrows * ld
+    double* d_xc = nullptr;          // n
+    double* d_stage[2] = {nullptr, nullptr};   // gradient of slot 0 / 1 (n doubles)
+    double* d_gt_own[2] = {nullptr, nullptr};  // Q*g of slot 0 / 1 (n doubles)
+    double* d_gt[2] = {nullptr, nullptr};      // buffers in use (own or caller's)
+    double* d_work = nullptr;        // EllStable vectors: w, z, gg, q, beta2
     DevState* d_st = nullptr;
 
-    double* h_stage = nullptr;    // pinned: n doubles + CutParams
-    DevState* h_result = nullptr; // pinned
+    double* h_stage[2] = {nullptr, nullptr};  // pinned, n doubles each
+    DevState* h_result = nullptr;             // pinned
 
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
@@ -75,7 +87,16 @@ struct ellhip_space {
     int no_defer_trick = 0;
     int use_parallel_cut = 1;
     bool needs_mirror = false;  // caller-supplied non-symmetric matrix, no successful update yet
-    bool pending = false;       // update_begin issued, update_end not yet
+
+    // pipeline state
+    int cur = 0;                  // slot of the primed / current gradient
+    bool primed = false;          // gt[cur] = Q * g[cur] is valid (or in flight)
+    const double* g_cur = nullptr;  // device pointer of the primed gradient (stage slot or queue entry)
+    bool shrink_pending = false;  // a cut succeeded (or may have: queue mode) and Q has not been shrunk yet
+    bool in_two_phase = false;    // update_begin issued, update_end not yet
+    CutParams two_phase_cp{};     // cut scalars kept between begin and end
+    int dir = 0;                  // direction of the next pass over Q (serpentine)
+    long long primed_qindex = -1; // queue index the primed gradient belongs to (-1: a direct gradient)
 
     // cached scalars (refreshed by every synchronous read-back)
     double kappa = 1.0, tsq = 0.0;
@@ -94,9 +115,8 @@ struct ellhip_space {
     double prof_ms[ELLHIP_NKERNEL_CLASSES] = {0};
     long long prof_cnt[ELLHIP_NKERNEL_CLASSES] = {0};
 
-    // launch shape (tunable through the environment for experiments)
-    int rw_gemv = 0, unr_gemv = 0, rw_rank1 = 0, unr_rank1 = 0;
-    int nt_gemv = 0, nt_rank1 = 0;  // non-temporal cache policy on the Q stream
+    // launch shapes per role (tunable through the environment for experiments)
+    Shape sh_gemv, sh_rank1, sh_fused;
 };
 
 namespace {
@@ -105,16 +125,12 @@ struct DeviceGuard {
     int prev = -1;
     bool switched = false;
     explicit DeviceGuard(int dev) {
-        if (hipGetDevice(&prev) == hipSuccess && prev != dev) {
-            switched = hipSetDevice(dev) == hipSuccess;
-        }
+        if (hipGetDevice(&prev) == hipSuccess && prev != dev) switched = hipSetDevice(dev) == hipSuccess;
     }
     ~DeviceGuard() {
         if (switched) (void)hipSetDevice(prev);
     }
 };
-
-size_t stage_bytes(long long n) { return (size_t)n * sizeof(double) + sizeof(CutParams); }
 
 // ---- profiling helpers ---------------------------------------------------------------------
 int prof_flush(ellhip_space* s) {
@@ -155,115 +171,87 @@ struct ProfScope {
 };
 
 // ---- launch-shape selection ------------------------------------------------------------------
-// A workgroup covers 4*RW rows; each lane keeps RW*UNR 16-byte loads in flight.  Defaults come from
-// in-process A/B sweeps on MI355X (tools/tune_ell.hip, numbers in DESIGN.md):
+// A workgroup covers RW rows; each lane keeps RW*UNR 16-byte loads in flight.  Defaults come from
+// in-process A/B sweeps on MI355X (tools/tune_ell.hip, numbers in DESIGN.md / profiles/):
 //   * local Q block fits the 256 MiB Infinity Cache (n = 4096: 128 MiB): keep the default cache
-//     policy so the other pass finds Q on-die, 4 rows per workgroup, deep unroll;
-//   * larger: the Q stream is touched once per pass, so use the non-temporal policy (GEMV 4.8 ->
-//     6.3 TB/s at n = 16384) and more rows per wave.
+//     policy so the next pass finds Q on-die;
+//   * larger: the Q stream is touched once per pass, so use the non-temporal policy (GEMV pass 4.9 ->
+//     7.0 TB/s at n = 16384).
 void pick_shape(ellhip_space* s) {
     const double q_bytes = (double)s->nrows * (double)s->ld * 8.0;
     const bool fits_mall = q_bytes <= 200.0 * 1024 * 1024;
-    int rwg, ung, rwr, unr, ntg, ntr;
     if (fits_mall) {
-        rwg = 1; ung = 4; rwr = 1; unr = 8; ntg = 0; ntr = 0;
+        s->sh_gemv = {4, 2, 0};
+        s->sh_rank1 = {4, 4, 0};
+        s->sh_fused = {4, 4, 0};
     } else {
-        rwg = 4; ung = 4; rwr = 2; unr = 4; ntg = 1; ntr = 1;
+        s->sh_gemv = {4, 4, 1};
+        s->sh_rank1 = {1, 4, 1};
+        s->sh_fused = {2, 8, 1};
     }
-    s->rw_gemv = env_int("ELLHIP_GEMV_RW", rwg);
-    s->unr_gemv = env_int("ELLHIP_GEMV_UNR", ung);
-    s->rw_rank1 = env_int("ELLHIP_RANK1_RW", rwr);
-    s->unr_rank1 = env_int("ELLHIP_RANK1_UNR", unr);
-    s->nt_gemv = env_int("ELLHIP_GEMV_NT", ntg);
-    s->nt_rank1 = env_int("ELLHIP_RANK1_NT", ntr);
+    s->sh_gemv.rw = env_int("ELLHIP_GEMV_RW", s->sh_gemv.rw);
+    s->sh_gemv.unr = env_int("ELLHIP_GEMV_UNR", s->sh_gemv.unr);
+    s->sh_gemv.nt = env_int("ELLHIP_GEMV_NT", s->sh_gemv.nt);
+    s->sh_rank1.rw = env_int("ELLHIP_RANK1_RW", s->sh_rank1.rw);
+    s->sh_rank1.unr = env_int("ELLHIP_RANK1_UNR", s->sh_rank1.unr);
+    s->sh_rank1.nt = env_int("ELLHIP_RANK1_NT", s->sh_rank1.nt);
+    s->sh_fused.rw = env_int("ELLHIP_FUSED_RW", s->sh_fused.rw);
+    s->sh_fused.unr = env_int("ELLHIP_FUSED_UNR", s->sh_fused.unr);
+    s->sh_fused.nt = env_int("ELLHIP_FUSED_NT", s->sh_fused.nt);
 }
 
-template <int VEC, bool NT>
-int launch_gemv_v(ellhip_space* s, const double* g, double* gt_out) {
+// One pass over Q in the given roles.  gt_r1: vector of the rank-1 role; gvec / gv_out: operand and
+// result of the GEMV role (gv_out is the full-length buffer; the shard's rows start at row0).
+template <int VEC, bool NT, bool R1, bool GV, bool SCALE>
+int launch_sweep_t(ellhip_space* s, const Shape& sh, const double* gt_r1, const double* gvec, double* gv_out) {
     const long long nr = s->nrows;
-    const int rw = s->rw_gemv, unr = s->unr_gemv;
-    const unsigned grid = (unsigned)((nr + 4LL * rw - 1) / (4LL * rw));
-#define GEMV_CASE(RW, UNR)                                                                       \
-    if (rw == RW && unr == UNR) {                                                                \
-        hipLaunchKernelGGL((k_gemv<RW, UNR, VEC, NT>), dim3(grid), dim3(256), 0, s->stream, s->d_Q,  \
-                           s->ld, s->n, nr, g, gt_out, s->d_st);                                 \
-        return 0;                                                                                \
+    const unsigned grid = (unsigned)((nr + sh.rw - 1) / sh.rw);
+    double* out = gv_out ? gv_out + s->row0 : nullptr;
+#define SWEEP_CASE(RW, UNR)                                                                                  \
+    if (sh.rw == RW && sh.unr == UNR) {                                                                      \
+        hipLaunchKernelGGL((k_sweep<RW, UNR, VEC, NT, R1, GV, SCALE>), dim3(grid), dim3(256), 0, s->stream,  \
+                           (const double*)s->d_Q, s->d_Q, s->ld, s->n, nr, s->row0, gt_r1, gvec, out, s->d_st, \
+                           s->dir);                                                                          \
+        return 0;                                                                                            \
     }
-    GEMV_CASE(1, 1) GEMV_CASE(1, 2) GEMV_CASE(1, 4) GEMV_CASE(1, 8)
-    GEMV_CASE(2, 1) GEMV_CASE(2, 2) GEMV_CASE(2, 4) GEMV_CASE(2, 8)
-    GEMV_CASE(4, 1) GEMV_CASE(4, 2) GEMV_CASE(4, 4)
-    GEMV_CASE(8, 1) GEMV_CASE(8, 2)
-#undef GEMV_CASE
-    return fail(ELLHIP_E_INVALID, "unsupported ELLHIP_GEMV_RW/UNR combination");
+    SWEEP_CASE(1, 4) SWEEP_CASE(1, 8) SWEEP_CASE(2, 4) SWEEP_CASE(2, 8) SWEEP_CASE(4, 2) SWEEP_CASE(4, 4)
+    SWEEP_CASE(8, 1) SWEEP_CASE(8, 2)
+#undef SWEEP_CASE
+    return fail(ELLHIP_E_INVALID, "unsupported RW/UNR launch shape (supported: 1x4 1x8 2x4 2x8 4x2 4x4 8x1 8x2)");
 }
 
-int launch_gemv(ellhip_space* s, const double* g) {
-    ProfScope ps(s, 0);
-    double* gt_out = s->d_gt + s->row0;
+template <bool R1, bool GV>
+int launch_sweep(ellhip_space* s, const Shape& sh, const double* gt_r1, const double* gvec, double* gv_out) {
+    const bool even = (s->n % 2) == 0;  // odd n: rows are not 16-byte aligned, use 8-byte accesses
+    const bool nt = even && sh.nt;
+    const bool scale = R1 && s->no_defer_trick;
     int rc;
-    if (s->n % 2 == 0)
-        rc = s->nt_gemv ? launch_gemv_v<2, true>(s, g, gt_out) : launch_gemv_v<2, false>(s, g, gt_out);
+    if (!even)
+        rc = scale ? launch_sweep_t<1, false, R1, GV, R1>(s, sh, gt_r1, gvec, gv_out)
+                   : launch_sweep_t<1, false, R1, GV, false>(s, sh, gt_r1, gvec, gv_out);
+    else if (nt)
+        rc = scale ? launch_sweep_t<2, true, R1, GV, R1>(s, sh, gt_r1, gvec, gv_out)
+                   : launch_sweep_t<2, true, R1, GV, false>(s, sh, gt_r1, gvec, gv_out);
     else
-        rc = launch_gemv_v<1, false>(s, g, gt_out);
+        rc = scale ? launch_sweep_t<2, false, R1, GV, R1>(s, sh, gt_r1, gvec, gv_out)
+                   : launch_sweep_t<2, false, R1, GV, false>(s, sh, gt_r1, gvec, gv_out);
     if (rc) return rc;
     HIPCHK(hipGetLastError());
+    s->dir ^= 1;  // the next pass over Q runs the other way
     return 0;
 }
 
-template <int VEC, bool SCALE, bool NT>
-int launch_rank1_v(ellhip_space* s) {
-    const long long nr = s->nrows;
-    const int rw = s->rw_rank1, unr = s->unr_rank1;
-    const unsigned grid = (unsigned)((nr + 4LL * rw - 1) / (4LL * rw));
-#define RANK1_CASE(RW, UNR)                                                                          \
-    if (rw == RW && unr == UNR) {                                                                    \
-        hipLaunchKernelGGL((k_rank1<RW, UNR, VEC, SCALE, NT>), dim3(grid), dim3(256), 0, s->stream,      \
-                           s->d_Q, s->d_Q, s->ld, s->n, nr, s->row0, s->d_gt, s->d_st);              \
-        return 0;                                                                                    \
-    }
-    RANK1_CASE(1, 1) RANK1_CASE(1, 2) RANK1_CASE(1, 4) RANK1_CASE(1, 8)
-    RANK1_CASE(2, 1) RANK1_CASE(2, 2) RANK1_CASE(2, 4) RANK1_CASE(2, 8)
-    RANK1_CASE(4, 1) RANK1_CASE(4, 2) RANK1_CASE(4, 4)
-    RANK1_CASE(8, 1) RANK1_CASE(8, 2)
-#undef RANK1_CASE
-    return fail(ELLHIP_E_INVALID, "unsupported ELLHIP_RANK1_RW/UNR combination");
-}
-
-int launch_rank1(ellhip_space* s) {
-    if (s->needs_mirror) {
-        const unsigned t = (unsigned)((s->n + 31) / 32);
-        hipLaunchKernelGGL(k_mirror_lower, dim3(t, t), dim3(256), 0, s->stream, s->d_Q, s->ld, s->n,
-                           s->d_st);
-        HIPCHK(hipGetLastError());
-    }
-    ProfScope ps(s, 2);
-    int rc;
-    const bool even = s->n % 2 == 0;
-    const bool nt = even && s->nt_rank1;
-    if (s->no_defer_trick)
-        rc = even ? (nt ? launch_rank1_v<2, true, true>(s) : launch_rank1_v<2, true, false>(s))
-                  : launch_rank1_v<1, true, false>(s);
-    else
-        rc = even ? (nt ? launch_rank1_v<2, false, true>(s) : launch_rank1_v<2, false, false>(s))
-                  : launch_rank1_v<1, false, false>(s);
-    if (rc) return rc;
-    HIPCHK(hipGetLastError());
-    return 0;
-}
-
-int launch_scalar(ellhip_space* s, const double* g, const CutParams* cp, int queue_mode, int* qst,
-                  double* qtsq) {
-    ProfScope ps(s, 1);
-    EllCalcDev calc = EllCalcDev::make(s->n, s->use_parallel_cut);
-    hipLaunchKernelGGL(k_scalar, dim3(1), dim3(1024), 0, s->stream, s->n, g, s->d_gt, s->d_xc, s->d_st,
-                       calc, cp, s->no_defer_trick, queue_mode, qst, qtsq);
+int launch_mirror_if_needed(ellhip_space* s) {
+    if (!s->needs_mirror) return 0;
+    const unsigned t = (unsigned)((s->n + 31) / 32);
+    hipLaunchKernelGGL(k_mirror_lower, dim3(t, t), dim3(256), 0, s->stream, s->d_Q, s->ld, s->n, s->d_st);
     HIPCHK(hipGetLastError());
     return 0;
 }
 
 // EllStable::update_core as a fixed sequence of launches (ellstable_kernels.hpp).
-int ellstable_issue(ellhip_space* s, const double* g_dev, const CutParams* cp_dev, int queue_mode, int* qst,
-                    double* qtsq) {
+int ellstable_issue(ellhip_space* s, const double* g_dev, const CutParams* cp_dev, CutParams cp_val, int queue_mode,
+                    int* qst, double* qtsq) {
     const long long n = s->n, ld = s->ld;
     const long long nb = (n + SB - 1) / SB;
     double* w = s->d_work;
@@ -273,7 +261,7 @@ int ellstable_issue(ellhip_space* s, const double* g_dev, const CutParams* cp_de
     double* beta2 = q + n;
     hipStream_t st = s->stream;
     {
-        ProfScope ps(s, 3);
+        ProfScope ps(s, CLS_ST_FWD);
         HIPCHK(hipMemcpyAsync(w, g_dev, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, st));
         hipLaunchKernelGGL(k_st_fwd_first, dim3(1), dim3(64), 0, st, s->d_Q, ld, n, g_dev, w, z, gg, s->d_st);
         for (long long kb = 0; kb + 1 < nb; ++kb) {
@@ -284,14 +272,14 @@ int ellstable_issue(ellhip_space* s, const double* g_dev, const CutParams* cp_de
         HIPCHK(hipGetLastError());
     }
     {
-        ProfScope ps(s, 1);
+        ProfScope ps(s, CLS_SCALAR);
         EllCalcDev calc = EllCalcDev::make(n, s->use_parallel_cut);
         hipLaunchKernelGGL(k_st_mid, dim3(1), dim3(1024), 0, st, s->d_Q, ld, n, z, gg, q, beta2, s->d_st, calc,
-                           cp_dev, queue_mode, qst, qtsq);
+                           cp_dev, cp_val, queue_mode, qst, qtsq);
         HIPCHK(hipGetLastError());
     }
     {
-        ProfScope ps(s, 4);
+        ProfScope ps(s, CLS_ST_BWD);
         hipLaunchKernelGGL(k_st_bwd_last, dim3(1), dim3(64), 0, st, s->d_Q, ld, n, nb - 1, q, s->d_st);
         for (long long kb = nb - 1; kb >= 1; --kb) {
             const unsigned grid = (unsigned)((kb * SB + SPANEL - 1) / SPANEL);
@@ -302,7 +290,7 @@ int ellstable_issue(ellhip_space* s, const double* g_dev, const CutParams* cp_de
         HIPCHK(hipGetLastError());
     }
     {
-        ProfScope ps(s, 5);
+        ProfScope ps(s, CLS_ST_FACTOR);
         hipLaunchKernelGGL(k_st_factor, dim3((unsigned)nb, (unsigned)nb), dim3(256), 0, st, s->d_Q, ld, n, beta2,
                            s->d_st);
         HIPCHK(hipGetLastError());
@@ -310,20 +298,46 @@ int ellstable_issue(ellhip_space* s, const double* g_dev, const CutParams* cp_de
     return 0;
 }
 
-// ---- one cut, phase 1 / phase 2, for either variant ------------------------------------------
-int issue_phase1(ellhip_space* s, const double* g_dev) {
-    if (s->variant == ELLHIP_SPACE_ELL) return launch_gemv(s, g_dev);
-    return 0;  // EllStable does everything in phase 2
+// ---- the three primitives --------------------------------------------------------------------
+
+// gt[slot] = Q * g  (Ell only; EllStable has no separate first pass)
+int do_prime(ellhip_space* s, const double* g_dev, int slot) {
+    if (s->variant != ELLHIP_SPACE_ELL) return 0;
+    ProfScope ps(s, CLS_GEMV);
+    return launch_sweep<false, true>(s, s->sh_gemv, nullptr, g_dev, s->d_gt[slot]);
 }
 
-int issue_phase2(ellhip_space* s, const double* g_dev, const CutParams* cp_dev, int queue_mode, int* qst,
-                 double* qtsq) {
-    if (s->variant == ELLHIP_SPACE_ELL) {
-        int rc = launch_scalar(s, g_dev, cp_dev, queue_mode, qst, qtsq);
+// scalar stage of the primed cut (asynchronous; the caller reads the state back if it needs it)
+int do_cut(ellhip_space* s, const double* g_dev, const CutParams* cp_dev, CutParams cp_val, int queue_mode, int* qst,
+           double* qtsq) {
+    if (s->variant != ELLHIP_SPACE_ELL) return ellstable_issue(s, g_dev, cp_dev, cp_val, queue_mode, qst, qtsq);
+    ProfScope ps(s, CLS_SCALAR);
+    EllCalcDev calc = EllCalcDev::make(s->n, s->use_parallel_cut);
+    hipLaunchKernelGGL(k_scalar, dim3(1), dim3(1024), 0, s->stream, s->n, g_dev, (const double*)s->d_gt[s->cur],
+                       s->d_xc, s->d_st, calc, cp_dev, cp_val, s->no_defer_trick, queue_mode, qst, qtsq);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+// rank-1 pass for the cut just taken (the kernel itself skips it when the cut failed), fused with
+// the GEMV pass of `gnext_dev` (into the other slot) when that is given.
+int do_commit(ellhip_space* s, bool shrink, const double* gnext_dev) {
+    if (s->variant != ELLHIP_SPACE_ELL) return 0;
+    if (shrink) {
+        int rc = launch_mirror_if_needed(s);
         if (rc) return rc;
-        return launch_rank1(s);
     }
-    return ellstable_issue(s, g_dev, cp_dev, queue_mode, qst, qtsq);
+    const double* gt_cur = s->d_gt[s->cur];
+    if (shrink && gnext_dev) {
+        ProfScope ps(s, CLS_FUSED);
+        return launch_sweep<true, true>(s, s->sh_fused, gt_cur, gnext_dev, s->d_gt[s->cur ^ 1]);
+    }
+    if (shrink) {
+        ProfScope ps(s, CLS_RANK1);
+        return launch_sweep<true, false>(s, s->sh_rank1, gt_cur, nullptr, nullptr);
+    }
+    if (gnext_dev) return do_prime(s, gnext_dev, s->cur ^ 1);
+    return 0;
 }
 
 int read_back(ellhip_space* s) {
@@ -334,20 +348,58 @@ int read_back(ellhip_space* s) {
     return 0;
 }
 
+// upload a host gradient into stage slot `slot`
+int stage_grad(ellhip_space* s, const double* grad, int slot) {
+    if (!grad) return fail(ELLHIP_E_INVALID, "grad is NULL");
+    const size_t bytes = (size_t)s->n * sizeof(double);
+    memcpy(s->h_stage[slot], grad, bytes);
+    HIPCHK(hipMemcpyAsync(s->d_stage[slot], s->h_stage[slot], bytes, hipMemcpyHostToDevice, s->stream));
+    return 0;
+}
+
+int make_params(int kind, double b0, int has_b1, double b1, CutParams& cp) {
+    if (kind < 0 || kind > 2) return fail(ELLHIP_E_INVALID, "bad cut kind");
+    cp.kind = kind;
+    cp.has_b1 = has_b1 ? 1 : 0;
+    cp.b0 = b0;
+    cp.b1 = has_b1 ? b1 : 0.0;
+    return 0;
+}
+
+// Make Q current: issue a shrink that a previous ellhip_cut / queue cut left pending.
+int ensure_committed(ellhip_space* s) {
+    if (s->in_two_phase) return fail(ELLHIP_E_STATE, "update_begin without update_end");
+    if (s->shrink_pending) {
+        int rc = do_commit(s, true, nullptr);
+        if (rc) return rc;
+        s->shrink_pending = false;
+    }
+    return 0;
+}
+
+void drop_prime(ellhip_space* s) {
+    s->primed = false;
+    s->g_cur = nullptr;
+    s->primed_qindex = -1;
+}
+
 int alloc_common(ellhip_space* s) {
     const long long n = s->n;
+    const size_t vbytes = (size_t)n * sizeof(double);
     HIPCHK(hipStreamCreateWithFlags(&s->own_stream, hipStreamNonBlocking));
     s->stream = s->own_stream;
     HIPCHK(hipMalloc(&s->d_Q, (size_t)s->nrows * (size_t)s->ld * sizeof(double)));
-    HIPCHK(hipMalloc(&s->d_xc, (size_t)n * sizeof(double)));
-    HIPCHK(hipMalloc(&s->d_stage, stage_bytes(n)));
-    HIPCHK(hipMalloc(&s->d_gt_own, (size_t)n * sizeof(double)));
-    s->d_gt = s->d_gt_own;
+    HIPCHK(hipMalloc(&s->d_xc, vbytes));
+    for (int k = 0; k < 2; ++k) {
+        HIPCHK(hipMalloc(&s->d_stage[k], vbytes));
+        HIPCHK(hipMalloc(&s->d_gt_own[k], vbytes));
+        s->d_gt[k] = s->d_gt_own[k];
+        HIPCHK(hipHostMalloc(&s->h_stage[k], vbytes, hipHostMallocDefault));
+        HIPCHK(hipMemsetAsync(s->d_gt_own[k], 0, vbytes, s->stream));
+    }
     HIPCHK(hipMalloc(&s->d_st, sizeof(DevState)));
-    if (s->variant == ELLHIP_SPACE_ELL_STABLE) HIPCHK(hipMalloc(&s->d_work, (size_t)n * 6 * sizeof(double)));
-    HIPCHK(hipHostMalloc(&s->h_stage, stage_bytes(n), hipHostMallocDefault));
+    if (s->variant == ELLHIP_SPACE_ELL_STABLE) HIPCHK(hipMalloc(&s->d_work, vbytes * 6));
     HIPCHK(hipHostMalloc(&s->h_result, sizeof(DevState), hipHostMallocDefault));
-    HIPCHK(hipMemsetAsync(s->d_gt_own, 0, (size_t)n * sizeof(double), s->stream));
     return 0;
 }
 
@@ -371,9 +423,8 @@ bool host_is_symmetric(const double* mq, long long n) {
     return true;
 }
 
-int create_impl(ellhip_space** out, int variant, long long n, long long row0, long long nrows,
-                bool sharded, double kappa, const double* mq, const double* diag, const double* xc,
-                int device) {
+int create_impl(ellhip_space** out, int variant, long long n, long long row0, long long nrows, bool sharded,
+                double kappa, const double* mq, const double* diag, const double* xc, int device) {
     if (!out) return fail(ELLHIP_E_INVALID, "out is NULL");
     *out = nullptr;
     if (n < 1 || nrows < 1 || row0 < 0 || row0 + nrows > n) return fail(ELLHIP_E_INVALID, "bad dimensions");
@@ -398,8 +449,9 @@ int create_impl(ellhip_space** out, int variant, long long n, long long row0, lo
     s->device = device;
     s->kappa = kappa;
     s->tsq = 0.0;
-    // Leading dimension: keep 16-byte row alignment for even n; break the power-of-two row pitch
-    // (all rows of a tile on one HBM channel group) with one extra 128-byte line per row.
+    // Leading dimension: rows stay 16-byte aligned for even n.  For blocks that stream from HBM a
+    // power-of-two row pitch is broken up with one extra 128-byte line per row (GEMV pass at
+    // n = 16384: 5.8 -> 6.3 TB/s); blocks that live in the Infinity Cache are left dense.
     s->ld = n;
     if ((n % 512) == 0 && (double)nrows * (double)n * 8.0 > 200.0 * 1024 * 1024) s->ld = n + 16;
     s->ld = n + env_int("ELLHIP_PAD", (int)(s->ld - n));
@@ -419,8 +471,8 @@ int create_impl(ellhip_space** out, int variant, long long n, long long row0, lo
     };
     // centre
     if (xc) {
-        memcpy(s->h_stage, xc, (size_t)n * sizeof(double));
-        if (hipMemcpyAsync(s->d_xc, s->h_stage, (size_t)n * sizeof(double), hipMemcpyHostToDevice, s->stream) !=
+        memcpy(s->h_stage[0], xc, (size_t)n * sizeof(double));
+        if (hipMemcpyAsync(s->d_xc, s->h_stage[0], (size_t)n * sizeof(double), hipMemcpyHostToDevice, s->stream) !=
             hipSuccess)
             return bail(fail(ELLHIP_E_HIP, "upload xc"));
         if (hipStreamSynchronize(s->stream) != hipSuccess) return bail(fail(ELLHIP_E_HIP, "sync"));
@@ -444,11 +496,11 @@ int create_impl(ellhip_space** out, int variant, long long n, long long row0, lo
     } else {
         double* d_diag = nullptr;
         if (diag) {
-            memcpy(s->h_stage, diag, (size_t)n * sizeof(double));
-            if (hipMemcpyAsync(s->d_stage, s->h_stage, (size_t)n * sizeof(double), hipMemcpyHostToDevice,
+            memcpy(s->h_stage[0], diag, (size_t)n * sizeof(double));
+            if (hipMemcpyAsync(s->d_stage[0], s->h_stage[0], (size_t)n * sizeof(double), hipMemcpyHostToDevice,
                                s->stream) != hipSuccess)
                 return bail(fail(ELLHIP_E_HIP, "upload diag"));
-            d_diag = s->d_stage;
+            d_diag = s->d_stage[0];
         }
         hipLaunchKernelGGL(k_fill_diag, dim3(2048), dim3(256), 0, s->stream, s->d_Q, s->ld, n, nrows, row0,
                            (const double*)d_diag);
@@ -461,26 +513,6 @@ int create_impl(ellhip_space** out, int variant, long long n, long long row0, lo
     return 0;
 }
 
-int stage_cut(ellhip_space* s, int kind, const double* grad, double b0, int has_b1, double b1) {
-    if (!grad) return fail(ELLHIP_E_INVALID, "grad is NULL");
-    if (kind < 0 || kind > 2) return fail(ELLHIP_E_INVALID, "bad cut kind");
-    const long long n = s->n;
-    memcpy(s->h_stage, grad, (size_t)n * sizeof(double));
-    CutParams cp;
-    cp.kind = kind;
-    cp.has_b1 = has_b1 ? 1 : 0;
-    cp.b0 = b0;
-    cp.b1 = has_b1 ? b1 : 0.0;
-    memcpy(reinterpret_cast<char*>(s->h_stage) + (size_t)n * sizeof(double), &cp, sizeof cp);
-    HIPCHK(hipMemcpyAsync(s->d_stage, s->h_stage, stage_bytes(n), hipMemcpyHostToDevice, s->stream));
-    return 0;
-}
-
-const CutParams* stage_params_dev(const ellhip_space* s) {
-    return reinterpret_cast<const CutParams*>(reinterpret_cast<const char*>(s->d_stage) +
-                                              (size_t)s->n * sizeof(double));
-}
-
 void queue_free(ellhip_space* s) {
     if (s->d_qparams) (void)hipFree(s->d_qparams);
     if (s->d_qgrads) (void)hipFree(s->d_qgrads);
@@ -491,6 +523,53 @@ void queue_free(ellhip_space* s) {
     s->d_qstatus = nullptr;
     s->d_qtsq = nullptr;
     s->qk = 0;
+}
+
+const double* qgrad(const ellhip_space* s, long long i) { return s->d_qgrads + (size_t)i * (size_t)s->n; }
+
+int queue_index_ok(const ellhip_space* s, long long i) {
+    if (!s) return fail(ELLHIP_E_INVALID, "NULL handle");
+    if (i < 0 || i >= s->qk) return fail(ELLHIP_E_INVALID, "queue index out of range");
+    return 0;
+}
+
+// queue: make sure gt[cur] = Q * grad[index] (no-op when the previous commit already fused it)
+int queue_prime_impl(ellhip_space* s, long long index) {
+    if (s->primed && s->primed_qindex == index) return 0;
+    int rc = ensure_committed(s);
+    if (rc) return rc;
+    rc = do_prime(s, qgrad(s, index), s->cur);
+    if (rc) return rc;
+    s->primed = true;
+    s->g_cur = qgrad(s, index);
+    s->primed_qindex = index;
+    return 0;
+}
+
+int queue_cut_impl(ellhip_space* s, long long index) {
+    if (!(s->primed && s->primed_qindex == index)) return fail(ELLHIP_E_STATE, "queue_cut: this cut is not primed");
+    CutParams none{};
+    int rc = do_cut(s, s->g_cur, s->d_qparams + index, none, 1, s->d_qstatus + index, s->d_qtsq + index);
+    if (rc) return rc;
+    s->shrink_pending = true;  // whether it really applies is decided on the device (DevState.apply)
+    return 0;
+}
+
+int queue_commit_impl(ellhip_space* s, long long index, long long next) {
+    (void)index;
+    const double* gnext = (next >= 0) ? qgrad(s, next) : nullptr;
+    int rc = do_commit(s, s->shrink_pending, gnext);
+    if (rc) return rc;
+    s->shrink_pending = false;
+    if (gnext) {
+        s->cur ^= 1;
+        s->primed = true;
+        s->g_cur = gnext;
+        s->primed_qindex = next;
+    } else {
+        drop_prime(s);
+    }
+    return 0;
 }
 
 }  // namespace
@@ -507,10 +586,10 @@ int ellhip_device_count(void) {
 
 const char* ellhip_last_error(void) { return g_last_error.c_str(); }
 
-const char* ellhip_version(void) { return "ellhip 0.1.0 gfx950"; }
+const char* ellhip_version(void) { return "ellhip 0.2.0 gfx950"; }
 
-int ellhip_create(ellhip_space** out, int variant, int64_t n, double kappa, const double* mq,
-                  const double* diag, const double* xc, int device) {
+int ellhip_create(ellhip_space** out, int variant, int64_t n, double kappa, const double* mq, const double* diag,
+                  const double* xc, int device) {
     return create_impl(out, variant, n, 0, n, false, kappa, mq, diag, xc, device);
 }
 
@@ -530,19 +609,25 @@ void ellhip_destroy(ellhip_space* s) {
     queue_free(s);
     if (s->d_Q) (void)hipFree(s->d_Q);
     if (s->d_xc) (void)hipFree(s->d_xc);
-    if (s->d_stage) (void)hipFree(s->d_stage);
-    if (s->d_gt_own) (void)hipFree(s->d_gt_own);
+    for (int k = 0; k < 2; ++k) {
+        if (s->d_stage[k]) (void)hipFree(s->d_stage[k]);
+        if (s->d_gt_own[k]) (void)hipFree(s->d_gt_own[k]);
+        if (s->h_stage[k]) (void)hipHostFree(s->h_stage[k]);
+    }
     if (s->d_work) (void)hipFree(s->d_work);
     if (s->d_st) (void)hipFree(s->d_st);
-    if (s->h_stage) (void)hipHostFree(s->h_stage);
     if (s->h_result) (void)hipHostFree(s->h_result);
     if (s->own_stream) (void)hipStreamDestroy(s->own_stream);
     delete s;
 }
 
-int ellhip_clone(const ellhip_space* src, ellhip_space** out) {
-    if (!src || !out) return fail(ELLHIP_E_INVALID, "NULL argument");
+int ellhip_clone(const ellhip_space* src_c, ellhip_space** out) {
+    if (!src_c || !out) return fail(ELLHIP_E_INVALID, "NULL argument");
     *out = nullptr;
+    ellhip_space* src = const_cast<ellhip_space*>(src_c);  // committing a pending shrink is not observable
+    DeviceGuard guard(src->device);
+    int rc = ensure_committed(src);
+    if (rc) return rc;
     ellhip_space* s = new (std::nothrow) ellhip_space();
     if (!s) return fail(ELLHIP_E_NOMEM, "host allocation failed");
     s->variant = src->variant;
@@ -557,14 +642,10 @@ int ellhip_clone(const ellhip_space* src, ellhip_space** out) {
     s->needs_mirror = src->needs_mirror;
     s->kappa = src->kappa;
     s->tsq = src->tsq;
-    s->rw_gemv = src->rw_gemv;
-    s->unr_gemv = src->unr_gemv;
-    s->rw_rank1 = src->rw_rank1;
-    s->unr_rank1 = src->unr_rank1;
-    s->nt_gemv = src->nt_gemv;
-    s->nt_rank1 = src->nt_rank1;
-    DeviceGuard guard(s->device);
-    int rc = alloc_common(s);
+    s->sh_gemv = src->sh_gemv;
+    s->sh_rank1 = src->sh_rank1;
+    s->sh_fused = src->sh_fused;
+    rc = alloc_common(s);
     if (rc) {
         ellhip_destroy(s);
         return rc;
@@ -576,8 +657,7 @@ int ellhip_clone(const ellhip_space* src, ellhip_space** out) {
                            hipMemcpyDeviceToDevice, s->stream);
     if (e == hipSuccess)
         e = hipMemcpyAsync(s->d_xc, src->d_xc, (size_t)s->n * sizeof(double), hipMemcpyDeviceToDevice, s->stream);
-    if (e == hipSuccess)
-        e = hipMemcpyAsync(s->d_st, src->d_st, sizeof(DevState), hipMemcpyDeviceToDevice, s->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(s->d_st, src->d_st, sizeof(DevState), hipMemcpyDeviceToDevice, s->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
     if (e != hipSuccess) {
         ellhip_destroy(s);
@@ -587,26 +667,97 @@ int ellhip_clone(const ellhip_space* src, ellhip_space** out) {
     return 0;
 }
 
-int ellhip_update_begin(ellhip_space* s, int kind, const double* grad, double beta0, int has_beta1,
-                        double beta1) {
+// ---- pipelined primitives ---------------------------------------------------------------------
+
+int ellhip_prime(ellhip_space* s, const double* grad) {
     if (!s) return fail(ELLHIP_E_INVALID, "NULL handle");
-    if (s->pending) return fail(ELLHIP_E_STATE, "update_begin called twice");
     DeviceGuard guard(s->device);
-    int rc = stage_cut(s, kind, grad, beta0, has_beta1, beta1);
+    int rc = ensure_committed(s);
     if (rc) return rc;
-    rc = issue_phase1(s, s->d_stage);
+    // re-priming over a gradient that may still be uploading: let the stream drain before the pinned
+    // staging buffer of this slot is overwritten
+    if (s->primed) HIPCHK(hipStreamSynchronize(s->stream));
+    rc = stage_grad(s, grad, s->cur);
     if (rc) return rc;
-    s->pending = true;
+    rc = do_prime(s, s->d_stage[s->cur], s->cur);
+    if (rc) return rc;
+    s->primed = true;
+    s->g_cur = s->d_stage[s->cur];
+    s->primed_qindex = -1;
+    return 0;
+}
+
+int ellhip_cut(ellhip_space* s, int kind, double beta0, int has_beta1, double beta1) {
+    if (!s) return fail(ELLHIP_E_INVALID, "NULL handle");
+    if (!s->primed) return fail(ELLHIP_E_STATE, "ellhip_cut without a primed gradient");
+    if (s->shrink_pending) return fail(ELLHIP_E_STATE, "ellhip_cut: previous cut not committed");
+    DeviceGuard guard(s->device);
+    CutParams cp;
+    int rc = make_params(kind, beta0, has_beta1, beta1, cp);
+    if (rc) return rc;
+    rc = do_cut(s, s->g_cur, nullptr, cp, 0, nullptr, nullptr);
+    if (rc) return rc;
+    rc = read_back(s);
+    if (rc) return rc;
+    const int status = s->h_result->status;
+    s->shrink_pending = (status == ELLHIP_SUCCESS) && s->variant == ELLHIP_SPACE_ELL;
+    s->primed = false;  // the gradient has been consumed; gt[cur] stays valid for the pending shrink
+    return status;
+}
+
+int ellhip_commit(ellhip_space* s, const double* next_grad) {
+    if (!s) return fail(ELLHIP_E_INVALID, "NULL handle");
+    if (s->in_two_phase) return fail(ELLHIP_E_STATE, "update_begin without update_end");
+    DeviceGuard guard(s->device);
+    const int nslot = s->cur ^ 1;
+    if (next_grad) {
+        int rc = stage_grad(s, next_grad, nslot);
+        if (rc) return rc;
+    }
+    const bool shrink = s->shrink_pending;
+    int rc = do_commit(s, shrink, next_grad ? s->d_stage[nslot] : nullptr);
+    if (rc) return rc;
+    if (shrink) s->needs_mirror = false;  // the mirror ran ahead of this successful shrink
+    s->shrink_pending = false;
+    if (next_grad) {
+        s->cur = nslot;
+        s->primed = true;
+        s->g_cur = s->d_stage[nslot];
+        s->primed_qindex = -1;
+    } else {
+        drop_prime(s);
+    }
+    return 0;
+}
+
+// ---- the SearchSpace update and its two-phase form ------------------------------------------------
+
+int ellhip_update_begin(ellhip_space* s, int kind, const double* grad, double beta0, int has_beta1, double beta1) {
+    if (!s) return fail(ELLHIP_E_INVALID, "NULL handle");
+    if (s->in_two_phase) return fail(ELLHIP_E_STATE, "update_begin called twice");
+    if (!grad) return fail(ELLHIP_E_INVALID, "grad is NULL");
+    CutParams cp;
+    int rc = make_params(kind, beta0, has_beta1, beta1, cp);
+    if (rc) return rc;
+    rc = ellhip_prime(s, grad);
+    if (rc) return rc;
+    s->two_phase_cp = cp;
+    s->in_two_phase = true;
     return 0;
 }
 
 int ellhip_update_end(ellhip_space* s) {
     if (!s) return fail(ELLHIP_E_INVALID, "NULL handle");
-    if (!s->pending) return fail(ELLHIP_E_STATE, "update_end without update_begin");
+    if (!s->in_two_phase) return fail(ELLHIP_E_STATE, "update_end without update_begin");
     DeviceGuard guard(s->device);
-    s->pending = false;
-    int rc = issue_phase2(s, s->d_stage, stage_params_dev(s), 0, nullptr, nullptr);
+    s->in_two_phase = false;
+    int rc = do_cut(s, s->g_cur, nullptr, s->two_phase_cp, 0, nullptr, nullptr);
     if (rc) return rc;
+    // the rank-1 pass is skipped on the device when the cut failed, so it can be issued before the
+    // status is known: one host synchronisation per update
+    rc = do_commit(s, true, nullptr);
+    if (rc) return rc;
+    drop_prime(s);
     rc = read_back(s);
     if (rc) return rc;
     const int status = s->h_result->status;
@@ -635,16 +786,21 @@ int ellhip_get_xc(const ellhip_space* s, double* xc_out) {
 int ellhip_set_xc(ellhip_space* s, const double* xc) {
     if (!s || !xc) return fail(ELLHIP_E_INVALID, "NULL argument");
     DeviceGuard guard(s->device);
+    // staged through the slot that is NOT holding a primed gradient
+    const int slot = s->cur ^ 1;
     HIPCHK(hipStreamSynchronize(s->stream));
-    memcpy(s->h_stage, xc, (size_t)s->n * sizeof(double));
-    HIPCHK(hipMemcpyAsync(s->d_xc, s->h_stage, (size_t)s->n * sizeof(double), hipMemcpyHostToDevice, s->stream));
+    memcpy(s->h_stage[slot], xc, (size_t)s->n * sizeof(double));
+    HIPCHK(hipMemcpyAsync(s->d_xc, s->h_stage[slot], (size_t)s->n * sizeof(double), hipMemcpyHostToDevice, s->stream));
     HIPCHK(hipStreamSynchronize(s->stream));
     return 0;
 }
 
-int ellhip_get_mq(const ellhip_space* s, double* mq_out) {
-    if (!s || !mq_out) return fail(ELLHIP_E_INVALID, "NULL argument");
+int ellhip_get_mq(const ellhip_space* s_c, double* mq_out) {
+    if (!s_c || !mq_out) return fail(ELLHIP_E_INVALID, "NULL argument");
+    ellhip_space* s = const_cast<ellhip_space*>(s_c);
     DeviceGuard guard(s->device);
+    int rc = ensure_committed(s);
+    if (rc) return rc;
     HIPCHK(hipMemcpy2DAsync(mq_out, (size_t)s->n * sizeof(double), s->d_Q, (size_t)s->ld * sizeof(double),
                             (size_t)s->n * sizeof(double), (size_t)s->nrows, hipMemcpyDeviceToHost, s->stream));
     HIPCHK(hipStreamSynchronize(s->stream));
@@ -664,8 +820,8 @@ int ellhip_set_use_parallel_cut(ellhip_space* s, int flag) {
     return 0;
 }
 
-int ellhip_calc(int64_t n, int use_parallel_cut, int kind, double beta0, int has_beta1, double beta1,
-                double tsq, double* out3, int device) {
+int ellhip_calc(int64_t n, int use_parallel_cut, int kind, double beta0, int has_beta1, double beta1, double tsq,
+                double* out3, int device) {
     if (!out3 || n < 1 || kind < 0 || kind > 2) return fail(ELLHIP_E_INVALID, "bad argument");
     if (ellhip_device_count() <= 0) return fail(ELLHIP_E_NODEVICE, "no HIP device");
     if (device < 0 && hipGetDevice(&device) != hipSuccess) device = 0;
@@ -688,21 +844,25 @@ int ellhip_calc(int64_t n, int use_parallel_cut, int kind, double beta0, int has
     return (int)h[0];
 }
 
-double* ellhip_gt_dev(ellhip_space* s) { return s ? s->d_gt : nullptr; }
+double* ellhip_gt_dev(ellhip_space* s) { return s ? s->d_gt[s->cur] : nullptr; }
 
-int ellhip_set_gt_dev(ellhip_space* s, double* gt_dev) {
+int ellhip_set_gt_dev(ellhip_space* s, double* gt_dev_a, double* gt_dev_b) {
     if (!s) return fail(ELLHIP_E_INVALID, "NULL handle");
-    if (s->pending) return fail(ELLHIP_E_STATE, "update in flight");
-    s->d_gt = gt_dev ? gt_dev : s->d_gt_own;
+    if (s->in_two_phase || s->primed || s->shrink_pending) return fail(ELLHIP_E_STATE, "update in flight");
+    s->d_gt[0] = gt_dev_a ? gt_dev_a : s->d_gt_own[0];
+    s->d_gt[1] = gt_dev_b ? gt_dev_b : s->d_gt_own[1];
     return 0;
 }
 
 // ---- queue ------------------------------------------------------------------------------------
 
-int ellhip_queue_upload(ellhip_space* s, int64_t k, const int32_t* kinds, const double* grads,
-                        const double* beta0, const int32_t* has_beta1, const double* beta1) {
+int ellhip_queue_upload(ellhip_space* s, int64_t k, const int32_t* kinds, const double* grads, const double* beta0,
+                        const int32_t* has_beta1, const double* beta1) {
     if (!s || k < 1 || !kinds || !grads || !beta0) return fail(ELLHIP_E_INVALID, "bad argument");
     DeviceGuard guard(s->device);
+    int rc = ensure_committed(s);
+    if (rc) return rc;
+    drop_prime(s);
     HIPCHK(hipStreamSynchronize(s->stream));
     queue_free(s);
     const long long n = s->n;
@@ -726,25 +886,55 @@ int ellhip_queue_upload(ellhip_space* s, int64_t k, const int32_t* kinds, const 
     return 0;
 }
 
-int ellhip_queue_begin(ellhip_space* s, int64_t index) {
-    if (!s || index < 0 || index >= s->qk) return fail(ELLHIP_E_INVALID, "queue index out of range");
+int ellhip_queue_prime(ellhip_space* s, int64_t index) {
+    int rc = queue_index_ok(s, index);
+    if (rc) return rc;
     DeviceGuard guard(s->device);
-    return issue_phase1(s, s->d_qgrads + (size_t)index * (size_t)s->n);
+    return queue_prime_impl(s, index);
 }
 
-int ellhip_queue_end(ellhip_space* s, int64_t index) {
-    if (!s || index < 0 || index >= s->qk) return fail(ELLHIP_E_INVALID, "queue index out of range");
+int ellhip_queue_cut(ellhip_space* s, int64_t index) {
+    int rc = queue_index_ok(s, index);
+    if (rc) return rc;
     DeviceGuard guard(s->device);
-    return issue_phase2(s, s->d_qgrads + (size_t)index * (size_t)s->n, s->d_qparams + index, 1,
-                        s->d_qstatus + index, s->d_qtsq + index);
+    return queue_cut_impl(s, index);
+}
+
+int ellhip_queue_commit(ellhip_space* s, int64_t index, int64_t next_index) {
+    int rc = queue_index_ok(s, index);
+    if (rc) return rc;
+    if (next_index >= s->qk) return fail(ELLHIP_E_INVALID, "queue next_index out of range");
+    DeviceGuard guard(s->device);
+    return queue_commit_impl(s, index, next_index);
+}
+
+int ellhip_queue_begin(ellhip_space* s, int64_t index) { return ellhip_queue_prime(s, index); }
+
+int ellhip_queue_end(ellhip_space* s, int64_t index) {
+    int rc = ellhip_queue_cut(s, index);
+    if (rc) return rc;
+    return ellhip_queue_commit(s, index, -1);
 }
 
 int ellhip_queue_run(ellhip_space* s, int64_t first, int64_t count) {
     if (!s || first < 0 || count < 0 || first + count > s->qk) return fail(ELLHIP_E_INVALID, "queue range");
+    DeviceGuard guard(s->device);
     for (int64_t i = first; i < first + count; ++i) {
-        int rc = ellhip_queue_begin(s, i);
+        int rc = queue_prime_impl(s, i);
+        if (!rc) rc = queue_cut_impl(s, i);
+        if (!rc) rc = queue_commit_impl(s, i, -1);
         if (rc) return rc;
-        rc = ellhip_queue_end(s, i);
+    }
+    return 0;
+}
+
+int ellhip_queue_run_fused(ellhip_space* s, int64_t first, int64_t count) {
+    if (!s || first < 0 || count < 0 || first + count > s->qk) return fail(ELLHIP_E_INVALID, "queue range");
+    DeviceGuard guard(s->device);
+    for (int64_t i = first; i < first + count; ++i) {
+        int rc = queue_prime_impl(s, i);  // only the first cut of a run pays a separate GEMV pass
+        if (!rc) rc = queue_cut_impl(s, i);
+        if (!rc) rc = queue_commit_impl(s, i, (i + 1 < s->qk) ? i + 1 : -1);
         if (rc) return rc;
     }
     return 0;
@@ -755,20 +945,24 @@ int ellhip_queue_results(ellhip_space* s, int32_t* status_out, double* tsq_out) 
     DeviceGuard guard(s->device);
     int rc = read_back(s);
     if (rc) return rc;
-    if (status_out) HIPCHK(hipMemcpy(status_out, s->d_qstatus, (size_t)s->qk * sizeof(int), hipMemcpyDeviceToHost));
+    std::vector<int32_t> st((size_t)s->qk);
+    HIPCHK(hipMemcpy(st.data(), s->d_qstatus, (size_t)s->qk * sizeof(int), hipMemcpyDeviceToHost));
+    if (status_out) memcpy(status_out, st.data(), (size_t)s->qk * sizeof(int));
     if (tsq_out) HIPCHK(hipMemcpy(tsq_out, s->d_qtsq, (size_t)s->qk * sizeof(double), hipMemcpyDeviceToHost));
-    if (s->needs_mirror && status_out) {
+    if (s->needs_mirror) {
         for (int64_t i = 0; i < s->qk; ++i)
-            if (status_out[i] == ELLHIP_SUCCESS) {
+            if (st[(size_t)i] == ELLHIP_SUCCESS) {
                 s->needs_mirror = false;
                 break;
             }
     }
-    // a halted queue stays halted until the next upload; clear the flag so direct updates work again
+    // a halted queue stays halted until its results have been read; then direct updates work again
     if (s->h_result->halted) {
         s->h_result->halted = 0;
         HIPCHK(hipMemcpyAsync(s->d_st, s->h_result, sizeof(DevState), hipMemcpyHostToDevice, s->stream));
         HIPCHK(hipStreamSynchronize(s->stream));
+        drop_prime(s);  // whatever was primed beyond the failing cut never ran
+        s->shrink_pending = false;
     }
     return 0;
 }

@@ -167,8 +167,9 @@ __global__ __launch_bounds__(1024) void k_st_mid(double* __restrict__ M, long lo
                                                  const double* __restrict__ z, const double* __restrict__ gg,
                                                  double* __restrict__ q, double* __restrict__ beta2,
                                                  DevState* __restrict__ st, EllCalcDev calc,
-                                                 const CutParams* __restrict__ cp, int queue_mode,
-                                                 int* __restrict__ q_status, double* __restrict__ q_tsq) {
+                                                 const CutParams* __restrict__ cp_dev, CutParams cp_val,
+                                                 int queue_mode, int* __restrict__ q_status,
+                                                 double* __restrict__ q_tsq) {
     __shared__ double red[16];
     __shared__ double tot[1024];
     __shared__ double bc[2];
@@ -207,7 +208,8 @@ __global__ __launch_bounds__(1024) void k_st_mid(double* __restrict__ M, long lo
         const double kappa = st->kappa;
         const double tsq = kappa * omega;  // :85
         Coef cf;
-        const int status = calc.dispatch(cp->kind, cp->b0, cp->has_b1, cp->b1, tsq, cf);  // :86
+        const CutParams cp = cp_dev ? *cp_dev : cp_val;
+        const int status = calc.dispatch(cp.kind, cp.b0, cp.has_b1, cp.b1, tsq, cf);  // :86
         st->tsq = tsq;
         st->omega = omega;
         st->status = status;

@@ -139,6 +139,19 @@ class _SpaceBase:
     def update_q(self, cut) -> CutStatus:
         return self._update(capi.CUT_Q, cut)
 
+    # ---- pipelined form (include/ellhip.h "pipelined update"): same results, one pass over Q per update
+    def prime(self, grad) -> None:
+        g = _f64(grad, self.n)
+        capi.check(self._lib.ellhip_prime(self._h, _p(g)), "ellhip_prime")
+
+    def cut(self, kind: int, beta) -> CutStatus:
+        b0, has1, b1 = _split(beta)
+        return CutStatus(capi.check(self._lib.ellhip_cut(self._h, kind, b0, has1, b1), "ellhip_cut"))
+
+    def commit(self, next_grad=None) -> None:
+        g = None if next_grad is None else _f64(next_grad, self.n)
+        capi.check(self._lib.ellhip_commit(self._h, _p(g)), "ellhip_commit")
+
     # ---- fields
     @property
     def kappa(self) -> float:
@@ -172,8 +185,9 @@ class _SpaceBase:
         self._qk = k
         return k
 
-    def queue_run(self, first: int, count: int) -> None:
-        capi.check(self._lib.ellhip_queue_run(self._h, first, count), "ellhip_queue_run")
+    def queue_run(self, first: int, count: int, fused: bool = False) -> None:
+        fn = self._lib.ellhip_queue_run_fused if fused else self._lib.ellhip_queue_run
+        capi.check(fn(self._h, first, count), "ellhip_queue_run")
 
     def queue_results(self):
         st = np.empty(self._qk, dtype=np.int32)

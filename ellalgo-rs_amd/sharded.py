@@ -57,14 +57,21 @@ class HipShardEngine:
         dev = torch.device("cuda", torch.cuda.current_device() if device < 0 else device)
         # gt lives in a tensor the collective library can address; all HIP work and the collective are
         # issued on one non-default torch stream, so they are ordered without host synchronisation
-        self.gt = torch.zeros(n, dtype=torch.float64, device=dev)
+        self._gts = [torch.zeros(n, dtype=torch.float64, device=dev) for _ in range(2)]
+        self._by_ptr = {t.data_ptr(): t for t in self._gts}
         self.stream = torch.cuda.Stream(device=dev)
         torch.cuda.synchronize(dev)
-        capi.check(self._lib.ellhip_set_gt_dev(h, C.c_void_p(self.gt.data_ptr())))
+        capi.check(self._lib.ellhip_set_gt_dev(h, C.c_void_p(self._gts[0].data_ptr()),
+                                               C.c_void_p(self._gts[1].data_ptr())))
         capi.check(self._lib.ellhip_set_stream(h, C.c_void_p(self.stream.cuda_stream)))
 
     def issue(self):
         return self._torch.cuda.stream(self.stream)
+
+    @property
+    def gt(self):
+        """The tensor holding Q*g of the most recently primed gradient (the one to all-gather)."""
+        return self._by_ptr[self._lib.ellhip_gt_dev(self.h)]
 
     def begin(self, kind, g, b0, has1, b1):
         capi.check(self._lib.ellhip_update_begin(self.h, kind, _p(g), b0, has1, b1), "ellhip_update_begin")
@@ -81,6 +88,15 @@ class HipShardEngine:
 
     def queue_end(self, i):
         capi.check(self._lib.ellhip_queue_end(self.h, i), "ellhip_queue_end")
+
+    def queue_prime(self, i):
+        capi.check(self._lib.ellhip_queue_prime(self.h, i), "ellhip_queue_prime")
+
+    def queue_cut(self, i):
+        capi.check(self._lib.ellhip_queue_cut(self.h, i), "ellhip_queue_cut")
+
+    def queue_commit(self, i, nxt):
+        capi.check(self._lib.ellhip_queue_commit(self.h, i, nxt), "ellhip_queue_commit")
 
     def queue_results(self, k):
         st = np.empty(k, dtype=np.int32)
@@ -150,6 +166,7 @@ class ShardedEll:
         self.engine = factory(self.n, self.row0, self.nrows, float(kappa), mq_rows, diag, xc)
         self._exchange = exchange or allgather_in_place
         self._qk = 0
+        self._primed_index = -1
 
     @classmethod
     def new_with_scalar(cls, val, xc, **kw):
@@ -218,18 +235,35 @@ class ShardedEll:
             b1[np.isnan(b1)] = 0.0
         self.engine.queue_upload(k, kinds, grads, beta0, has1, b1)
         self._qk = k
+        self._primed_index = -1
         return k
 
-    def queue_run(self, first: int, count: int) -> None:
+    def queue_run(self, first: int, count: int, fused: bool = False) -> None:
         eng, ex, row0, nrows = self.engine, self._exchange, self.row0, self.nrows
         with self._issue():
-            for i in range(first, first + count):
-                eng.queue_begin(i)
+            if not fused:   # two passes over the local rows per cut
+                for i in range(first, first + count):
+                    eng.queue_begin(i)
+                    ex(eng.gt, row0, nrows)
+                    eng.queue_end(i)
+                return
+            # pipelined: one pass per cut; the collective follows whichever call ran a GEMV
+            if self._primed_index != first:
+                eng.queue_prime(first)
                 ex(eng.gt, row0, nrows)
-                eng.queue_end(i)
+            for i in range(first, first + count):
+                nxt = i + 1 if i + 1 < self._qk else -1
+                eng.queue_cut(i)
+                eng.queue_commit(i, nxt)
+                if nxt >= 0:
+                    ex(eng.gt, row0, nrows)
+                self._primed_index = nxt
 
     def queue_results(self):
-        return self.engine.queue_results(self._qk)
+        st, ts = self.engine.queue_results(self._qk)
+        if np.any(st[st >= 0] != 0):   # the queue halted: nothing stays primed
+            self._primed_index = -1
+        return st, ts
 
     def synchronize(self):
         self.engine.synchronize()

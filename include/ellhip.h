@@ -126,11 +126,32 @@ int ellhip_calc(int64_t n, int use_parallel_cut, int kind, double beta0, int has
 int ellhip_update_begin(ellhip_space *s, int kind, const double *grad, double beta0,
                         int has_beta1, double beta1);
 int ellhip_update_end(ellhip_space *s);
-/* Device pointer of the full-length (n doubles) gt buffer. */
+/* Device pointer of the full-length (n doubles) gt buffer of the most recently primed gradient
+ * (the one to all-gather). */
 double *ellhip_gt_dev(ellhip_space *s);
-/* Use caller-provided device memory (n doubles) as the gt buffer, e.g. a tensor a collective
- * library already knows.  NULL restores the handle's own buffer. */
-int ellhip_set_gt_dev(ellhip_space *s, double *gt_dev);
+/* Use caller-provided device memory (n doubles each) as the two gt buffers, e.g. tensors a
+ * collective library already knows (the pipelined schedule alternates between them; the two-phase
+ * schedule only uses the one ellhip_gt_dev returns).  NULLs restore the handle's own buffers. */
+int ellhip_set_gt_dev(ellhip_space *s, double *gt_dev_a, double *gt_dev_b);
+
+/* ---- pipelined update: 16 n^2 instead of 24 n^2 bytes per update (Ell) -----------------------
+ * Ell::update_core reads Q twice: once for gt = Q*g (src/ell.rs:102) and once for the rank-1 shrink
+ * (src/ell.rs:117-128).  The NEXT cut's gradient only depends on the new centre, which the scalar
+ * stage (src/ell.rs:103-115) produces BEFORE the shrink, so the shrink of update k and the GEMV of
+ * update k+1 can share one pass over Q.  Results are bit-identical to ellhip_update.
+ *   ellhip_prime(grad)      gt = Q*grad for the first cut                          (asynchronous)
+ *   ellhip_cut(kind, betas) scalar stage of the primed cut: status, tsq, xc, kappa are final and
+ *                           observable at return (synchronous); Q is not shrunk yet
+ *   ellhip_commit(next)     shrink Q for the cut just taken (if it succeeded) and, in the same pass,
+ *                           prime `next` (NULL: shrink only)                       (asynchronous)
+ * Driver shape (equivalent to src/cutting_plane.rs:299-311):
+ *   prime(g0); loop { st = cut(..); if stop { commit(NULL); break; } x = get_xc(); (g, beta) =
+ *   oracle(x); commit(g); }
+ * Any other call that needs Q (update, get_mq, clone, ...) commits a pending shrink first.
+ * EllStable accepts the same calls but gains nothing (its work happens in ellhip_cut). */
+int ellhip_prime(ellhip_space *s, const double *grad);
+int ellhip_cut(ellhip_space *s, int kind, double beta0, int has_beta1, double beta1);
+int ellhip_commit(ellhip_space *s, const double *next_grad);
 
 /* ---- device-resident cut queue (benchmarks, replay of recorded cut sequences) ---------------
  * Uploads k cuts once; run/begin/end then execute them without touching host memory, stopping
@@ -138,11 +159,20 @@ int ellhip_set_gt_dev(ellhip_space *s, double *gt_dev);
  * drivers do (src/cutting_plane.rs:222,308).  grads: k*n doubles. */
 int ellhip_queue_upload(ellhip_space *s, int64_t k, const int32_t *kinds, const double *grads,
                         const double *beta0, const int32_t *has_beta1, const double *beta1);
-/* Enqueue cuts [first, first+count) on the stream; asynchronous. */
+/* Enqueue cuts [first, first+count) on the stream; asynchronous.  ellhip_queue_run uses the
+ * two-pass schedule (GEMV pass + rank-1 pass per cut); ellhip_queue_run_fused the pipelined one
+ * (one pass per cut: the shrink of cut i fused with the GEMV of cut i+1). Same results. */
 int ellhip_queue_run(ellhip_space *s, int64_t first, int64_t count);
-/* Two-phase form of one queued cut (multi-GPU); both asynchronous. */
+int ellhip_queue_run_fused(ellhip_space *s, int64_t first, int64_t count);
+/* Phase-wise forms of one queued cut for the multi-GPU schedule; all asynchronous.  After every call
+ * that ran a GEMV (begin, prime, commit with next_index >= 0) the caller all-gathers ellhip_gt_dev.
+ *   two-pass:   queue_begin(i) -> gather -> queue_end(i)
+ *   pipelined:  queue_prime(first) -> gather -> { queue_cut(i) -> queue_commit(i, i+1 or -1) -> gather } */
 int ellhip_queue_begin(ellhip_space *s, int64_t index);
 int ellhip_queue_end(ellhip_space *s, int64_t index);
+int ellhip_queue_prime(ellhip_space *s, int64_t index);
+int ellhip_queue_cut(ellhip_space *s, int64_t index);
+int ellhip_queue_commit(ellhip_space *s, int64_t index, int64_t next_index);
 /* Waits for the stream, then copies per-cut status (int32) and tsq (double) for all k cuts. */
 int ellhip_queue_results(ellhip_space *s, int32_t *status_out, double *tsq_out);
 
@@ -152,9 +182,10 @@ int ellhip_set_stream(ellhip_space *s, void *hip_stream);
 int ellhip_synchronize(ellhip_space *s);
 /* Per-kernel HIP-event timing: when enabled every kernel launch is bracketed by events on the
  * launch stream.  ellhip_profile_read waits for them and returns accumulated milliseconds and
- * launch counts per kernel class, then resets.  Classes: 0 = GEMV (Q*g), 1 = scalar stage,
- * 2 = rank-1 shrink, 3 = EllStable forward, 4 = EllStable backward, 5 = EllStable factor update. */
-#define ELLHIP_NKERNEL_CLASSES 6
+ * launch counts per kernel class, then resets.  Classes: 0 = GEMV pass (Q*g), 1 = scalar stage,
+ * 2 = rank-1 pass, 3 = EllStable forward, 4 = EllStable backward, 5 = EllStable factor update,
+ * 6 = fused pass (rank-1 of cut k + GEMV of cut k+1). */
+#define ELLHIP_NKERNEL_CLASSES 7
 int ellhip_profile_enable(ellhip_space *s, int flag);
 int ellhip_profile_read(ellhip_space *s, double *ms_out, int64_t *count_out);
 

@@ -25,13 +25,13 @@ class OracleShardEngine:
         self.cut = None
         self.q = None
         self.halted = False
+        self.pending = None
 
-    # ---- phase 1 / phase 2 (mirror of ellhip_update_begin / ellhip_update_end)
-    def begin(self, kind, g, b0, has1, b1):
-        self.cut = (kind, np.array(g, dtype=np.float64), b0, b1 if has1 else None)
-        oracle.rows_gemv(self.n, self.row0, self.nrows, self.Q, self.cut[1], self.gt_np)
+    # ---- the three primitives (mirror of prime / cut / commit in csrc/ellhip_capi.hip)
+    def _gemv(self, g):
+        oracle.rows_gemv(self.n, self.row0, self.nrows, self.Q, g, self.gt_np)
 
-    def end(self) -> int:
+    def _scalar(self) -> int:
         kind, g, b0, b1 = self.cut
         gt = self.gt_np
         omega = 0.0
@@ -39,16 +39,33 @@ class OracleShardEngine:
             omega += float(a) * float(b)
         self.tsqv = self.kap * omega
         st, (rho, sigma, delta) = self.calc.dispatch(kind, b0, b1, self.tsqv)
+        self.pending = None
         if st != 0:
             return st
         self.xcv -= (rho / omega) * gt   # every rank updates its full copy identically
-        ratio = sigma / omega
+        self.pending = (sigma / omega, gt.copy())
+        self.kap *= delta
+        return st
+
+    def _shrink(self):
+        if self.pending is None:
+            return
+        ratio, gt = self.pending
+        self.pending = None
         rows = self.row0 + np.arange(self.nrows)[:, None]
         cols = np.arange(self.n)[None, :]
         lower = (ratio * gt[rows]) * gt[cols]      # (ratio*gt[i])*gt[j], j <= i   (src/ell.rs:119-121)
         upper = (ratio * gt[cols]) * gt[rows]      # mirrored element (i, j) = (col, row)
         self.Q -= np.where(cols <= rows, lower, upper)
-        self.kap *= delta
+
+    # ---- phase 1 / phase 2 (mirror of ellhip_update_begin / ellhip_update_end)
+    def begin(self, kind, g, b0, has1, b1):
+        self.cut = (kind, np.array(g, dtype=np.float64), b0, b1 if has1 else None)
+        self._gemv(self.cut[1])
+
+    def end(self) -> int:
+        st = self._scalar()
+        self._shrink()
         return st
 
     # ---- queue
@@ -58,20 +75,38 @@ class OracleShardEngine:
         self.qtsq = np.zeros(k)
         self.halted = False
 
-    def queue_begin(self, i):
-        if self.halted:
-            return
+    def _qcut(self, i):
         kinds, grads, b0, has1, b1 = self.q
-        self.begin(int(kinds[i]), grads[i], float(b0[i]), int(has1[i]), float(b1[i]))
+        return (int(kinds[i]), grads[i], float(b0[i]), float(b1[i]) if has1[i] else None)
 
-    def queue_end(self, i):
+    def queue_prime(self, i):
+        if not self.halted:
+            self.cut = self._qcut(i)
+            self._gemv(self.cut[1])
+
+    def queue_cut(self, i):
         if self.halted:
             self.qstatus[i] = 3
             return
-        st = self.end()
+        self.cut = self._qcut(i)
+        st = self._scalar()
         self.qstatus[i], self.qtsq[i] = st, self.tsqv
         if st != 0:
             self.halted = True
+
+    def queue_commit(self, i, nxt):
+        if self.halted:
+            return
+        self._shrink()
+        if nxt >= 0:
+            self._gemv(self._qcut(nxt)[1])   # GEMV of the next cut on the freshly shrunk rows
+
+    def queue_begin(self, i):
+        self.queue_prime(i)
+
+    def queue_end(self, i):
+        self.queue_cut(i)
+        self.queue_commit(i, -1)
 
     def queue_results(self, k):
         self.halted = False

@@ -357,7 +357,7 @@ def test_row_sharded_two_phase_equals_unsharded(gpu, orc):
         h = C.c_void_p()
         pkg.capi.check(L.ellhip_create_shard(C.byref(h), n, r * half, half, 1.5, None, None, None, -1))
         hs.append(h)
-    pkg.capi.check(L.ellhip_set_gt_dev(hs[1], L.ellhip_gt_dev(hs[0])))
+    pkg.capi.check(L.ellhip_set_gt_dev(hs[1], L.ellhip_gt_dev(hs[0]), None))
     try:
         for i in range(10):
             g = np.ascontiguousarray(rng.standard_normal(n))
@@ -396,3 +396,113 @@ def test_bad_arguments_return_error_codes(gpu):
     assert L.ellhip_update_end(e._h) == gpu.capi.E_STATE
     with pytest.raises(ValueError):
         e.update_bias_cut((np.zeros(5), 0.0))   # n mismatch: the reference would panic (src/arr.rs:427-429)
+
+
+# ---------------------------------------------------------------- pipelined (one pass per update)
+def _pipelined_run(space, cuts):
+    """prime / cut / commit driver in the shape of include/ellhip.h; returns statuses and tsqs."""
+    out = []
+    space.prime(cuts[0][1])
+    for i, (kind, g, b0, b1) in enumerate(cuts):
+        st = space.cut(kind, (b0, b1))
+        out.append((int(st), space.tsq(), space.kappa, space.xc()))
+        nxt = cuts[i + 1][1] if i + 1 < len(cuts) else None
+        space.commit(nxt)
+    return out
+
+
+@pytest.mark.parametrize("n,no_defer", [(2, False), (33, False), (256, False), (1000, True), (2048, False)])
+def test_pipelined_is_bit_identical_to_update(gpu, orc, n, no_defer):
+    """ellhip_prime/cut/commit (shrink of cut k fused with the GEMV of cut k+1) must give exactly the
+    bits of ellhip_update, including across failed cuts (which skip the shrink but not the GEMV)."""
+    from util import mixed_cut
+    rng = np.random.default_rng(77 + n)
+    a = gpu.Ell.new_with_scalar(2.0, np.linspace(-1, 1, n))
+    b = gpu.Ell.new_with_scalar(2.0, np.linspace(-1, 1, n))
+    o = orc.OracleEll.new_with_scalar(2.0, np.linspace(-1, 1, n))
+    a.no_defer_trick = b.no_defer_trick = no_defer
+    o.set_no_defer_trick(no_defer)
+    cuts, ref = [], []
+    for i in range(24):
+        g = rng.standard_normal(n)
+        g /= np.linalg.norm(g)
+        tau = float(np.sqrt(max(o.kappa * (g @ (o.mq @ g)), 0.0)))
+        kind, b0, b1 = mixed_cut(i, g, tau, rng)
+        cuts.append((kind, g, b0, b1))
+        o.update(kind, g, b0, b1)
+        st = a._update(kind, (g, (b0, b1)))
+        ref.append((int(st), a.tsq(), a.kappa, a.xc()))
+    got = _pipelined_run(b, cuts)
+    assert any(r[0] != 0 for r in ref) and any(r[0] == 0 for r in ref)
+    for i, (r, g_) in enumerate(zip(ref, got)):
+        assert r[0] == g_[0] and r[1] == g_[1] and r[2] == g_[2], f"step {i}: {r[:3]} vs {g_[:3]}"
+        assert np.array_equal(r[3], g_[3]), f"xc step {i}"
+    assert np.array_equal(a.mq, b.mq)
+    assert_state_close(b, o, what=f"pipelined n={n}")
+
+
+def test_pipelined_observers_commit_pending_shrink(gpu):
+    """get_mq / clone / update in the middle of a pipelined sequence see the shrunk Q."""
+    n = 96
+    rng = np.random.default_rng(8)
+    g1, g2 = rng.standard_normal(n), rng.standard_normal(n)
+    a = gpu.Ell.new_with_scalar(1.0, np.zeros(n))
+    b = gpu.Ell.new_with_scalar(1.0, np.zeros(n))
+    assert a.update_bias_cut((g1, 0.01)) == 0
+    b.prime(g1)
+    assert b.cut(0, 0.01) == 0
+    assert np.array_equal(a.mq, b.mq)             # get_mq committed the shrink
+    c = b.clone()
+    assert np.array_equal(c.mq, a.mq)
+    assert a.update_central_cut((g2, 0.0)) == 0 and b.update_central_cut((g2, 0.0)) == 0
+    assert np.array_equal(a.mq, b.mq) and a.kappa == b.kappa
+
+
+def test_pipelined_nonsymmetric_input(gpu, orc):
+    n = 50
+    rng = np.random.default_rng(12)
+    mq = np.eye(n) + 0.01 * rng.standard_normal((n, n))
+    cuts = [(0, rng.standard_normal(n), 0.01, None) for _ in range(4)]
+    a = gpu.Ell.new_with_matrix(1.0, mq, np.zeros(n))
+    b = gpu.Ell.new_with_matrix(1.0, mq, np.zeros(n))
+    for kind, g, b0, b1 in cuts:
+        assert a._update(kind, (g, b0)) == 0
+    _pipelined_run(b, cuts)
+    assert np.array_equal(a.mq, b.mq) and np.array_equal(a.xc(), b.xc())
+
+
+@pytest.mark.parametrize("n", [384, 8192])
+def test_queue_fused_is_bit_identical_to_queue(gpu, n):
+    from ellalgo_rs_amd import synth
+    k = 10
+    kinds, grads, b0, b1 = synth.parallel_cuts(n, k)
+    a = gpu.Ell.new_with_scalar(1.0, np.zeros(n))
+    b = gpu.Ell.new_with_scalar(1.0, np.zeros(n))
+    a.queue_upload(kinds, grads, b0, b1)
+    b.queue_upload(kinds, grads, b0, b1)
+    a.queue_run(0, k)
+    b.queue_run(0, 3, fused=True)       # split like the benchmark: the second run finds cut 3 primed
+    b.queue_run(3, k - 3, fused=True)
+    sa, ta = a.queue_results()
+    sb, tb = b.queue_results()
+    assert np.array_equal(sa, sb) and np.array_equal(ta, tb) and np.all(sa == 0)
+    assert np.array_equal(a.mq, b.mq) and np.array_equal(a.xc(), b.xc()) and a.kappa == b.kappa
+
+
+def test_queue_fused_halts_at_first_failure(gpu):
+    n, k = 64, 6
+    rng = np.random.default_rng(2)
+    grads = rng.standard_normal((k, n))
+    kinds = np.zeros(k, dtype=np.int32)
+    b0 = np.array([0.01, 0.01, 1e9, 0.01, 0.01, 0.01])
+    a = gpu.Ell.new_with_scalar(1.0, np.zeros(n))
+    b = gpu.Ell.new_with_scalar(1.0, np.zeros(n))
+    a.queue_upload(kinds, grads, b0)
+    a.queue_run(0, k, fused=True)
+    st, _ = a.queue_results()
+    assert list(st) == [0, 0, 1, 3, 3, 3]
+    for i in range(2):
+        b.update_bias_cut((grads[i], b0[i]))
+    assert np.array_equal(a.mq, b.mq) and a.kappa == b.kappa
+    assert a.update_bias_cut((grads[3], 0.01)) == 0 and b.update_bias_cut((grads[3], 0.01)) == 0
+    assert np.array_equal(a.mq, b.mq)

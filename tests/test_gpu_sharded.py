@@ -27,7 +27,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, backend, n, k, errq):
+def _worker(rank, world, port, backend, n, k, fused, errq):
     try:
         for p in (ROOT, HERE):
             if p not in sys.path:
@@ -63,7 +63,8 @@ def _worker(rank, world, port, backend, n, k, errq):
         # then the device-resident queue
         sh.queue_upload(kinds[half:], grads[half:], b0[half:], b1[half:])
         ref.queue_upload(kinds[half:], grads[half:], b0[half:], b1[half:])
-        sh.queue_run(0, k - half)
+        sh.queue_run(0, 2, fused=fused)
+        sh.queue_run(2, k - half - 2, fused=fused)
         ref.queue_run(0, k - half)
         st_s, ts_s = sh.queue_results()
         st_r, ts_r = ref.queue_results()
@@ -77,11 +78,11 @@ def _worker(rank, world, port, backend, n, k, errq):
         raise
 
 
-def _run(world, backend, n, k):
+def _run(world, backend, n, k, fused=False):
     ctx = mp.get_context("spawn")
     errq = ctx.SimpleQueue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, backend, n, k, errq)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, backend, n, k, fused, errq)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
@@ -101,5 +102,13 @@ def test_two_ranks_one_gpu_gloo_transport(gpu):
     _run(2, "gloo", 512, 12)
 
 
+def test_two_ranks_one_gpu_pipelined_schedule(gpu):
+    _run(2, "gloo", 512, 12, fused=True)
+
+
 def test_one_rank_rccl_in_place_allgather(gpu):
     _run(1, "nccl", 1024, 12)
+
+
+def test_one_rank_rccl_pipelined_schedule(gpu):
+    _run(1, "nccl", 1024, 12, fused=True)

@@ -57,7 +57,7 @@ def _worker(rank, world, port, n, k, mode, errq):
                 ss = sh._update(kind, (g, (b0, b1)))
                 assert int(ss) == so, (i, int(ss), so)
                 assert sh.tsq() == ref.tsq
-        if mode == "queue":
+        if mode in ("queue", "queue_fused"):
             # the queue halts at the first failure, so replay only the successful prefix rule: build a
             # fresh reference that stops like the drivers do
             ref = oracle.OracleEll.new_with_scalar(2.0, xc0)
@@ -66,7 +66,11 @@ def _worker(rank, world, port, n, k, mode, errq):
             b0s = np.array([c[2] for c in cuts])
             b1s = np.array([np.nan if c[3] is None else c[3] for c in cuts])
             sh.queue_upload(kinds, grads, b0s, b1s)
-            sh.queue_run(0, k)
+            if mode == "queue":
+                sh.queue_run(0, k)
+            else:   # pipelined schedule, split in two calls like the benchmark (warm-up, then timed)
+                sh.queue_run(0, 3, fused=True)
+                sh.queue_run(3, k - 3, fused=True)
             st, ts = sh.queue_results()
             halted = False
             for i, (kind, g, b0, b1) in enumerate(cuts):
@@ -118,6 +122,10 @@ def test_sharded_direct_updates_bit_identical(world, n):
 
 def test_sharded_queue_bit_identical_and_halts():
     _run(2, 48, 16, "queue")
+
+
+def test_sharded_pipelined_queue_bit_identical_and_halts():
+    _run(2, 48, 16, "queue_fused")
 
 
 def test_partition_rules():
