@@ -97,6 +97,11 @@ def main() -> None:
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     ap.add_argument("--host-path-steps", type=int, default=20,
                     help="extra synchronous ellhip_update() calls from host buffers (PCIe-inclusive rate)")
+    ap.add_argument("--schedule", choices=["pipelined", "two-pass"], default="pipelined",
+                    help="pipelined: one pass over Q per update (shrink of cut k fused with the GEMV of cut k+1, "
+                         "16*n^2 B); two-pass: GEMV pass + rank-1 pass per update (24*n^2 B). Same results.")
+    ap.add_argument("--compare-steps", type=int, default=60,
+                    help="extra timed steps with the OTHER schedule, reported alongside (0 = skip)")
     ap.add_argument("--force-sharded", action="store_true",
                     help="run the row-partitioned (multi-GPU) code path even with one rank (rehearsal)")
     args = ap.parse_args()
@@ -129,7 +134,9 @@ def main() -> None:
     n, variant, cutgen, desc = WORKLOADS[args.workload]
     K, W, P = args.steps, args.warmup, args.profile_steps
     H = args.host_path_steps if not sharded else 0
-    total = W + K + P + H
+    fused = args.schedule == "pipelined" and variant == "ell"
+    C2 = args.compare_steps if variant == "ell" else 0
+    total = W + K + P + 2 * C2 + H
     if sharded and variant != "ell":
         raise SystemExit("EllStable does not shard: replicas only (see DESIGN.md)")
     if n % world:
@@ -147,11 +154,11 @@ def main() -> None:
     else:
         from ellalgo_rs_amd.sharded import ShardedEll
         space = ShardedEll.new_with_scalar(1.0, np.zeros(n), device=local_rank)
-    nq = W + K + P
+    nq = W + K + P + 2 * C2
     space.queue_upload(kinds[:nq], grads[:nq], b0[:nq], b1[:nq])
 
-    def run(first: int, count: int) -> None:
-        space.queue_run(first, count)
+    def run(first: int, count: int, use_fused: bool = fused) -> None:
+        space.queue_run(first, count, fused=use_fused)
 
     def fence() -> None:
         torch.cuda.synchronize()
@@ -181,8 +188,28 @@ def main() -> None:
         prof = space.profile_read()
         space.profile_enable(False)
 
+    # ---- the other schedule on the same handle, for comparison (timed the same way + per-kernel events)
+    other = None
+    if C2 > 0:
+        run(W + K + P, 0)  # no-op, keeps indices explicit
+        fence()
+        t2 = time.perf_counter()
+        run(W + K + P, C2, not fused)
+        fence()
+        el2 = time.perf_counter() - t2
+        if sharded:
+            t = torch.tensor([el2], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el2 = float(t.item())
+        space.profile_enable(True)
+        run(W + K + P + C2, C2, not fused)
+        space.synchronize()
+        other = {"schedule": "two-pass" if fused else "pipelined", "steps": C2, "updates_per_s": C2 / el2,
+                 "ms_per_step": el2 / C2 * 1e3, "prof": space.profile_read()}
+        space.profile_enable(False)
+
     status, tsqs = space.queue_results()
-    ran = W + K + P
+    ran = W + K + P + 2 * C2
     ok = bool(np.all(status[:ran] == 0))
     if not ok:
         bad = int(np.argmax(status[:ran] != 0))
@@ -206,33 +233,50 @@ def main() -> None:
         dist.destroy_process_group()
         return
 
-    bytes_update = 24.0 * n * n / world  # per GPU
+    n2w = float(n) * float(n) / world  # n^2 per GPU
     ms_per_step = elapsed / K * 1e3
     value = K / elapsed
-    roofline = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None}
-    per_kernel = {}
-    if prof:
-        alg = {"gemv": 8.0 * n * n / world, "rank1": 16.0 * n * n / world,
-               "stable_fwd": 8.0 * n * n, "stable_bwd": 4.0 * n * n, "stable_factor": 12.0 * n * n}
-        for name, (ms, cnt) in prof.items():
+    # algorithmic bytes per launch of each kernel class (per GPU)
+    alg = {"gemv": 8.0 * n2w, "rank1": 16.0 * n2w, "fused": 16.0 * n2w,
+           "stable_fwd": 8.0 * n * n, "stable_bwd": 4.0 * n * n, "stable_factor": 12.0 * n * n}
+
+    def kernel_table(pr):
+        tab = {}
+        for name, (ms, cnt) in (pr or {}).items():
             if cnt:
                 avg_ms = ms / cnt
                 e = {"avg_ms": avg_ms, "launches": cnt}
                 if name in alg:
                     e["alg_bytes"] = alg[name]
                     e["GBps"] = alg[name] / (avg_ms * 1e-3) / 1e9
-                per_kernel[name] = e
-        dom = "rank1" if variant == "ell" else max((k for k in per_kernel if k in alg), key=lambda k: per_kernel[k]["avg_ms"])
-        if dom in per_kernel:
-            roofline.update({"kernel": "k_" + dom, "achieved": per_kernel[dom]["GBps"],
-                             "frac": per_kernel[dom]["GBps"] / HBM_PEAK_GBS,
-                             "alg_bytes_per_launch": per_kernel[dom]["alg_bytes"],
-                             "avg_launch_ms": per_kernel[dom]["avg_ms"]})
+                tab[name] = e
+        return tab
+
+    per_kernel = kernel_table(prof)
+    # bytes one update moves under the schedule that was timed
+    if variant != "ell":
+        bytes_update, model = 24.0 * n * n, "24*n^2 B per update (EllStable: fwd 8 + bwd 4 + factor 12)"
+    elif fused:
+        bytes_update, model = 16.0 * n2w, ("16*n^2 B per update per GPU-share (pipelined: the rank-1 pass of cut k and the "
+                                           "GEMV of cut k+1 share one read of Q; NOT credited against the 24*n^2 model)")
+    else:
+        bytes_update, model = 24.0 * n2w, "24*n^2 B per update per GPU-share (GEMV pass 8 + rank-1 pass 16)"
+    roofline = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None, "byte_model": model}
+    if variant == "ell":
+        dom = "fused" if fused else "rank1"
+    else:
+        cands = [k for k in per_kernel if k in alg]
+        dom = max(cands, key=lambda k: per_kernel[k]["avg_ms"]) if cands else None
+    if dom in per_kernel:
+        roofline.update({"kernel": "k_sweep:" + dom if variant == "ell" else "k_st_" + dom[7:],
+                         "achieved": per_kernel[dom]["GBps"], "frac": per_kernel[dom]["GBps"] / HBM_PEAK_GBS,
+                         "alg_bytes_per_launch": per_kernel[dom]["alg_bytes"],
+                         "avg_launch_ms": per_kernel[dom]["avg_ms"]})
     try:  # measured HBM traffic per launch (PMC counters, collected separately under rocprofv3)
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
             pmc = json.load(f).get(args.workload)
-        if pmc and world == 1 and roofline.get("kernel", "").startswith("k_"):
-            roofline["traffic"] = pmc.get(roofline["kernel"][2:])
+        if pmc and world == 1 and dom:
+            roofline["traffic"] = pmc.get(dom)
             roofline["traffic_source"] = pmc.get("source")
     except OSError:
         pass
@@ -242,6 +286,11 @@ def main() -> None:
                                 "frac": upd_gbps / HBM_PEAK_GBS}
     if "achieved" not in roofline:
         roofline.update({"kernel": "whole_update", "achieved": upd_gbps, "frac": upd_gbps / HBM_PEAK_GBS})
+    if other:
+        ob = (24.0 if other["schedule"] == "two-pass" else 16.0) * n2w
+        og = ob / (other["ms_per_step"] * 1e-3) / 1e9
+        other["whole_update"] = {"alg_bytes_per_gpu": ob, "GBps_per_gpu": og, "frac": og / HBM_PEAK_GBS}
+        other["per_kernel"] = kernel_table(other.pop("prof"))
 
     out = {
         "metric": "ellipsoid updates/sec at n=%d; achieved HBM GB/s vs peak" % n,
@@ -257,10 +306,13 @@ def main() -> None:
         "dtype": "f64",
         "data": "synthetic",
         "config": {"workload": args.workload, "n": n, "space": variant, "cuts": cutgen,
+                   "schedule": ("pipelined" if fused else "two-pass") if variant == "ell" else "ellstable",
                    "description": desc, "partition": f"row-block x{world}" if world > 1 else "none",
                    "q_bytes_per_gpu": 8.0 * n * n / world},
         "roofline": roofline,
     }
+    if other:
+        out["other_schedule"] = other
     if host_path:
         out["host_call_path"] = host_path
     if world == 1 and not args.no_cpu_baseline:
