@@ -7,8 +7,10 @@
 // CutStatus::Unknown instead.
 #pragma once
 
+#include <optional>
 #include <stdexcept>
 #include <string>
+#include <tuple>
 #include <utility>
 
 #include "../../../include/ellhip.h"
@@ -75,6 +77,22 @@ class SpaceHip {
     template <class Cut>
     CutStatus update_q(const std::pair<Arr, Cut>& cut) { return update(ELLHIP_CUT_Q, cut); }
 
+    // ---- pipelined form (include/ellhip.h "pipelined update"): one pass over Q per update, same bits
+    void prime(const Arr& grad) {
+        if (grad.size() != n_) throw Error(ELLHIP_E_INVALID, "prime: gradient dimension mismatch");
+        check(ellhip_prime(h_, grad.data()), "ellhip_prime");
+    }
+    template <class Cut>
+    CutStatus cut(int kind, const Cut& c) {
+        const CutScalars b = cut_scalars(c);
+        return static_cast<CutStatus>(check(ellhip_cut(h_, kind, b.beta0, b.has_beta1, b.beta1), "ellhip_cut"));
+    }
+    void commit() { check(ellhip_commit(h_, nullptr), "ellhip_commit"); }
+    void commit(const Arr& next_grad) {
+        if (next_grad.size() != n_) throw Error(ELLHIP_E_INVALID, "commit: gradient dimension mismatch");
+        check(ellhip_commit(h_, next_grad.data()), "ellhip_commit");
+    }
+
     // ---- public fields of the reference struct
     double kappa() const { return ellhip_kappa(h_); }
     Arr mq() const {
@@ -104,5 +122,61 @@ class SpaceHip {
 
 using EllHip = SpaceHip<ELLHIP_SPACE_ELL>;
 using EllStableHip = SpaceHip<ELLHIP_SPACE_ELL_STABLE>;
+
+// cutting_plane_optim (src/cutting_plane.rs:286-313) restructured for the pipelined engine: the oracle
+// for iteration k+1 is queried between the scalar stage and the shrink of iteration k (the new centre
+// is already final there), so the shrink and the next GEMV share one pass over Q.  The sequence of
+// oracle calls, cuts, statuses and the returned (x_best, niter) are exactly those of the reference loop.
+template <class Oracle, int VARIANT>
+std::pair<std::optional<Arr>, std::size_t> cutting_plane_optim_pipelined(Oracle& omega, SpaceHip<VARIANT>& space,
+                                                                         double& gamma, const Options& options) {
+    std::optional<Arr> x_best;
+    if (options.max_iters == 0) return {x_best, 0};
+    Arr xc = space.xc();
+    auto [cut, shrunk] = omega.assess_optim(xc, gamma);
+    space.prime(cut.first);
+    for (std::size_t niter = 0; niter < options.max_iters; ++niter) {
+        if (shrunk) x_best = xc;  // better gamma obtained at the centre the oracle was queried at
+        const CutStatus status = space.cut(shrunk ? ELLHIP_CUT_CENTRAL : ELLHIP_CUT_BIAS, cut.second);
+        if (status != CutStatus::Success || space.tsq() < options.tolerance) {
+            space.commit();
+            return {x_best, niter};
+        }
+        if (niter + 1 == options.max_iters) break;
+        xc = space.xc();                                    // x_{k+1}: final before the shrink
+        std::tie(cut, shrunk) = omega.assess_optim(xc, gamma);
+        space.commit(cut.first);                            // shrink for cut k + GEMV for cut k+1
+    }
+    space.commit();
+    return {x_best, options.max_iters};
+}
+
+// cutting_plane_feas (src/cutting_plane.rs:205-227), pipelined the same way.
+template <class Oracle, int VARIANT>
+std::pair<std::optional<Arr>, std::size_t> cutting_plane_feas_pipelined(Oracle& omega, SpaceHip<VARIANT>& space,
+                                                                        const Options& options) {
+    if (options.max_iters == 0) return {std::nullopt, 0};
+    Arr xc = space.xc();
+    auto cut = omega.assess_feas(xc);
+    if (!cut.has_value()) return {xc, 0};
+    space.prime(cut->first);
+    for (std::size_t niter = 0; niter < options.max_iters; ++niter) {
+        const CutStatus status = space.cut(ELLHIP_CUT_BIAS, cut->second);
+        if (status != CutStatus::Success || space.tsq() < options.tolerance) {
+            space.commit();
+            return {std::nullopt, niter};
+        }
+        if (niter + 1 == options.max_iters) break;
+        xc = space.xc();
+        cut = omega.assess_feas(xc);
+        if (!cut.has_value()) {  // feasible solution obtained (found at the top of iteration niter+1)
+            space.commit();
+            return {xc, niter + 1};
+        }
+        space.commit(cut->first);
+    }
+    space.commit();
+    return {std::nullopt, options.max_iters};
+}
 
 }  // namespace ellhip

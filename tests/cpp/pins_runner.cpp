@@ -32,14 +32,35 @@ static void emit(const std::string& name, size_t niter, bool has_x, const Arr* x
     printf("]}\n");
 }
 
+static bool g_pipelined = false;  // --pipelined: drive Ell through prime / cut / commit (HIP backend only)
+
 template <class Space, class Oracle>
 static void run_optim(const std::string& name, Space space, Oracle omega, double gamma, Options opt) {
+#ifdef BACKEND_HIP
+    if (g_pipelined) {
+        auto [x, niter] = cutting_plane_optim_pipelined(omega, space, gamma, opt);
+        emit(name, niter, x.has_value(), x ? &*x : nullptr, gamma);
+        return;
+    }
+#endif
     auto [x, niter] = cutting_plane_optim(omega, space, gamma, opt);
     emit(name, niter, x.has_value(), x ? &*x : nullptr, gamma);
 }
 
+template <class Space, class Oracle>
+static std::pair<std::optional<Arr>, std::size_t> run_feas(Oracle& omega, Space& space, const Options& opt) {
+#ifdef BACKEND_HIP
+    if (g_pipelined) return cutting_plane_feas_pipelined(omega, space, opt);
+#endif
+    return cutting_plane_feas(omega, space, opt);
+}
+
 int main(int argc, char** argv) {
-    const bool with_stable = !(argc > 1 && std::string(argv[1]) == "--no-stable");
+    bool with_stable = true;
+    for (int i = 1; i < argc; ++i) {
+        if (std::string(argv[i]) == "--no-stable") with_stable = false;
+        if (std::string(argv[i]) == "--pipelined") g_pipelined = true;
+    }
     const double NEG_INF = -std::numeric_limits<double>::infinity();
     const double INF = std::numeric_limits<double>::infinity();
     Options tol10;  // Options { tolerance: 1e-10, ..Default::default() }
@@ -92,13 +113,13 @@ int main(int argc, char** argv) {
         {
             EllT s = EllT::new_with_scalar(10.0, {0.0, 0.0});
             FeasXY3 om;
-            auto [x, niter] = cutting_plane_feas(om, s, Options(200, 1e-20));
+            auto [x, niter] = run_feas(om, s, Options(200, 1e-20));
             emit("cp_feas", niter, x.has_value(), x ? &*x : nullptr);
         }
         {
             EllT s = EllT::new_with_scalar(10.0, {0.0, 0.0});
             AlwaysCutFeas om;
-            auto [x, niter] = cutting_plane_feas(om, s, Options(200, 1e-20));
+            auto [x, niter] = run_feas(om, s, Options(200, 1e-20));
             emit("cp_feas_no_soln", niter, x.has_value());
         }
         run_optim("cp_optim", EllT::new_with_scalar(10.0, {0.0, 0.0}), OptimBox{}, 0.0, Options(200, 1e-20));
@@ -107,7 +128,7 @@ int main(int argc, char** argv) {
         {
             EllT s = EllT::new_with_scalar(10.0, {0.0, 0.0});
             AlwaysCutFeas om;
-            auto [x, niter] = cutting_plane_feas(om, s, Options(5, 1e-20));
+            auto [x, niter] = run_feas(om, s, Options(5, 1e-20));
             emit("cp_feas_max_iters", niter, x.has_value());
         }
     }
@@ -140,11 +161,11 @@ int main(int argc, char** argv) {
     {  // tests/example2_tests.rs:49-68
         EllT s1 = EllT::new_with_scalar(10.0, {0.0, 0.0});
         Example2 o1;
-        auto [x1, n1] = cutting_plane_feas(o1, s1, Options{});
+        auto [x1, n1] = run_feas(o1, s1, Options{});
         emit("example2_feasible", n1, x1.has_value(), x1 ? &*x1 : nullptr);
         EllT s2 = EllT::new_with_scalar(10.0, {100.0, 100.0});
         Example2 o2;
-        auto [x2, n2] = cutting_plane_feas(o2, s2, Options{});
+        auto [x2, n2] = run_feas(o2, s2, Options{});
         emit("example2_infeasible", n2, x2.has_value());
     }
     {  // tests/integration_test.rs:85-132 (n = 5) and its n = 16 generalisation (BASELINE config 1)
@@ -161,7 +182,12 @@ int main(int argc, char** argv) {
             EllT s = EllT::new_with_scalar(10.0, zero);
             QuadTarget om{zero};
             double gamma = NEG_INF;
+#ifdef BACKEND_HIP
+            auto [x, niter] = g_pipelined ? cutting_plane_optim_pipelined(om, s, gamma, Options{})
+                                          : cutting_plane_optim(om, s, gamma, Options{});
+#else
             auto [x, niter] = cutting_plane_optim(om, s, gamma, Options{});
+#endif
             Arr k{s.kappa(), s.tsq()};
             emit("bench_degenerate_n" + std::to_string(n), niter, x.has_value(), nullptr, 0.0,
                  std::isnan(s.kappa()) ? 1 : 0);

@@ -29,6 +29,24 @@ def test_pinned_extra_assertions(results):
     pins.check_extra(results)
 
 
+@pytest.fixture(scope="module")
+def results_pipelined(gpu):
+    return run_json_lines(build_runner("pins_runner.cpp", "hip"), "--pipelined")
+
+
+@pytest.mark.parametrize("case", sorted(pins.PINNED))
+def test_pinned_case_hip_pipelined_drivers(results_pipelined, case):
+    """cutting_plane_optim_pipelined / _feas_pipelined (prime / cut / commit) reproduce the same pins."""
+    pins.check_case(case, results_pipelined[case])
+
+
+def test_pipelined_drivers_equal_plain_drivers(results, results_pipelined):
+    for case, want in results.items():
+        got = results_pipelined[case]
+        assert (got["niter"], got["has_x"], got["flag"]) == (want["niter"], want["has_x"], want["flag"]), case
+        assert got["x"] == want["x"] and got["gamma"] == want["gamma"], case   # bit-identical engine paths
+
+
 def test_solutions_match_oracle_backend(results, results_oracle):
     for case, want in results_oracle.items():
         got = results[case]
