@@ -54,7 +54,8 @@ struct DevState {
     int status;             // CutStatus of the last cut
     int apply;              // 1 -> the second pass over Q runs
     int halted;             // queue mode: set at the first non-Success cut
-    int pad_;
+    int halted_in;          // snapshot of `halted` for kernels whose lead workgroup rewrites it
+    double kappa_in;        // snapshot of kappa taken by k_scalar_dot for k_scalar_apply
 };
 
 typedef double double2_t __attribute__((ext_vector_type(2)));
@@ -240,8 +241,120 @@ __global__ __launch_bounds__(256) void k_sweep(const double* Q, double* Qout, lo
 }
 
 // ---------------------------------------------------------------------------------- k_scalar ---
-// One workgroup of 1024 threads.  omega = sum_i g[i]*gt[i] (src/arr.rs:443-451) with a fixed
-// reduction shape, then the coefficient stage and the O(n) vector updates.
+// The scalar stage between the two passes, spread over G workgroups (one CU moves only ~70 GB/s, and
+// the stage touches ~56 n bytes) in two launches:
+//   k_scalar_dot    partial[b] = sum over slice b of g[i]*gt[i]          (src/arr.rs:443-451)
+//   k_scalar_apply  every workgroup: omega = sum_b partial[b]; tsq = kappa*omega; EllCalc; then its slice
+//                   of xc -= (rho/omega) gt; workgroup 0 publishes kappa / status / ratio (src/ell.rs:105-135)
+// The reduction shape is fixed by n alone (slice length, 256 sequential-per-thread lanes, xor
+// butterfly, ((w0+w1)+w2)+w3, then the partials in index order), so omega has the same bits on every
+// rank of a row-partitioned run and in every schedule.
+__host__ __device__ inline int scalar_groups(long long n) {
+    long long g = n / 1024;  // >= 1024 elements per workgroup
+    if (g < 1) g = 1;
+    if (g > 64) g = 64;
+    return (int)g;
+}
+__host__ __device__ inline long long scalar_slice(long long n) {
+    const long long g = scalar_groups(n);
+    long long m = (n + g - 1) / g;
+    return (m + 1) & ~1LL;  // even, so a slice never splits a 16-byte pair
+}
+
+__global__ __launch_bounds__(256) void k_scalar_dot(long long n, const double* __restrict__ g,
+                                                    const double* __restrict__ gt,
+                                                    double* __restrict__ partial, DevState* __restrict__ st) {
+    __shared__ double red[4];
+    const int tid = threadIdx.x;
+    const int halted = st->halted;
+    if (blockIdx.x == 0 && tid == 0) {
+        // snapshots for k_scalar_apply, whose lead workgroup rewrites kappa / halted while the others read
+        st->halted_in = halted;
+        st->kappa_in = st->kappa;
+    }
+    if (halted) return;
+    const long long m = scalar_slice(n);
+    const long long lo = (long long)blockIdx.x * m;
+    const long long hi = (lo + m < n) ? lo + m : n;
+    double s = 0.0;
+    for (long long i = lo + tid; i < hi; i += 256) s += g[i] * gt[i];
+    s = wave_allreduce_sum(s);
+    if ((tid & 63) == 0) red[tid >> 6] = s;
+    __syncthreads();
+    if (tid == 0) partial[blockIdx.x] = ((red[0] + red[1]) + red[2]) + red[3];
+}
+
+__global__ __launch_bounds__(256) void k_scalar_apply(long long n, const double* __restrict__ gt,
+                                                      double* __restrict__ xc,
+                                                      const double* __restrict__ partial,
+                                                      DevState* __restrict__ st, EllCalcDev calc,
+                                                      const CutParams* __restrict__ cp_dev, CutParams cp_val,
+                                                      int no_defer_trick, int queue_mode,
+                                                      int* __restrict__ q_status, double* __restrict__ q_tsq) {
+    __shared__ double bc_roo;
+    __shared__ int bc_status;
+    const int tid = threadIdx.x;
+    const bool lead = blockIdx.x == 0;
+    if (st->halted_in) {  // snapshot taken before this launch (see below): uniform across workgroups
+        if (lead && tid == 0 && q_status) {
+            *q_status = ST_UNKNOWN;
+            *q_tsq = st->tsq;
+        }
+        return;
+    }
+    if (tid == 0) {
+        const int G = scalar_groups(n);
+        double omega = 0.0;
+        for (int b = 0; b < G; ++b) omega += partial[b];
+        const double kappa = st->kappa_in;
+        const double tsq = kappa * omega;  // src/ell.rs:105
+        Coef cf;
+        const CutParams cp = cp_dev ? *cp_dev : cp_val;  // queued cuts live in HBM, direct ones arrive by value
+        const int status = calc.dispatch(cp.kind, cp.b0, cp.has_b1, cp.b1, tsq, cf);  // :106
+        double roo = 0.0;
+        if (status == ST_SUCCESS) roo = cf.rho / omega;  // :112
+        if (lead) {
+            st->tsq = tsq;
+            st->omega = omega;
+            st->status = status;
+            if (status == ST_SUCCESS) {
+                st->rho_over_omega = roo;
+                st->ratio = cf.sigma / omega;          // :117
+                const double knew = kappa * cf.delta;  // :130
+                if (no_defer_trick) {                  // :132-135
+                    st->scale = knew;
+                    st->kappa = 1.0;
+                } else {
+                    st->scale = 1.0;
+                    st->kappa = knew;
+                }
+                st->apply = 1;
+            } else {
+                st->apply = 0;  // :107-109  Q, xc, kappa untouched
+                if (queue_mode) st->halted = 1;
+            }
+            if (q_status) {
+                *q_status = status;
+                *q_tsq = tsq;
+            }
+        }
+        bc_roo = roo;
+        bc_status = status;
+    }
+    __syncthreads();
+    if (bc_status != ST_SUCCESS) return;
+    const double roo = bc_roo;
+    const long long m = scalar_slice(n);
+    const long long lo = (long long)blockIdx.x * m;
+    const long long hi = (lo + m < n) ? lo + m : n;
+    for (long long i = lo + tid; i < hi; i += 256) xc[i] = xc[i] - roo * gt[i];  // :113-115
+}
+
+constexpr long long SCALAR_SPLIT_N = 8192;
+
+// Small n (< SCALAR_SPLIT_N): the whole scalar stage in ONE workgroup of 1024 threads -- a second
+// launch would cost more (~5 us) than one CU's bandwidth limit does.  Same arithmetic, its own fixed
+// reduction shape (which form runs depends on n only, so results stay reproducible).
 __global__ __launch_bounds__(1024) void k_scalar(long long n, const double* __restrict__ g,
                                                  const double* __restrict__ gt, double* __restrict__ xc,
                                                  DevState* __restrict__ st, EllCalcDev calc,

@@ -76,6 +76,7 @@ struct ellhip_space {
     double* d_gt_own[2] = {nullptr, nullptr};  // Q*g of slot 0 / 1 (n doubles)
     double* d_gt[2] = {nullptr, nullptr};      // buffers in use (own or caller's)
     double* d_work = nullptr;        // EllStable vectors: w, z, gg, q, beta2
+    double* d_partial = nullptr;     // per-workgroup partial sums of omega (64)
     DevState* d_st = nullptr;
 
     double* h_stage[2] = {nullptr, nullptr};  // pinned, n doubles each
@@ -259,11 +260,12 @@ int ellstable_issue(ellhip_space* s, const double* g_dev, const CutParams* cp_de
     double* gg = z + n;
     double* q = gg + n;
     double* beta2 = q + n;
+    double* dscale = beta2 + n;
     hipStream_t st = s->stream;
     {
         ProfScope ps(s, CLS_ST_FWD);
         HIPCHK(hipMemcpyAsync(w, g_dev, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, st));
-        hipLaunchKernelGGL(k_st_fwd_first, dim3(1), dim3(64), 0, st, s->d_Q, ld, n, g_dev, w, z, gg, s->d_st);
+        hipLaunchKernelGGL(k_st_fwd_first, dim3(1), dim3(256), 0, st, s->d_Q, ld, n, g_dev, w, z, gg, s->d_st);
         for (long long kb = 0; kb + 1 < nb; ++kb) {
             const long long rest = n - (kb + 1) * SB;
             const unsigned grid = (unsigned)((rest + SPANEL - 1) / SPANEL);
@@ -274,13 +276,15 @@ int ellstable_issue(ellhip_space* s, const double* g_dev, const CutParams* cp_de
     {
         ProfScope ps(s, CLS_SCALAR);
         EllCalcDev calc = EllCalcDev::make(n, s->use_parallel_cut);
-        hipLaunchKernelGGL(k_st_mid, dim3(1), dim3(1024), 0, st, s->d_Q, ld, n, z, gg, q, beta2, s->d_st, calc,
-                           cp_dev, cp_val, queue_mode, qst, qtsq);
+        hipLaunchKernelGGL(k_st_mid, dim3(1), dim3(1024), 0, st, s->d_Q, ld, n, z, gg, q, beta2, dscale, s->d_st,
+                           calc, cp_dev, cp_val, queue_mode, qst, qtsq);
+        hipLaunchKernelGGL(k_st_diag, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, s->d_Q, ld, n,
+                           (const double*)dscale, s->d_st);
         HIPCHK(hipGetLastError());
     }
     {
         ProfScope ps(s, CLS_ST_BWD);
-        hipLaunchKernelGGL(k_st_bwd_last, dim3(1), dim3(64), 0, st, s->d_Q, ld, n, nb - 1, q, s->d_st);
+        hipLaunchKernelGGL(k_st_bwd_last, dim3(1), dim3(256), 0, st, s->d_Q, ld, n, nb - 1, q, s->d_st);
         for (long long kb = nb - 1; kb >= 1; --kb) {
             const unsigned grid = (unsigned)((kb * SB + SPANEL - 1) / SPANEL);
             hipLaunchKernelGGL(k_st_bwd_step, dim3(grid), dim3(256), 0, st, s->d_Q, ld, n, kb, q, s->d_st);
@@ -291,8 +295,8 @@ int ellstable_issue(ellhip_space* s, const double* g_dev, const CutParams* cp_de
     }
     {
         ProfScope ps(s, CLS_ST_FACTOR);
-        hipLaunchKernelGGL(k_st_factor, dim3((unsigned)nb, (unsigned)nb), dim3(256), 0, st, s->d_Q, ld, n, beta2,
-                           s->d_st);
+        const unsigned nt64 = (unsigned)((n + 63) / 64);  // the factor update works on 64x64 tiles
+        hipLaunchKernelGGL(k_st_factor, dim3(nt64, nt64), dim3(256), 0, st, s->d_Q, ld, n, beta2, s->d_st);
         HIPCHK(hipGetLastError());
     }
     return 0;
@@ -313,8 +317,18 @@ int do_cut(ellhip_space* s, const double* g_dev, const CutParams* cp_dev, CutPar
     if (s->variant != ELLHIP_SPACE_ELL) return ellstable_issue(s, g_dev, cp_dev, cp_val, queue_mode, qst, qtsq);
     ProfScope ps(s, CLS_SCALAR);
     EllCalcDev calc = EllCalcDev::make(s->n, s->use_parallel_cut);
-    hipLaunchKernelGGL(k_scalar, dim3(1), dim3(1024), 0, s->stream, s->n, g_dev, (const double*)s->d_gt[s->cur],
-                       s->d_xc, s->d_st, calc, cp_dev, cp_val, s->no_defer_trick, queue_mode, qst, qtsq);
+    const unsigned G = (unsigned)scalar_groups(s->n);
+    const double* gt = s->d_gt[s->cur];
+    if (s->n < SCALAR_SPLIT_N) {
+        hipLaunchKernelGGL(k_scalar, dim3(1), dim3(1024), 0, s->stream, s->n, g_dev, gt, s->d_xc, s->d_st, calc,
+                           cp_dev, cp_val, s->no_defer_trick, queue_mode, qst, qtsq);
+        HIPCHK(hipGetLastError());
+        return 0;
+    }
+    hipLaunchKernelGGL(k_scalar_dot, dim3(G), dim3(256), 0, s->stream, s->n, g_dev, gt, s->d_partial, s->d_st);
+    hipLaunchKernelGGL(k_scalar_apply, dim3(G), dim3(256), 0, s->stream, s->n, gt, s->d_xc,
+                       (const double*)s->d_partial, s->d_st, calc, cp_dev, cp_val, s->no_defer_trick, queue_mode,
+                       qst, qtsq);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -398,7 +412,8 @@ int alloc_common(ellhip_space* s) {
         HIPCHK(hipMemsetAsync(s->d_gt_own[k], 0, vbytes, s->stream));
     }
     HIPCHK(hipMalloc(&s->d_st, sizeof(DevState)));
-    if (s->variant == ELLHIP_SPACE_ELL_STABLE) HIPCHK(hipMalloc(&s->d_work, vbytes * 6));
+    HIPCHK(hipMalloc(&s->d_partial, 64 * sizeof(double)));
+    if (s->variant == ELLHIP_SPACE_ELL_STABLE) HIPCHK(hipMalloc(&s->d_work, vbytes * 7));
     HIPCHK(hipHostMalloc(&s->h_result, sizeof(DevState), hipHostMallocDefault));
     return 0;
 }
@@ -615,6 +630,7 @@ void ellhip_destroy(ellhip_space* s) {
         if (s->h_stage[k]) (void)hipHostFree(s->h_stage[k]);
     }
     if (s->d_work) (void)hipFree(s->d_work);
+    if (s->d_partial) (void)hipFree(s->d_partial);
     if (s->d_st) (void)hipFree(s->d_st);
     if (s->h_result) (void)hipHostFree(s->h_result);
     if (s->own_stream) (void)hipStreamDestroy(s->own_stream);

@@ -7,12 +7,13 @@
 // The reference is BUG-COMPATIBLY reproduced: the back substitution reads the scratch
 // triangle (:96) and the factor update adds beta2 * S[l][j] (:116).
 //
-// One update, blocked by B = 64 rows/columns (block kb = indices [64 kb, 64 kb + 64)):
+// One update, blocked by B = 128 rows/columns (block kb = indices [128 kb, 128 kb + 128)):
 //
 //   forward   w = L^-1 g            right-looking: for each block, a one-wave register solve of the
-//             S <- U .* w            64x64 diagonal block, then a grid-wide panel update of every
-//                                    column to its right (reads 64 rows of U coalesced, writes the
-//                                    products transposed through LDS as full 128-byte lines of S).
+//             S <- U .* w            128x128 diagonal block (two 64-wide halves + a 64x64 mini panel),
+//                                    then a grid-wide panel update of every column to its right
+//                                    (reads 128 rows of U coalesced, writes the products transposed
+//                                    through LDS as full 128-byte lines of S).
 //                                    The workgroup that owns the next block's columns runs that
 //                                    block's diagonal solve in the same launch.     reads 4n^2, writes 4n^2
 //   mid       z = d.*w, gg = z.*w (in the diagonal solves), omega = sum gg, tsq, EllCalc, kappa,
@@ -24,7 +25,7 @@
 // 24 n^2 algorithmic bytes per successful update, like Ell; but the two triangular solves are
 // length-n dependency chains (n sequential multiply-subtract steps), which bounds this variant well
 // below the HBM roofline.  Summation order inside a column differs from the reference's
-// strict left-to-right order only by the grouping into 16-row partial sums (deterministic).
+// strict left-to-right order only by the grouping into 32-row partial sums (deterministic).
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -33,115 +34,247 @@
 
 namespace ellhip {
 
-constexpr int SB = 64;        // block size of the triangular solves
+constexpr int SB = 128;       // block size of the triangular solves (two 64-wide halves per diagonal block)
+constexpr int SH = 64;        // half block = one wave's register solve
 constexpr int SPANEL = 128;   // columns per panel workgroup (2 per lane)
 constexpr int SLDS_PAD = 18;  // doubles per LDS tile row (16 + 2: keeps 16-byte alignment)
 
 // ------------------------------------------------------------------------------ forward ------
-// One wave: finish w for block J0..J0+63 given its partial values, park the products in S, emit z, gg.
-// Lane l owns column J0 + l.  src/ell_stable.rs:61-83 restricted to the diagonal block.
-__device__ __forceinline__ void st_fwd_diag_wave(double* __restrict__ M, long long ld, long long n,
-                                                 long long J0, double wi, double* __restrict__ w,
-                                                 double* __restrict__ z, double* __restrict__ gg) {
-    const int lane = threadIdx.x & 63;
-    const long long c = J0 + lane;
-    const bool live = c < n;
-    const long long cc = live ? c : n - 1;
-    double u[SB];
+// The diagonal-block solve is a length-128 dependency chain, so it is kept free of memory latency:
+// all 4 waves of the owning workgroup prefetch the three 64x64 pieces of the block (AA, AB, BB) and
+// the 128 diagonal entries into registers before the panel work, park them in LDS, ONE wave runs the
+// chain out of LDS/registers and leaves the products in LDS, and all 4 waves write them back to the
+// scratch triangle as coalesced rows.
+constexpr int BLK_PITCH = 65;  // doubles per LDS row of a 64x64 piece: odd, so the column reads AND the
+                               // transposed product writes of the chain wave are both bank-conflict-free
+
+struct Blk3 {  // one thread's share (8 x 16 B per piece) of the three 64x64 pieces of a diagonal block
+    double2_t aa[8], ab[8], bb[8];
+};
+
+// Broadcast lane j's value to the whole wave through the scalar unit (v_readlane_b32 x2, a few
+// cycles) -- __shfl would go through the LDS crossbar (ds_bpermute, ~100 cycles) on every chain step.
+__device__ __forceinline__ double lane_bcast(double v, int j) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), j);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), j);
+    return __hiloint2double(hi, lo);
+}
+
+// piece rows r = (tid >> 5) + 8k, column pair cp = tid & 31
+__device__ __forceinline__ void st_load_piece(const double* __restrict__ M, long long ld, long long n,
+                                              long long r0, long long c0, double2_t (&v)[8]) {
+    const int tr = threadIdx.x >> 5, cp = threadIdx.x & 31;
 #pragma unroll
-    for (int j = 0; j < SB; ++j) {
-        long long r = J0 + j;
+    for (int k = 0; k < 8; ++k) {
+        long long r = r0 + tr + 8 * k, c = c0 + 2 * cp;
         if (r > n - 1) r = n - 1;
-        u[j] = M[r * ld + cc];  // U[J0+j][c]; only j < lane is used
+        if (c > n - 1) c = 0;  // outside the matrix: any valid address, the value is never used
+        v[k] = *reinterpret_cast<const double2_t*>(M + r * ld + c);
+    }
+}
+__device__ __forceinline__ void st_park_piece(double* __restrict__ lds, const double2_t (&v)[8]) {
+    const int tr = threadIdx.x >> 5, cp = threadIdx.x & 31;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {  // two 8-byte writes: rows are not 16-byte aligned with the odd pitch
+        lds[(tr + 8 * k) * BLK_PITCH + 2 * cp] = v[k].x;
+        lds[(tr + 8 * k) * BLK_PITCH + 2 * cp + 1] = v[k].y;
+    }
+}
+
+// Chain for 64 columns H0..: u[j] = piece[j][lane]; products are left in piece[lane][j] (transposed in
+// place: every lane has read its whole column before any lane writes).  src/ell_stable.rs:61-69
+__device__ __forceinline__ double st_fwd_half_chain(double* __restrict__ piece, double wi) {
+    const int lane = threadIdx.x & 63;
+    double u[SH];
+#pragma unroll
+    for (int j = 0; j < SH; ++j) u[j] = piece[j * BLK_PITCH + lane];
+#pragma unroll
+    for (int j = 0; j < SH; ++j) {
+        const double wj = lane_bcast(wi, j);
+        const double v = u[j] * wj;      // :65
+        u[j] = v;                        // parked product, :66 (meaningful for j < lane only)
+        wi = (lane > j) ? wi - v : wi;   // :67
     }
 #pragma unroll
-    for (int j = 0; j < SB; ++j) {
-        const double wj = __shfl(wi, j, 64);
-        if (lane > j) {
-            const double v = u[j] * wj;  // :65
-            u[j] = v;                    // parked product, :66
-            wi = wi - v;                 // :67
+    for (int j = 0; j < SH; ++j) piece[lane * BLK_PITCH + j] = u[j];
+    return wi;
+}
+// Rows A (final, lane j holds w[A0+j]) applied to the 64 columns of B: products left in piece[lane][j].
+__device__ __forceinline__ double st_fwd_mini_chain(double* __restrict__ piece, double wa, double wb) {
+    const int lane = threadIdx.x & 63;
+    double u[SH];
+#pragma unroll
+    for (int j = 0; j < SH; ++j) u[j] = piece[j * BLK_PITCH + lane];
+#pragma unroll
+    for (int j = 0; j < SH; ++j) {
+        const double wj = lane_bcast(wa, j);
+        const double v = u[j] * wj;
+        u[j] = v;
+        wb = wb - v;
+    }
+#pragma unroll
+    for (int j = 0; j < SH; ++j) piece[lane * BLK_PITCH + j] = u[j];
+    return wb;
+}
+
+// All threads: write the parked products of a piece to S rows R0.., columns C0..; `lower_only`: only
+// the strict lower triangle of the piece belongs to S (the rest is factor / diagonal, never touched).
+__device__ __forceinline__ void st_store_piece(double* __restrict__ M, long long ld, long long n,
+                                               long long R0, long long C0, const double* __restrict__ piece,
+                                               bool lower_only) {
+    const int tr = threadIdx.x >> 5, cp = threadIdx.x & 31;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int r = tr + 8 * k;
+        const long long row = R0 + r;
+        if (row >= n) continue;
+        const double2_t v = {piece[r * BLK_PITCH + 2 * cp], piece[r * BLK_PITCH + 2 * cp + 1]};
+        double* dst = M + row * ld + C0 + 2 * cp;
+        if (!lower_only) {
+            *reinterpret_cast<double2_t*>(dst) = v;  // C0 + 63 < R0 <= row: always inside the matrix
+        } else {
+            if (2 * cp < r) dst[0] = v.x;
+            if (2 * cp + 1 < r) dst[1] = v.y;
         }
     }
-    if (live) {
-        // S[c][J0 + j] for j < lane: this lane's own row, contiguous
-        double* srow = M + c * ld + J0;
-#pragma unroll
-        for (int j = 0; j < SB; ++j)
-            if (j < lane) srow[j] = u[j];
-        const double d = M[c * ld + c];
-        const double zi = wi * d;  // :74
-        w[c] = wi;
-        z[c] = zi;
-        gg[c] = zi * wi;  // :81
+}
+
+// Whole 128-wide diagonal block at J0, called by all 256 threads of one workgroup.
+//   blk: prefetched pieces; dreg: this thread's diagonal entry M[J0+t][J0+t] (t < 128);
+//   lds: 3 * 64 * BLK_PITCH doubles; wpart[128]: partial w of the block's columns (LDS).
+__device__ __forceinline__ void st_fwd_diag_block(double* __restrict__ M, long long ld, long long n, long long J0,
+                                                  const Blk3& blk, double dreg, double* __restrict__ lds,
+                                                  double* __restrict__ dlds, const double* __restrict__ wpart,
+                                                  double* __restrict__ w, double* __restrict__ z,
+                                                  double* __restrict__ gg) {
+    double* pAA = lds;
+    double* pAB = lds + SH * BLK_PITCH;
+    double* pBB = lds + 2 * SH * BLK_PITCH;
+    st_park_piece(pAA, blk.aa);
+    st_park_piece(pAB, blk.ab);
+    st_park_piece(pBB, blk.bb);
+    if (threadIdx.x < SB) dlds[threadIdx.x] = dreg;
+    __syncthreads();
+    const bool has_b = J0 + SH < n;
+    if ((threadIdx.x >> 6) == 0) {
+        const int lane = threadIdx.x;
+        double wA = st_fwd_half_chain(pAA, wpart[lane]);
+        {
+            const long long c = J0 + lane;
+            if (c < n) {
+                const double zi = wA * dlds[lane];  // :74
+                w[c] = wA;
+                z[c] = zi;
+                gg[c] = zi * wA;  // :81
+            }
+        }
+        if (has_b) {
+            double wB = st_fwd_mini_chain(pAB, wA, wpart[lane + SH]);
+            wB = st_fwd_half_chain(pBB, wB);
+            const long long c = J0 + SH + lane;
+            if (c < n) {
+                const double zi = wB * dlds[lane + SH];
+                w[c] = wB;
+                z[c] = zi;
+                gg[c] = zi * wB;
+            }
+        }
+    }
+    __syncthreads();
+    st_store_piece(M, ld, n, J0, J0, pAA, true);                       // S[A][A], strict lower
+    if (has_b) {
+        st_store_piece(M, ld, n, J0 + SH, J0, pAB, false);             // S[B][A], full
+        st_store_piece(M, ld, n, J0 + SH, J0 + SH, pBB, true);         // S[B][B], strict lower
     }
 }
 
-__global__ __launch_bounds__(64) void k_st_fwd_first(double* __restrict__ M, long long ld, long long n,
-                                                     const double* __restrict__ g, double* __restrict__ w,
-                                                     double* __restrict__ z, double* __restrict__ gg,
-                                                     const DevState* __restrict__ st) {
-    if (st->halted) return;
-    const int lane = threadIdx.x;
-    const double wi = (lane < n) ? g[lane] : 0.0;
-    st_fwd_diag_wave(M, ld, n, 0, wi, w, z, gg);
+__device__ __forceinline__ void st_prefetch_block(const double* __restrict__ M, long long ld, long long n,
+                                                  long long J0, Blk3& blk, double& dreg) {
+    st_load_piece(M, ld, n, J0, J0, blk.aa);
+    st_load_piece(M, ld, n, J0, J0 + SH, blk.ab);
+    st_load_piece(M, ld, n, J0 + SH, J0 + SH, blk.bb);
+    long long dj = J0 + (threadIdx.x & (SB - 1));
+    if (dj > n - 1) dj = n - 1;
+    dreg = M[dj * ld + dj];
 }
 
-// Panel update for block kb (rows J0..J0+63, already final in w) over columns >= J0 + 64, 128 columns
-// per workgroup; 4 waves take 16 rows each.  Workgroup 0 then solves the next diagonal block.
-// `wsrc` is g for columns that have not been touched yet (first panel) -- handled by k_st_copy.
+constexpr int ST_LDS_DOUBLES = 3 * SH * BLK_PITCH;  // 96 KiB: the three parked pieces (the panel tile aliases it)
+
+__global__ __launch_bounds__(256) void k_st_fwd_first(double* __restrict__ M, long long ld, long long n,
+                                                      const double* __restrict__ g, double* __restrict__ w,
+                                                      double* __restrict__ z, double* __restrict__ gg,
+                                                      const DevState* __restrict__ st) {
+    if (st->halted) return;
+    __shared__ __attribute__((aligned(16))) double lds[ST_LDS_DOUBLES];
+    __shared__ double dlds[SB];
+    __shared__ double wpart[SB];
+    Blk3 blk;
+    double dreg;
+    st_prefetch_block(M, ld, n, 0, blk, dreg);
+    if (threadIdx.x < SB) wpart[threadIdx.x] = (threadIdx.x < n) ? g[threadIdx.x] : 0.0;
+    st_fwd_diag_block(M, ld, n, 0, blk, dreg, lds, dlds, wpart, w, z, gg);
+}
+
+// Panel update for block kb (rows J0..J0+127, already final in w) over columns >= J0 + 128, 128 columns
+// per workgroup; each of the 4 waves takes 32 rows in two 16-row passes.  Workgroup 0 then solves the
+// next diagonal block (its 128 columns are exactly that block).
 __global__ __launch_bounds__(256) void k_st_fwd_step(double* __restrict__ M, long long ld, long long n,
                                                      long long kb, double* __restrict__ w,
                                                      double* __restrict__ z, double* __restrict__ gg,
                                                      const DevState* __restrict__ st) {
     if (st->halted) return;
-    __shared__ __attribute__((aligned(16))) double tile[4][SPANEL * SLDS_PAD];
+    __shared__ __attribute__((aligned(16))) double lds[ST_LDS_DOUBLES];  // panel tiles, then the parked pieces
     __shared__ double part[4][SPANEL];
     __shared__ double wnext[SPANEL];
+    __shared__ double dlds[SB];
     const int lane = threadIdx.x & 63;
     const int wv = threadIdx.x >> 6;
     const long long J0 = kb * SB;
-    const long long Jend = J0 + SB;
+    const long long Jend = J0 + SB;  // < n: there are columns to the right, so all 128 rows exist
     const long long c0 = Jend + (long long)blockIdx.x * SPANEL;
     const long long c = c0 + 2 * lane;  // this lane's two columns c, c+1 (ld is even: 16-byte aligned)
-    const bool live0 = c < n, live1 = c + 1 < n;
+    const long long cl = (c < n) ? c : 0;
+    const int piece = lane & 7;  // which 16-byte piece of a 128-byte line this lane stores
+    const bool owner = blockIdx.x == 0;
 
-    // rows of this wave: J0 + 16 wv + r
+    Blk3 blk;
+    double dreg = 0.0;
+    if (owner) st_prefetch_block(M, ld, n, Jend, blk, dreg);  // independent of w: overlaps the panel work
+
     double p0 = 0.0, p1 = 0.0;
-    double2_t u[16];
-    const long long cl = live0 ? c : 0;
+    double* t = lds + wv * (SPANEL * SLDS_PAD);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const long long row = J0 + 16 * wv + r;  // < Jend <= n here because c0 >= Jend exists only if Jend < n
-        u[r] = *reinterpret_cast<const double2_t*>(M + row * ld + cl);
-    }
-    double* t = tile[wv];
+    for (int h = 0; h < 2; ++h) {
+        const long long r0 = J0 + 32 * wv + 16 * h;  // 16 rows of this pass
+        double2_t u[16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const double wj = w[J0 + 16 * wv + r];  // wave-uniform
-        const double v0 = u[r].x * wj;
-        const double v1 = u[r].y * wj;
-        p0 += v0;
-        p1 += v1;
-        t[(2 * lane) * SLDS_PAD + r] = v0;
-        t[(2 * lane + 1) * SLDS_PAD + r] = v1;
-    }
-    part[wv][2 * lane] = p0;
-    part[wv][2 * lane + 1] = p1;
-    __syncthreads();
-    // S[col][J0 + 16 wv .. +16) for the 128 columns of this workgroup: 8 lanes x 16 B = one 128-byte line
-    {
-        const int piece = lane & 7;  // which 16-byte piece of the 128-byte line
+        for (int r = 0; r < 16; ++r) u[r] = *reinterpret_cast<const double2_t*>(M + (r0 + r) * ld + cl);
+        if (h) __syncthreads();  // the tile of the previous pass has been drained
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const double wj = w[r0 + r];  // wave-uniform
+            const double v0 = u[r].x * wj;
+            const double v1 = u[r].y * wj;
+            p0 += v0;
+            p1 += v1;
+            t[(2 * lane) * SLDS_PAD + r] = v0;
+            t[(2 * lane + 1) * SLDS_PAD + r] = v1;
+        }
+        __syncthreads();
+        // S[col][r0 .. r0+16) for the 128 columns: 8 lanes x 16 B = one full 128-byte line per column
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
             const int col_local = 8 * k + (lane >> 3);
             const long long col = c0 + col_local;
             if (col < n) {
                 const double2_t v = *reinterpret_cast<const double2_t*>(&t[col_local * SLDS_PAD + 2 * piece]);
-                *reinterpret_cast<double2_t*>(M + col * ld + J0 + 16 * wv + 2 * piece) = v;
+                *reinterpret_cast<double2_t*>(M + col * ld + r0 + 2 * piece) = v;
             }
         }
     }
+    part[wv][2 * lane] = p0;
+    part[wv][2 * lane + 1] = p1;
+    __syncthreads();
     // w[col] -= (((p_0 + p_1) + p_2) + p_3): threads 0..127
     if (threadIdx.x < SPANEL) {
         const long long col = c0 + threadIdx.x;
@@ -154,10 +287,9 @@ __global__ __launch_bounds__(256) void k_st_fwd_step(double* __restrict__ M, lon
         }
         wnext[threadIdx.x] = wn;
     }
-    (void)live1;
-    if (blockIdx.x != 0 || Jend >= n) return;
-    __syncthreads();
-    if (wv == 0) st_fwd_diag_wave(M, ld, n, Jend, wnext[lane], w, z, gg);
+    if (!owner) return;
+    __syncthreads();  // panel tiles are dead from here on: `lds` is reused for the parked pieces
+    st_fwd_diag_block(M, ld, n, Jend, blk, dreg, lds, dlds, wnext, w, z, gg);
 }
 
 // ---------------------------------------------------------------------------------- mid -------
@@ -166,6 +298,7 @@ __global__ __launch_bounds__(256) void k_st_fwd_step(double* __restrict__ M, lon
 __global__ __launch_bounds__(1024) void k_st_mid(double* __restrict__ M, long long ld, long long n,
                                                  const double* __restrict__ z, const double* __restrict__ gg,
                                                  double* __restrict__ q, double* __restrict__ beta2,
+                                                 double* __restrict__ dscale,
                                                  DevState* __restrict__ st, EllCalcDev calc,
                                                  const CutParams* __restrict__ cp_dev, CutParams cp_val,
                                                  int queue_mode, int* __restrict__ q_status,
@@ -237,74 +370,140 @@ __global__ __launch_bounds__(1024) void k_st_mid(double* __restrict__ M, long lo
     for (long long j = lo; j < hi; ++j) {
         const double tnew = told + gg[j];      // :111
         beta2[j] = z[j] / tnew;                // :112
-        M[j * ld + j] = M[j * ld + j] * (told / tnew);  // :113 / :121
+        dscale[j] = told / tnew;               // :113 / :121, applied by k_st_diag
         q[j] = z[j];                           // :93
         told = tnew;
     }
 }
 
-// ------------------------------------------------------------------------------ backward ------
-// One wave: finish q for block J0..J0+63 (its partial values already hold the contributions of all
-// later blocks): for j descending, q[t] -= S[J0+j][J0+t] * q[J0+j], t < j.   src/ell_stable.rs:93-98
-__device__ __forceinline__ void st_bwd_diag_wave(const double* __restrict__ M, long long ld, long long n,
-                                                 long long J0, double qi, double* __restrict__ q) {
-    const int lane = threadIdx.x & 63;
-    const long long c = J0 + lane;
-    const bool live = c < n;
-    const long long cc = live ? c : n - 1;
-    double s[SB];
-#pragma unroll
-    for (int j = 0; j < SB; ++j) {
-        long long r = J0 + j;
-        if (r > n - 1) r = n - 1;
-        s[j] = M[r * ld + cc];  // S[J0+j][c]; only j > lane is used
-    }
-#pragma unroll
-    for (int j = SB - 1; j >= 1; --j) {
-        const double qj = __shfl(qi, j, 64);
-        if (lane < j && J0 + j < n) qi = qi - s[j] * qj;
-    }
-    if (live) q[c] = qi;
-}
-
-__global__ __launch_bounds__(64) void k_st_bwd_last(const double* __restrict__ M, long long ld, long long n,
-                                                    long long kb_last, double* __restrict__ q,
-                                                    const DevState* __restrict__ st) {
+// d[j] *= t_{j-1}/t_j  (src/ell_stable.rs:113,121): one strided element per thread, spread over the chip.
+__global__ __launch_bounds__(256) void k_st_diag(double* __restrict__ M, long long ld, long long n,
+                                                 const double* __restrict__ dscale,
+                                                 const DevState* __restrict__ st) {
     if (!st->apply) return;
-    const long long c = kb_last * SB + threadIdx.x;
-    const double qi = (c < n) ? q[c] : 0.0;
-    st_bwd_diag_wave(M, ld, n, kb_last * SB, qi, q);
+    const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < n) M[j * ld + j] = M[j * ld + j] * dscale[j];
 }
 
-// Panel for block kb (rows J0..J0+63 of S, q final there) over columns t < J0, 128 per workgroup, then
-// the workgroup that owns block kb-1 solves it.
+// ------------------------------------------------------------------------------ backward ------
+// q = z; for j descending: q[t] -= S[j][t] * q[j], t < j   (src/ell_stable.rs:93-98; rows of the scratch
+// triangle, bug-compatible).  Same structure as the forward solve, without stores: the three pieces of
+// the diagonal block (BB, BA, AA) are prefetched by all 4 waves, one wave runs the chain out of LDS.
+__device__ __forceinline__ double st_bwd_half_chain(const double* __restrict__ piece, long long H0, long long n,
+                                                    double qi) {
+    const int lane = threadIdx.x & 63;
+    double sv[SH];
+#pragma unroll
+    for (int j = 0; j < SH; ++j) sv[j] = piece[j * BLK_PITCH + lane];  // S[H0+j][H0+lane]; used for j > lane
+    const int nvalid = (n - H0 < SH) ? (int)(n - H0) : SH;  // rows of this half that exist
+#pragma unroll
+    for (int j = SH - 1; j >= 1; --j) {
+        const double qj = lane_bcast(qi, j);
+        const double v = sv[j] * qj;
+        qi = (lane < j && j < nvalid) ? qi - v : qi;
+    }
+    return qi;
+}
+__device__ __forceinline__ double st_bwd_mini_chain(const double* __restrict__ piece, long long B0, long long n,
+                                                    double qb, double qa) {
+    const int lane = threadIdx.x & 63;
+    double sv[SH];
+#pragma unroll
+    for (int j = 0; j < SH; ++j) sv[j] = piece[j * BLK_PITCH + lane];  // S[B0+j][A0+lane]
+    const int nvalid = (n - B0 < SH) ? (int)(n - B0) : SH;
+#pragma unroll
+    for (int j = SH - 1; j >= 0; --j) {
+        const double qj = lane_bcast(qb, j);
+        const double v = sv[j] * qj;
+        qa = (j < nvalid) ? qa - v : qa;
+    }
+    return qa;
+}
+
+struct Blk3b {
+    double2_t bb[8], ba[8], aa[8];
+};
+__device__ __forceinline__ void st_prefetch_block_bwd(const double* __restrict__ M, long long ld, long long n,
+                                                      long long J0, Blk3b& blk) {
+    st_load_piece(M, ld, n, J0 + SH, J0 + SH, blk.bb);
+    st_load_piece(M, ld, n, J0 + SH, J0, blk.ba);
+    st_load_piece(M, ld, n, J0, J0, blk.aa);
+}
+
+// Whole 128-wide diagonal block at J0 (upper half first), called by all 256 threads.
+__device__ __forceinline__ void st_bwd_diag_block(long long n, long long J0, const Blk3b& blk,
+                                                  double* __restrict__ lds, const double* __restrict__ qpart,
+                                                  double* __restrict__ q) {
+    double* pBB = lds;
+    double* pBA = lds + SH * BLK_PITCH;
+    double* pAA = lds + 2 * SH * BLK_PITCH;
+    st_park_piece(pBB, blk.bb);
+    st_park_piece(pBA, blk.ba);
+    st_park_piece(pAA, blk.aa);
+    __syncthreads();
+    if ((threadIdx.x >> 6) != 0) return;
+    const int lane = threadIdx.x;
+    double qA = qpart[lane];
+    if (J0 + SH < n) {
+        double qB = st_bwd_half_chain(pBB, J0 + SH, n, qpart[lane + SH]);
+        if (J0 + SH + lane < n) q[J0 + SH + lane] = qB;
+        qA = st_bwd_mini_chain(pBA, J0 + SH, n, qB, qA);
+    }
+    qA = st_bwd_half_chain(pAA, J0, n, qA);
+    if (J0 + lane < n) q[J0 + lane] = qA;
+}
+
+constexpr int ST_LDS_DOUBLES_B = 3 * SH * BLK_PITCH;
+
+__global__ __launch_bounds__(256) void k_st_bwd_last(const double* __restrict__ M, long long ld, long long n,
+                                                     long long kb_last, double* __restrict__ q,
+                                                     const DevState* __restrict__ st) {
+    if (!st->apply) return;
+    __shared__ double lds[ST_LDS_DOUBLES_B];
+    __shared__ double qpart[SB];
+    const long long J0 = kb_last * SB;
+    Blk3b blk;
+    st_prefetch_block_bwd(M, ld, n, J0, blk);
+    if (threadIdx.x < SB) qpart[threadIdx.x] = (J0 + threadIdx.x < n) ? q[J0 + threadIdx.x] : 0.0;
+    st_bwd_diag_block(n, J0, blk, lds, qpart, q);
+}
+
+// Panel for block kb (rows J0..J0+127 of S, q final there) over columns t < J0, 128 per workgroup (each
+// wave 32 rows in two passes), then the workgroup that owns block kb-1 solves it.
 __global__ __launch_bounds__(256) void k_st_bwd_step(const double* __restrict__ M, long long ld, long long n,
                                                      long long kb, double* __restrict__ q,
                                                      const DevState* __restrict__ st) {
     if (!st->apply) return;
+    __shared__ double lds[ST_LDS_DOUBLES_B];
     __shared__ double part[4][SPANEL];
     __shared__ double qnext[SPANEL];
     const int lane = threadIdx.x & 63;
     const int wv = threadIdx.x >> 6;
     const long long J0 = kb * SB;
     const long long c0 = (long long)blockIdx.x * SPANEL;
-    const long long c = c0 + 2 * lane;  // columns c, c+1 < J0 (J0 is a multiple of 64, so both or neither)
-    const bool live = c < J0;
+    const long long c = c0 + 2 * lane;  // columns c, c+1 < J0 (J0 is a multiple of 128, so both or neither)
+    const bool owner = (long long)blockIdx.x == kb - 1;  // block kb-1 = columns [J0-128, J0)
+    Blk3b blk;
+    if (owner) st_prefetch_block_bwd(M, ld, n, J0 - SB, blk);  // independent of q: overlaps the panel work
     double p0 = 0.0, p1 = 0.0;
-    if (live) {
-        double2_t sv[16];
+    if (c < J0) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            long long row = J0 + 16 * wv + r;
-            if (row > n - 1) row = n - 1;
-            sv[r] = *reinterpret_cast<const double2_t*>(M + row * ld + c);
-        }
+        for (int h = 0; h < 2; ++h) {
+            const long long r0 = J0 + 32 * wv + 16 * h;
+            double2_t sv[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const long long row = J0 + 16 * wv + r;
-            const double qj = (row < n) ? q[row] : 0.0;  // wave-uniform
-            p0 += sv[r].x * qj;
-            p1 += sv[r].y * qj;
+            for (int r = 0; r < 16; ++r) {
+                long long row = r0 + r;
+                if (row > n - 1) row = n - 1;
+                sv[r] = *reinterpret_cast<const double2_t*>(M + row * ld + c);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const long long row = r0 + r;
+                const double qj = (row < n) ? q[row] : 0.0;  // wave-uniform
+                p0 += sv[r].x * qj;
+                p1 += sv[r].y * qj;
+            }
         }
     }
     part[wv][2 * lane] = p0;
@@ -321,11 +520,9 @@ __global__ __launch_bounds__(256) void k_st_bwd_step(const double* __restrict__ 
         }
         qnext[threadIdx.x] = qn;
     }
-    // block kb-1 = columns [J0-64, J0): owned by workgroup (J0-64)/128
-    const long long Jp = J0 - SB;
-    if (Jp < 0 || (long long)blockIdx.x != Jp / SPANEL) return;
+    if (!owner) return;
     __syncthreads();
-    if (wv == 0) st_bwd_diag_wave(M, ld, n, Jp, qnext[(Jp - c0) + lane], q);
+    st_bwd_diag_block(n, J0 - SB, blk, lds, qnext, q);
 }
 
 // xc -= (rho/omega) q   (src/ell_stable.rs:101-104)
