@@ -180,14 +180,18 @@ struct ProfScope {
 //     7.0 TB/s at n = 16384).
 void pick_shape(ellhip_space* s) {
     const double q_bytes = (double)s->nrows * (double)s->ld * 8.0;
-    const bool fits_mall = q_bytes <= 200.0 * 1024 * 1024;
-    if (fits_mall) {
+    const double MiB = 1024.0 * 1024.0;
+    if (q_bytes <= 200.0 * MiB) {          // lives in the Infinity Cache between passes
         s->sh_gemv = {4, 2, 0};
         s->sh_rank1 = {4, 4, 0};
         s->sh_fused = {4, 4, 0};
-    } else {
+    } else if (q_bytes <= 1024.0 * MiB) {  // a few x the cache: read-only pass streams, RMW passes keep what fits
         s->sh_gemv = {4, 4, 1};
-        s->sh_rank1 = {1, 4, 1};
+        s->sh_rank1 = {4, 4, 0};
+        s->sh_fused = {4, 4, 0};
+    } else {                               // pure streaming
+        s->sh_gemv = {4, 4, 1};
+        s->sh_rank1 = {2, 8, 1};
         s->sh_fused = {2, 8, 1};
     }
     s->sh_gemv.rw = env_int("ELLHIP_GEMV_RW", s->sh_gemv.rw);
