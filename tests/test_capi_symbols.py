@@ -1,0 +1,63 @@
+"""CPU: libellhip.so loads, exports every entry point include/ellhip.h declares, and refuses to
+compute without a HIP device (there is no CPU fallback to fall into)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_functions():
+    src = open(os.path.join(ROOT, "include", "ellhip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(ellhip_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_declares_what_the_binding_lists():
+    import ellalgo_rs_amd as pkg
+    assert declared_functions() == sorted(pkg.capi.EXPORTS)
+
+
+@pytest.mark.parametrize("name", declared_functions())
+def test_symbol_exported(name):
+    import ellalgo_rs_amd as pkg
+    lib = C.CDLL(pkg.capi.lib_path())
+    assert getattr(lib, name) is not None
+
+
+def test_version_string():
+    import ellalgo_rs_amd as pkg
+    assert pkg.capi.load().ellhip_version().decode().startswith("ellhip ")
+
+
+def test_no_device_means_loud_failure_not_fallback():
+    import ellalgo_rs_amd as pkg
+    lib = pkg.capi.load()
+    if lib.ellhip_device_count() > 0:
+        pytest.skip("a HIP device is visible here")
+    h = C.c_void_p()
+    rc = lib.ellhip_create(C.byref(h), 0, 4, 1.0, None, None, None, -1)
+    assert rc == pkg.capi.E_NODEVICE and not h.value
+    assert b"no HIP device" in lib.ellhip_last_error()
+    out = (C.c_double * 3)()
+    assert lib.ellhip_calc(4, 1, 0, 0.05, 0, 0.0, 0.01, out, -1) == pkg.capi.E_NODEVICE
+    with pytest.raises(pkg.capi.EllHipError):
+        pkg.Ell.new_with_scalar(1.0, np.zeros(4))
+    with pytest.raises(pkg.capi.EllHipError):
+        pkg.EllStable.new_with_scalar(1.0, np.zeros(4))
+
+
+def test_product_package_never_imports_the_oracle():
+    """The oracle is test infrastructure: nothing under ellalgo-rs_amd/ may reference it."""
+    pkg_dir = os.path.join(ROOT, "ellalgo-rs_amd")
+    offenders = []
+    for base, _, files in os.walk(pkg_dir):
+        for f in files:
+            if f.endswith((".py", ".hpp", ".hip", ".h", ".cpp")):
+                text = open(os.path.join(base, f), errors="replace").read()
+                if re.search(r"(from|import)\s+oracle\b|ell_oracle\.h|libell_oracle", text):
+                    offenders.append(os.path.join(base, f))
+    assert not offenders, offenders
