@@ -56,6 +56,8 @@ struct DevState {
     int halted;             // queue mode: set at the first non-Success cut
     int halted_in;          // snapshot of `halted` for kernels whose lead workgroup rewrites it
     double kappa_in;        // snapshot of kappa taken by k_scalar_dot for k_scalar_apply
+    int solve_err;          // EllStable persistent solves: nonzero if a bounded flag wait timed out
+    int pad_;
 };
 
 typedef double double2_t __attribute__((ext_vector_type(2)));

@@ -14,6 +14,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <cstddef>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -77,6 +78,9 @@ struct ellhip_space {
     double* d_gt[2] = {nullptr, nullptr};      // buffers in use (own or caller's)
     double* d_work = nullptr;        // EllStable vectors: w, z, gg, q, beta2
     double* d_partial = nullptr;     // per-workgroup partial sums of omega (64)
+    int* d_flags = nullptr;          // EllStable persistent solves: block-ready flags (forward | backward)
+    int epoch = 0;                   // hand-off epoch, bumped per persistent launch
+    int stable_persist = 1;          // one-launch flag-chained solves (0: one launch per block)
     DevState* d_st = nullptr;
 
     double* h_stage[2] = {nullptr, nullptr};  // pinned, n doubles each
@@ -266,14 +270,23 @@ int ellstable_issue(ellhip_space* s, const double* g_dev, const CutParams* cp_de
     double* beta2 = q + n;
     double* dscale = beta2 + n;
     hipStream_t st = s->stream;
+    // One launch per solve when every 128-column strip can have its own resident workgroup; otherwise
+    // (n > 128 * 256) one launch per block.
+    const bool persist = s->stable_persist && nb <= 256;
+    int* err = reinterpret_cast<int*>(reinterpret_cast<char*>(s->d_st) + offsetof(DevState, solve_err));
     {
         ProfScope ps(s, CLS_ST_FWD);
-        HIPCHK(hipMemcpyAsync(w, g_dev, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, st));
-        hipLaunchKernelGGL(k_st_fwd_first, dim3(1), dim3(256), 0, st, s->d_Q, ld, n, g_dev, w, z, gg, s->d_st);
-        for (long long kb = 0; kb + 1 < nb; ++kb) {
-            const long long rest = n - (kb + 1) * SB;
-            const unsigned grid = (unsigned)((rest + SPANEL - 1) / SPANEL);
-            hipLaunchKernelGGL(k_st_fwd_step, dim3(grid), dim3(256), 0, st, s->d_Q, ld, n, kb, w, z, gg, s->d_st);
+        if (persist) {
+            hipLaunchKernelGGL(k_st_fwd_persist, dim3((unsigned)nb), dim3(256), 0, st, s->d_Q, ld, n, g_dev, w, z, gg,
+                               s->d_flags, err, ++s->epoch, s->d_st);
+        } else {
+            HIPCHK(hipMemcpyAsync(w, g_dev, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, st));
+            hipLaunchKernelGGL(k_st_fwd_first, dim3(1), dim3(256), 0, st, s->d_Q, ld, n, g_dev, w, z, gg, s->d_st);
+            for (long long kb = 0; kb + 1 < nb; ++kb) {
+                const long long rest = n - (kb + 1) * SB;
+                const unsigned grid = (unsigned)((rest + SPANEL - 1) / SPANEL);
+                hipLaunchKernelGGL(k_st_fwd_step, dim3(grid), dim3(256), 0, st, s->d_Q, ld, n, kb, w, z, gg, s->d_st);
+            }
         }
         HIPCHK(hipGetLastError());
     }
@@ -288,10 +301,15 @@ int ellstable_issue(ellhip_space* s, const double* g_dev, const CutParams* cp_de
     }
     {
         ProfScope ps(s, CLS_ST_BWD);
-        hipLaunchKernelGGL(k_st_bwd_last, dim3(1), dim3(256), 0, st, s->d_Q, ld, n, nb - 1, q, s->d_st);
-        for (long long kb = nb - 1; kb >= 1; --kb) {
-            const unsigned grid = (unsigned)((kb * SB + SPANEL - 1) / SPANEL);
-            hipLaunchKernelGGL(k_st_bwd_step, dim3(grid), dim3(256), 0, st, s->d_Q, ld, n, kb, q, s->d_st);
+        if (persist) {
+            hipLaunchKernelGGL(k_st_bwd_persist, dim3((unsigned)nb), dim3(256), 0, st, s->d_Q, ld, n, q,
+                               s->d_flags + 256, err, ++s->epoch, s->d_st);
+        } else {
+            hipLaunchKernelGGL(k_st_bwd_last, dim3(1), dim3(256), 0, st, s->d_Q, ld, n, nb - 1, q, s->d_st);
+            for (long long kb = nb - 1; kb >= 1; --kb) {
+                const unsigned grid = (unsigned)((kb * SB + SPANEL - 1) / SPANEL);
+                hipLaunchKernelGGL(k_st_bwd_step, dim3(grid), dim3(256), 0, st, s->d_Q, ld, n, kb, q, s->d_st);
+            }
         }
         const unsigned gx = (unsigned)((n + 255) / 256);
         hipLaunchKernelGGL(k_st_xc, dim3(gx < 256 ? gx : 256), dim3(256), 0, st, n, q, s->d_xc, s->d_st);
@@ -363,6 +381,8 @@ int read_back(ellhip_space* s) {
     HIPCHK(hipStreamSynchronize(s->stream));
     s->kappa = s->h_result->kappa;
     s->tsq = s->h_result->tsq;
+    if (s->h_result->solve_err)
+        return fail(ELLHIP_E_HIP, "EllStable persistent solve: a flag wait timed out (set ELLHIP_STABLE_PERSIST=0)");
     return 0;
 }
 
@@ -417,6 +437,11 @@ int alloc_common(ellhip_space* s) {
     }
     HIPCHK(hipMalloc(&s->d_st, sizeof(DevState)));
     HIPCHK(hipMalloc(&s->d_partial, 64 * sizeof(double)));
+    if (s->variant == ELLHIP_SPACE_ELL_STABLE) {
+        HIPCHK(hipMalloc(&s->d_flags, 512 * sizeof(int)));
+        HIPCHK(hipMemsetAsync(s->d_flags, 0, 512 * sizeof(int), s->stream));
+        s->stable_persist = env_int("ELLHIP_STABLE_PERSIST", 1);
+    }
     if (s->variant == ELLHIP_SPACE_ELL_STABLE) HIPCHK(hipMalloc(&s->d_work, vbytes * 7));
     HIPCHK(hipHostMalloc(&s->h_result, sizeof(DevState), hipHostMallocDefault));
     return 0;
@@ -635,6 +660,7 @@ void ellhip_destroy(ellhip_space* s) {
     }
     if (s->d_work) (void)hipFree(s->d_work);
     if (s->d_partial) (void)hipFree(s->d_partial);
+    if (s->d_flags) (void)hipFree(s->d_flags);
     if (s->d_st) (void)hipFree(s->d_st);
     if (s->h_result) (void)hipHostFree(s->h_result);
     if (s->own_stream) (void)hipStreamDestroy(s->own_stream);

@@ -88,12 +88,17 @@ __device__ __forceinline__ double st_fwd_half_chain(double* __restrict__ piece, 
     double u[SH];
 #pragma unroll
     for (int j = 0; j < SH; ++j) u[j] = piece[j * BLK_PITCH + lane];
+    // Critical path per step: subtract -> broadcast lane j+1 -> multiply -> subtract.  The broadcast
+    // reads the unselected difference `t` (lane j+1 is always an active lane of step j), so the select
+    // that protects the already-final lanes <= j runs beside the chain, not in it.
+    double t = wi;
 #pragma unroll
     for (int j = 0; j < SH; ++j) {
-        const double wj = lane_bcast(wi, j);
-        const double v = u[j] * wj;      // :65
-        u[j] = v;                        // parked product, :66 (meaningful for j < lane only)
-        wi = (lane > j) ? wi - v : wi;   // :67
+        const double wj = lane_bcast(t, j);  // lane j's value is final after step j-1
+        const double v = u[j] * wj;          // :65
+        u[j] = v;                            // parked product, :66 (meaningful for j < lane only)
+        t = wi - v;                          // :67
+        wi = (lane > j) ? t : wi;
     }
 #pragma unroll
     for (int j = 0; j < SH; ++j) piece[lane * BLK_PITCH + j] = u[j];
@@ -139,14 +144,42 @@ __device__ __forceinline__ void st_store_piece(double* __restrict__ M, long long
     }
 }
 
+// ---- in-launch hand-off of a finished 128-vector between workgroups (persistent solves) ------------
+// cdna_hip_programming.md Guideline 16, write-through form: the payload is stored with agent-scope
+// relaxed atomics (sc1, 8 bytes each) by ONE wave, that wave drains its stores (s_waitcnt vmcnt(0)) and
+// its lane 0 stores the flag; a consumer polls the flag with ONE lane (relaxed, agent), then a
+// workgroup barrier, then every load of the payload is again an sc1 load.  Spins are bounded: on
+// time-out the error word is set and the workgroup leaves (results are then invalid, the GPU is not hung).
+__device__ __forceinline__ void st_publish_store(double* p, double v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double st_published_load(const double* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_raise_flag(int* flag, int epoch) {  // called by the storing wave, all lanes
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if ((threadIdx.x & 63) == 0) __hip_atomic_store(flag, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// One lane polls; returns false on time-out.  Call from thread 0 only.
+__device__ __forceinline__ bool st_wait_flag(const int* flag, int epoch) {
+    for (int spin = 0; spin < (1 << 20); ++spin) {
+        if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch) return true;
+        __builtin_amdgcn_s_sleep(2);
+    }
+    return false;
+}
+
 // Whole 128-wide diagonal block at J0, called by all 256 threads of one workgroup.
 //   blk: prefetched pieces; dreg: this thread's diagonal entry M[J0+t][J0+t] (t < 128);
 //   lds: 3 * 64 * BLK_PITCH doubles; wpart[128]: partial w of the block's columns (LDS).
+//   PUBLISH: w is handed to other workgroups inside this launch (write-through stores + flag) before the
+//   parked products are written back.
+template <bool PUBLISH>
 __device__ __forceinline__ void st_fwd_diag_block(double* __restrict__ M, long long ld, long long n, long long J0,
                                                   const Blk3& blk, double dreg, double* __restrict__ lds,
                                                   double* __restrict__ dlds, const double* __restrict__ wpart,
                                                   double* __restrict__ w, double* __restrict__ z,
-                                                  double* __restrict__ gg) {
+                                                  double* __restrict__ gg, int* flag = nullptr, int epoch = 0) {
     double* pAA = lds;
     double* pAB = lds + SH * BLK_PITCH;
     double* pBB = lds + 2 * SH * BLK_PITCH;
@@ -163,7 +196,7 @@ __device__ __forceinline__ void st_fwd_diag_block(double* __restrict__ M, long l
             const long long c = J0 + lane;
             if (c < n) {
                 const double zi = wA * dlds[lane];  // :74
-                w[c] = wA;
+                if (PUBLISH) st_publish_store(w + c, wA); else w[c] = wA;
                 z[c] = zi;
                 gg[c] = zi * wA;  // :81
             }
@@ -174,11 +207,12 @@ __device__ __forceinline__ void st_fwd_diag_block(double* __restrict__ M, long l
             const long long c = J0 + SH + lane;
             if (c < n) {
                 const double zi = wB * dlds[lane + SH];
-                w[c] = wB;
+                if (PUBLISH) st_publish_store(w + c, wB); else w[c] = wB;
                 z[c] = zi;
                 gg[c] = zi * wB;
             }
         }
+        if (PUBLISH) st_raise_flag(flag, epoch);
     }
     __syncthreads();
     st_store_piece(M, ld, n, J0, J0, pAA, true);                       // S[A][A], strict lower
@@ -212,7 +246,7 @@ __global__ __launch_bounds__(256) void k_st_fwd_first(double* __restrict__ M, lo
     double dreg;
     st_prefetch_block(M, ld, n, 0, blk, dreg);
     if (threadIdx.x < SB) wpart[threadIdx.x] = (threadIdx.x < n) ? g[threadIdx.x] : 0.0;
-    st_fwd_diag_block(M, ld, n, 0, blk, dreg, lds, dlds, wpart, w, z, gg);
+    st_fwd_diag_block<false>(M, ld, n, 0, blk, dreg, lds, dlds, wpart, w, z, gg);
 }
 
 // Panel update for block kb (rows J0..J0+127, already final in w) over columns >= J0 + 128, 128 columns
@@ -289,7 +323,102 @@ __global__ __launch_bounds__(256) void k_st_fwd_step(double* __restrict__ M, lon
     }
     if (!owner) return;
     __syncthreads();  // panel tiles are dead from here on: `lds` is reused for the parked pieces
-    st_fwd_diag_block(M, ld, n, Jend, blk, dreg, lds, dlds, wnext, w, z, gg);
+    st_fwd_diag_block<false>(M, ld, n, Jend, blk, dreg, lds, dlds, wnext, w, z, gg);
+}
+
+// Persistent forward solve: ONE launch, workgroup s owns the 128 columns of block s.  It applies the row
+// blocks kb = 0..s-1 to its strip as soon as their w is published (flag kb), keeping the strip's partial w
+// in LDS, then solves its own diagonal block and publishes.  The dependency chain (n steps + one hand-off
+// per block) is the critical path; all panel traffic overlaps with it.  grid = ceil(n/128) <= #CUs.
+__global__ __launch_bounds__(256) void k_st_fwd_persist(double* __restrict__ M, long long ld, long long n,
+                                                        const double* __restrict__ g, double* __restrict__ w,
+                                                        double* __restrict__ z, double* __restrict__ gg,
+                                                        int* __restrict__ flags, int* __restrict__ err, int epoch,
+                                                        const DevState* __restrict__ st) {
+    if (st->halted) return;
+    __shared__ __attribute__((aligned(16))) double lds[ST_LDS_DOUBLES];  // panel tiles, then the parked pieces
+    __shared__ double part[4][SPANEL];
+    __shared__ double wstrip[SPANEL];
+    __shared__ double wblk[SB];
+    __shared__ double dlds[SB];
+    __shared__ int ok;
+    const int lane = threadIdx.x & 63;
+    const int wv = threadIdx.x >> 6;
+    const long long sblk = blockIdx.x;
+    const long long c0 = sblk * SB;
+    const long long c = c0 + 2 * lane;
+    const long long cl = (c < n) ? c : 0;
+    const int piece = lane & 7;
+
+    Blk3 blk;
+    double dreg;
+    st_prefetch_block(M, ld, n, c0, blk, dreg);  // own diagonal block: independent of everything else
+    if (threadIdx.x < SPANEL) wstrip[threadIdx.x] = (c0 + threadIdx.x < n) ? g[c0 + threadIdx.x] : 0.0;
+
+    double* t = lds + wv * (SPANEL * SLDS_PAD);
+    for (long long kb = 0; kb < sblk; ++kb) {
+        const long long J0 = kb * SB;  // all 128 rows exist: J0 + 128 <= c0 < n
+        // the U rows of the first pass do not depend on the flag: issue them before waiting
+        double2_t u0[16];
+        {
+            const long long r0 = J0 + 32 * wv;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) u0[r] = *reinterpret_cast<const double2_t*>(M + (r0 + r) * ld + cl);
+        }
+        if (threadIdx.x == 0) ok = st_wait_flag(flags + kb, epoch) ? 1 : 0;
+        __syncthreads();
+        if (!ok) {
+            if (threadIdx.x == 0) atomicExch(err, 1);
+            return;
+        }
+        if (threadIdx.x < SB) wblk[threadIdx.x] = st_published_load(w + J0 + threadIdx.x);
+        __syncthreads();
+        double p0 = 0.0, p1 = 0.0;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const long long r0 = J0 + 32 * wv + 16 * h;
+            double2_t u[16];
+            if (h == 0) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) u[r] = u0[r];
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) u[r] = *reinterpret_cast<const double2_t*>(M + (r0 + r) * ld + cl);
+                __syncthreads();  // the tile of the previous pass has been drained
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const double wj = wblk[32 * wv + 16 * h + r];
+                const double v0 = u[r].x * wj;
+                const double v1 = u[r].y * wj;
+                p0 += v0;
+                p1 += v1;
+                t[(2 * lane) * SLDS_PAD + r] = v0;
+                t[(2 * lane + 1) * SLDS_PAD + r] = v1;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const int col_local = 8 * k + (lane >> 3);
+                const long long col = c0 + col_local;
+                if (col < n) {
+                    const double2_t v = *reinterpret_cast<const double2_t*>(&t[col_local * SLDS_PAD + 2 * piece]);
+                    *reinterpret_cast<double2_t*>(M + col * ld + r0 + 2 * piece) = v;
+                }
+            }
+        }
+        part[wv][2 * lane] = p0;
+        part[wv][2 * lane + 1] = p1;
+        __syncthreads();
+        if (threadIdx.x < SPANEL) {
+            const double s4 = ((part[0][threadIdx.x] + part[1][threadIdx.x]) + part[2][threadIdx.x]) +
+                              part[3][threadIdx.x];
+            wstrip[threadIdx.x] = wstrip[threadIdx.x] - s4;
+        }
+        __syncthreads();  // tiles drained, wstrip / part reusable
+    }
+    __syncthreads();
+    st_fwd_diag_block<true>(M, ld, n, c0, blk, dreg, lds, dlds, wstrip, w, z, gg, flags + sblk, epoch);
 }
 
 // ---------------------------------------------------------------------------------- mid -------
@@ -431,9 +560,10 @@ __device__ __forceinline__ void st_prefetch_block_bwd(const double* __restrict__
 }
 
 // Whole 128-wide diagonal block at J0 (upper half first), called by all 256 threads.
+template <bool PUBLISH>
 __device__ __forceinline__ void st_bwd_diag_block(long long n, long long J0, const Blk3b& blk,
                                                   double* __restrict__ lds, const double* __restrict__ qpart,
-                                                  double* __restrict__ q) {
+                                                  double* __restrict__ q, int* flag = nullptr, int epoch = 0) {
     double* pBB = lds;
     double* pBA = lds + SH * BLK_PITCH;
     double* pAA = lds + 2 * SH * BLK_PITCH;
@@ -446,11 +576,16 @@ __device__ __forceinline__ void st_bwd_diag_block(long long n, long long J0, con
     double qA = qpart[lane];
     if (J0 + SH < n) {
         double qB = st_bwd_half_chain(pBB, J0 + SH, n, qpart[lane + SH]);
-        if (J0 + SH + lane < n) q[J0 + SH + lane] = qB;
+        if (J0 + SH + lane < n) {
+            if (PUBLISH) st_publish_store(q + J0 + SH + lane, qB); else q[J0 + SH + lane] = qB;
+        }
         qA = st_bwd_mini_chain(pBA, J0 + SH, n, qB, qA);
     }
     qA = st_bwd_half_chain(pAA, J0, n, qA);
-    if (J0 + lane < n) q[J0 + lane] = qA;
+    if (J0 + lane < n) {
+        if (PUBLISH) st_publish_store(q + J0 + lane, qA); else q[J0 + lane] = qA;
+    }
+    if (PUBLISH) st_raise_flag(flag, epoch);
 }
 
 constexpr int ST_LDS_DOUBLES_B = 3 * SH * BLK_PITCH;
@@ -465,7 +600,7 @@ __global__ __launch_bounds__(256) void k_st_bwd_last(const double* __restrict__ 
     Blk3b blk;
     st_prefetch_block_bwd(M, ld, n, J0, blk);
     if (threadIdx.x < SB) qpart[threadIdx.x] = (J0 + threadIdx.x < n) ? q[J0 + threadIdx.x] : 0.0;
-    st_bwd_diag_block(n, J0, blk, lds, qpart, q);
+    st_bwd_diag_block<false>(n, J0, blk, lds, qpart, q);
 }
 
 // Panel for block kb (rows J0..J0+127 of S, q final there) over columns t < J0, 128 per workgroup (each
@@ -522,7 +657,88 @@ __global__ __launch_bounds__(256) void k_st_bwd_step(const double* __restrict__ 
     }
     if (!owner) return;
     __syncthreads();
-    st_bwd_diag_block(n, J0 - SB, blk, lds, qnext, q);
+    st_bwd_diag_block<false>(n, J0 - SB, blk, lds, qnext, q);
+}
+
+// Persistent backward solve: ONE launch; workgroup b owns strip nblk-1-b (dispatch order = dependency
+// order).  It applies the row blocks kb = nblk-1 .. strip+1 of the scratch triangle to its 128 columns as
+// their q is published, then solves its diagonal block and publishes.
+__global__ __launch_bounds__(256) void k_st_bwd_persist(const double* __restrict__ M, long long ld, long long n,
+                                                        double* __restrict__ q, int* __restrict__ flags,
+                                                        int* __restrict__ err, int epoch,
+                                                        const DevState* __restrict__ st) {
+    if (!st->apply) return;
+    __shared__ double lds[ST_LDS_DOUBLES_B];
+    __shared__ double part[4][SPANEL];
+    __shared__ double qstrip[SPANEL];
+    __shared__ double qblk[SB];
+    __shared__ int ok;
+    const int lane = threadIdx.x & 63;
+    const int wv = threadIdx.x >> 6;
+    const long long nblk = gridDim.x;
+    const long long sblk = nblk - 1 - blockIdx.x;
+    const long long c0 = sblk * SB;
+    const long long c = c0 + 2 * lane;  // columns c, c+1 < c0 + 128 <= J0 of every row block applied here
+
+    Blk3b blk;
+    st_prefetch_block_bwd(M, ld, n, c0, blk);
+    if (threadIdx.x < SPANEL) qstrip[threadIdx.x] = (c0 + threadIdx.x < n) ? q[c0 + threadIdx.x] : 0.0;
+
+    for (long long kb = nblk - 1; kb > sblk; --kb) {
+        const long long J0 = kb * SB;
+        double2_t s0[16];
+        {
+            const long long r0 = J0 + 32 * wv;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                long long row = r0 + r;
+                if (row > n - 1) row = n - 1;
+                s0[r] = *reinterpret_cast<const double2_t*>(M + row * ld + c);
+            }
+        }
+        if (threadIdx.x == 0) ok = st_wait_flag(flags + kb, epoch) ? 1 : 0;
+        __syncthreads();
+        if (!ok) {
+            if (threadIdx.x == 0) atomicExch(err, 2);
+            return;
+        }
+        if (threadIdx.x < SB) qblk[threadIdx.x] = (J0 + threadIdx.x < n) ? st_published_load(q + J0 + threadIdx.x) : 0.0;
+        __syncthreads();
+        double p0 = 0.0, p1 = 0.0;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const long long r0 = J0 + 32 * wv + 16 * h;
+            double2_t sv[16];
+            if (h == 0) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sv[r] = s0[r];
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    long long row = r0 + r;
+                    if (row > n - 1) row = n - 1;
+                    sv[r] = *reinterpret_cast<const double2_t*>(M + row * ld + c);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const double qj = qblk[32 * wv + 16 * h + r];  // 0 for rows beyond n
+                p0 += sv[r].x * qj;
+                p1 += sv[r].y * qj;
+            }
+        }
+        part[wv][2 * lane] = p0;
+        part[wv][2 * lane + 1] = p1;
+        __syncthreads();
+        if (threadIdx.x < SPANEL) {
+            const double s4 = ((part[0][threadIdx.x] + part[1][threadIdx.x]) + part[2][threadIdx.x]) +
+                              part[3][threadIdx.x];
+            qstrip[threadIdx.x] = qstrip[threadIdx.x] - s4;
+        }
+        __syncthreads();
+    }
+    __syncthreads();
+    st_bwd_diag_block<true>(n, c0, blk, lds, qstrip, q, flags + sblk, epoch);
 }
 
 // xc -= (rho/omega) q   (src/ell_stable.rs:101-104)
