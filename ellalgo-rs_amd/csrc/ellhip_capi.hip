@@ -81,6 +81,7 @@ struct ellhip_space {
     int* d_flags = nullptr;          // EllStable persistent solves: block-ready flags (forward | backward)
     int epoch = 0;                   // hand-off epoch, bumped per persistent launch
     int stable_persist = 1;          // one-launch flag-chained solves (0: one launch per block)
+    int stable_overlap = 1;          // factor update beside the persistent backward solve
     DevState* d_st = nullptr;
 
     double* h_stage[2] = {nullptr, nullptr};  // pinned, n doubles each
@@ -88,6 +89,8 @@ struct ellhip_space {
 
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
+    hipStream_t aux_stream = nullptr;           // EllStable: factor update runs beside the persistent backward solve
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 
     int no_defer_trick = 0;
     int use_parallel_cut = 1;
@@ -154,7 +157,8 @@ int prof_flush(ellhip_space* s) {
 struct ProfScope {
     ellhip_space* s;
     ProfEvent* pe = nullptr;
-    ProfScope(ellhip_space* sp, int cls) : s(sp) {
+    hipStream_t stream;
+    ProfScope(ellhip_space* sp, int cls, hipStream_t on = nullptr) : s(sp), stream(on ? on : sp->stream) {
         if (!s->profile) return;
         if (s->prof_used == s->prof_events.size()) {
             if (s->prof_events.size() >= 8192) {
@@ -168,10 +172,10 @@ struct ProfScope {
         }
         pe = &s->prof_events[s->prof_used++];
         pe->cls = cls;
-        (void)hipEventRecord(pe->a, s->stream);
+        (void)hipEventRecord(pe->a, stream);
     }
     ~ProfScope() {
-        if (pe) (void)hipEventRecord(pe->b, s->stream);
+        if (pe) (void)hipEventRecord(pe->b, stream);
     }
 };
 
@@ -299,6 +303,12 @@ int ellstable_issue(ellhip_space* s, const double* g_dev, const CutParams* cp_de
                            (const double*)dscale, s->d_st);
         HIPCHK(hipGetLastError());
     }
+    // The factor update (reads S, rewrites U) and the backward solve (reads S, writes q) are independent.
+    // With the persistent backward solve (128 resident workgroups, latency-bound) the bandwidth-bound
+    // factor update runs beside it on the auxiliary stream, launched AFTER it so the solve's workgroups
+    // are placed first; the streams join before anything else touches the buffer.
+    const bool overlap = persist && s->stable_overlap;
+    if (overlap) HIPCHK(hipEventRecord(s->ev_fork, st));
     {
         ProfScope ps(s, CLS_ST_BWD);
         if (persist) {
@@ -316,10 +326,18 @@ int ellstable_issue(ellhip_space* s, const double* g_dev, const CutParams* cp_de
         HIPCHK(hipGetLastError());
     }
     {
-        ProfScope ps(s, CLS_ST_FACTOR);
-        const unsigned nt64 = (unsigned)((n + 63) / 64);  // the factor update works on 64x64 tiles
-        hipLaunchKernelGGL(k_st_factor, dim3(nt64, nt64), dim3(256), 0, st, s->d_Q, ld, n, beta2, s->d_st);
-        HIPCHK(hipGetLastError());
+        hipStream_t fs = overlap ? s->aux_stream : st;
+        if (overlap) HIPCHK(hipStreamWaitEvent(fs, s->ev_fork, 0));
+        {
+            ProfScope ps(s, CLS_ST_FACTOR, fs);
+            const unsigned nt64 = (unsigned)((n + 63) / 64);  // the factor update works on 64x64 tiles
+            hipLaunchKernelGGL(k_st_factor, dim3(nt64, nt64), dim3(256), 0, fs, s->d_Q, ld, n, beta2, s->d_st);
+            HIPCHK(hipGetLastError());
+        }
+        if (overlap) {
+            HIPCHK(hipEventRecord(s->ev_join, fs));
+            HIPCHK(hipStreamWaitEvent(st, s->ev_join, 0));
+        }
     }
     return 0;
 }
@@ -441,6 +459,10 @@ int alloc_common(ellhip_space* s) {
         HIPCHK(hipMalloc(&s->d_flags, 512 * sizeof(int)));
         HIPCHK(hipMemsetAsync(s->d_flags, 0, 512 * sizeof(int), s->stream));
         s->stable_persist = env_int("ELLHIP_STABLE_PERSIST", 1);
+        s->stable_overlap = env_int("ELLHIP_STABLE_OVERLAP", 1);
+        HIPCHK(hipStreamCreateWithFlags(&s->aux_stream, hipStreamNonBlocking));
+        HIPCHK(hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&s->ev_join, hipEventDisableTiming));
     }
     if (s->variant == ELLHIP_SPACE_ELL_STABLE) HIPCHK(hipMalloc(&s->d_work, vbytes * 7));
     HIPCHK(hipHostMalloc(&s->h_result, sizeof(DevState), hipHostMallocDefault));
@@ -663,6 +685,10 @@ void ellhip_destroy(ellhip_space* s) {
     if (s->d_flags) (void)hipFree(s->d_flags);
     if (s->d_st) (void)hipFree(s->d_st);
     if (s->h_result) (void)hipHostFree(s->h_result);
+    if (s->aux_stream) (void)hipStreamSynchronize(s->aux_stream);
+    if (s->ev_fork) (void)hipEventDestroy(s->ev_fork);
+    if (s->ev_join) (void)hipEventDestroy(s->ev_join);
+    if (s->aux_stream) (void)hipStreamDestroy(s->aux_stream);
     if (s->own_stream) (void)hipStreamDestroy(s->own_stream);
     delete s;
 }
