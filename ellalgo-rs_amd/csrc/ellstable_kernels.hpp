@@ -110,13 +110,18 @@ __device__ __forceinline__ double st_fwd_mini_chain(double* __restrict__ piece, 
     double u[SH];
 #pragma unroll
     for (int j = 0; j < SH; ++j) u[j] = piece[j * BLK_PITCH + lane];
+    // not a dependency chain: four interleaved partial sums (16 steps deep instead of 64)
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
 #pragma unroll
-    for (int j = 0; j < SH; ++j) {
-        const double wj = lane_bcast(wa, j);
-        const double v = u[j] * wj;
-        u[j] = v;
-        wb = wb - v;
+    for (int j = 0; j < SH; j += 4) {
+        const double v0 = u[j] * lane_bcast(wa, j);
+        const double v1 = u[j + 1] * lane_bcast(wa, j + 1);
+        const double v2 = u[j + 2] * lane_bcast(wa, j + 2);
+        const double v3 = u[j + 3] * lane_bcast(wa, j + 3);
+        u[j] = v0, u[j + 1] = v1, u[j + 2] = v2, u[j + 3] = v3;
+        a0 += v0, a1 += v1, a2 += v2, a3 += v3;
     }
+    wb = wb - ((a0 + a1) + (a2 + a3));
 #pragma unroll
     for (int j = 0; j < SH; ++j) piece[lane * BLK_PITCH + j] = u[j];
     return wb;
@@ -351,20 +356,23 @@ __global__ __launch_bounds__(256) void k_st_fwd_persist(double* __restrict__ M, 
     const int piece = lane & 7;
 
     Blk3 blk;
-    double dreg;
-    st_prefetch_block(M, ld, n, c0, blk, dreg);  // own diagonal block: independent of everything else
+    double dreg = 0.0;
+    if (sblk == 0) st_prefetch_block(M, ld, n, c0, blk, dreg);  // no panel work: fetch the own block right away
     if (threadIdx.x < SPANEL) wstrip[threadIdx.x] = (c0 + threadIdx.x < n) ? g[c0 + threadIdx.x] : 0.0;
 
     double* t = lds + wv * (SPANEL * SLDS_PAD);
     for (long long kb = 0; kb < sblk; ++kb) {
         const long long J0 = kb * SB;  // all 128 rows exist: J0 + 128 <= c0 < n
-        // the U rows of the first pass do not depend on the flag: issue them before waiting
-        double2_t u0[16];
-        {
-            const long long r0 = J0 + 32 * wv;
+        // nothing below depends on the flag except w: request both passes' rows of U (and, in the last
+        // iteration, the own diagonal block) before waiting, so their HBM latency is hidden behind the wait
+        double2_t u[2][16];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) u0[r] = *reinterpret_cast<const double2_t*>(M + (r0 + r) * ld + cl);
+        for (int h = 0; h < 2; ++h) {
+            const long long r0 = J0 + 32 * wv + 16 * h;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) u[h][r] = *reinterpret_cast<const double2_t*>(M + (r0 + r) * ld + cl);
         }
+        if (kb == sblk - 1) st_prefetch_block(M, ld, n, c0, blk, dreg);
         if (threadIdx.x == 0) ok = st_wait_flag(flags + kb, epoch) ? 1 : 0;
         __syncthreads();
         if (!ok) {
@@ -377,20 +385,12 @@ __global__ __launch_bounds__(256) void k_st_fwd_persist(double* __restrict__ M, 
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const long long r0 = J0 + 32 * wv + 16 * h;
-            double2_t u[16];
-            if (h == 0) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) u[r] = u0[r];
-            } else {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) u[r] = *reinterpret_cast<const double2_t*>(M + (r0 + r) * ld + cl);
-                __syncthreads();  // the tile of the previous pass has been drained
-            }
+            if (h) __syncthreads();  // the tile of the previous pass has been drained
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const double wj = wblk[32 * wv + 16 * h + r];
-                const double v0 = u[r].x * wj;
-                const double v1 = u[r].y * wj;
+                const double v0 = u[h][r].x * wj;
+                const double v1 = u[h][r].y * wj;
                 p0 += v0;
                 p1 += v1;
                 t[(2 * lane) * SLDS_PAD + r] = v0;
@@ -540,13 +540,19 @@ __device__ __forceinline__ double st_bwd_mini_chain(const double* __restrict__ p
 #pragma unroll
     for (int j = 0; j < SH; ++j) sv[j] = piece[j * BLK_PITCH + lane];  // S[B0+j][A0+lane]
     const int nvalid = (n - B0 < SH) ? (int)(n - B0) : SH;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;  // four interleaved partial sums, not a 64-deep chain
 #pragma unroll
-    for (int j = SH - 1; j >= 0; --j) {
-        const double qj = lane_bcast(qb, j);
-        const double v = sv[j] * qj;
-        qa = (j < nvalid) ? qa - v : qa;
+    for (int j = 0; j < SH; j += 4) {
+        const double v0 = sv[j] * lane_bcast(qb, j);
+        const double v1 = sv[j + 1] * lane_bcast(qb, j + 1);
+        const double v2 = sv[j + 2] * lane_bcast(qb, j + 2);
+        const double v3 = sv[j + 3] * lane_bcast(qb, j + 3);
+        a0 += (j < nvalid) ? v0 : 0.0;
+        a1 += (j + 1 < nvalid) ? v1 : 0.0;
+        a2 += (j + 2 < nvalid) ? v2 : 0.0;
+        a3 += (j + 3 < nvalid) ? v3 : 0.0;
     }
-    return qa;
+    return qa - ((a0 + a1) + (a2 + a3));
 }
 
 struct Blk3b {
@@ -681,21 +687,23 @@ __global__ __launch_bounds__(256) void k_st_bwd_persist(const double* __restrict
     const long long c = c0 + 2 * lane;  // columns c, c+1 < c0 + 128 <= J0 of every row block applied here
 
     Blk3b blk;
-    st_prefetch_block_bwd(M, ld, n, c0, blk);
+    if (sblk == nblk - 1) st_prefetch_block_bwd(M, ld, n, c0, blk);
     if (threadIdx.x < SPANEL) qstrip[threadIdx.x] = (c0 + threadIdx.x < n) ? q[c0 + threadIdx.x] : 0.0;
 
     for (long long kb = nblk - 1; kb > sblk; --kb) {
         const long long J0 = kb * SB;
-        double2_t s0[16];
-        {
-            const long long r0 = J0 + 32 * wv;
+        double2_t sv[2][16];  // both passes' rows requested before the flag wait
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const long long r0 = J0 + 32 * wv + 16 * h;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 long long row = r0 + r;
                 if (row > n - 1) row = n - 1;
-                s0[r] = *reinterpret_cast<const double2_t*>(M + row * ld + c);
+                sv[h][r] = *reinterpret_cast<const double2_t*>(M + row * ld + c);
             }
         }
+        if (kb == sblk + 1) st_prefetch_block_bwd(M, ld, n, c0, blk);
         if (threadIdx.x == 0) ok = st_wait_flag(flags + kb, epoch) ? 1 : 0;
         __syncthreads();
         if (!ok) {
@@ -707,24 +715,11 @@ __global__ __launch_bounds__(256) void k_st_bwd_persist(const double* __restrict
         double p0 = 0.0, p1 = 0.0;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            const long long r0 = J0 + 32 * wv + 16 * h;
-            double2_t sv[16];
-            if (h == 0) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) sv[r] = s0[r];
-            } else {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    long long row = r0 + r;
-                    if (row > n - 1) row = n - 1;
-                    sv[r] = *reinterpret_cast<const double2_t*>(M + row * ld + c);
-                }
-            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const double qj = qblk[32 * wv + 16 * h + r];  // 0 for rows beyond n
-                p0 += sv[r].x * qj;
-                p1 += sv[r].y * qj;
+                p0 += sv[h][r].x * qj;
+                p1 += sv[h][r].y * qj;
             }
         }
         part[wv][2 * lane] = p0;
