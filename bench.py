@@ -100,8 +100,12 @@ def main() -> None:
     ap.add_argument("--schedule", choices=["pipelined", "two-pass"], default="pipelined",
                     help="pipelined: one pass over Q per update (shrink of cut k fused with the GEMV of cut k+1, "
                          "16*n^2 B); two-pass: GEMV pass + rank-1 pass per update (24*n^2 B). Same results.")
-    ap.add_argument("--compare-steps", type=int, default=60,
-                    help="extra timed steps with the OTHER schedule, reported alongside (0 = skip)")
+    ap.add_argument("--defer", type=int, choices=[1, 8], default=8,
+                    help="8: record cuts and apply them to Q in batches of 8 (GEMV passes are read-only, "
+                         "8*n^2*(1+1/8) B per update); 1: rewrite Q at every cut like the reference. Same results "
+                         "to the 1e-10 parity tolerance.")
+    ap.add_argument("--compare-steps", type=int, default=48,
+                    help="extra timed steps for each OTHER schedule / depth, reported alongside (0 = skip)")
     ap.add_argument("--force-sharded", action="store_true",
                     help="run the row-partitioned (multi-GPU) code path even with one rank (rehearsal)")
     args = ap.parse_args()
@@ -135,8 +139,15 @@ def main() -> None:
     K, W, P = args.steps, args.warmup, args.profile_steps
     H = args.host_path_steps if not sharded else 0
     fused = args.schedule == "pipelined" and variant == "ell"
+    depth = args.defer if variant == "ell" else 1
     C2 = args.compare_steps if variant == "ell" else 0
-    total = W + K + P + 2 * C2 + H
+    # alternatives measured after the main run, on the same handle: (schedule, depth)
+    alts = []
+    if C2 > 0:
+        for alt in (("pipelined", 8), ("pipelined", 1), ("two-pass", 8), ("two-pass", 1)):
+            if alt != (args.schedule, depth):
+                alts.append(alt)
+    total = W + K + P + 2 * C2 * len(alts) + H
     if sharded and variant != "ell":
         raise SystemExit("EllStable does not shard: replicas only (see DESIGN.md)")
     if n % world:
@@ -154,7 +165,9 @@ def main() -> None:
     else:
         from ellalgo_rs_amd.sharded import ShardedEll
         space = ShardedEll.new_with_scalar(1.0, np.zeros(n), device=local_rank)
-    nq = W + K + P + 2 * C2
+    nq = W + K + P + 2 * C2 * len(alts)
+    if variant == "ell" and depth != 1:
+        space.set_defer_depth(depth) if sharded else setattr(space, "defer_depth", depth)
     space.queue_upload(kinds[:nq], grads[:nq], b0[:nq], b1[:nq])
 
     def run(first: int, count: int, use_fused: bool = fused) -> None:
@@ -188,13 +201,15 @@ def main() -> None:
         prof = space.profile_read()
         space.profile_enable(False)
 
-    # ---- the other schedule on the same handle, for comparison (timed the same way + per-kernel events)
-    other = None
-    if C2 > 0:
-        run(W + K + P, 0)  # no-op, keeps indices explicit
+    # ---- the other schedules / depths on the same handle, for comparison (timed the same way + per-kernel events)
+    others = []
+    pos = W + K + P
+    for (alt_sched, alt_depth) in alts:
+        alt_fused = alt_sched == "pipelined"
+        space.set_defer_depth(alt_depth) if sharded else setattr(space, "defer_depth", alt_depth)
         fence()
         t2 = time.perf_counter()
-        run(W + K + P, C2, not fused)
+        run(pos, C2, alt_fused)
         fence()
         el2 = time.perf_counter() - t2
         if sharded:
@@ -202,14 +217,15 @@ def main() -> None:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el2 = float(t.item())
         space.profile_enable(True)
-        run(W + K + P + C2, C2, not fused)
+        run(pos + C2, C2, alt_fused)
         space.synchronize()
-        other = {"schedule": "two-pass" if fused else "pipelined", "steps": C2, "updates_per_s": C2 / el2,
-                 "ms_per_step": el2 / C2 * 1e3, "prof": space.profile_read()}
+        others.append({"schedule": alt_sched, "defer_depth": alt_depth, "steps": C2, "updates_per_s": C2 / el2,
+                       "ms_per_step": el2 / C2 * 1e3, "prof": space.profile_read()})
         space.profile_enable(False)
+        pos += 2 * C2
 
     status, tsqs = space.queue_results()
-    ran = W + K + P + 2 * C2
+    ran = nq
     ok = bool(np.all(status[:ran] == 0))
     if not ok:
         bad = int(np.argmax(status[:ran] != 0))
@@ -237,8 +253,20 @@ def main() -> None:
     ms_per_step = elapsed / K * 1e3
     value = K / elapsed
     # algorithmic bytes per launch of each kernel class (per GPU)
-    alg = {"gemv": 8.0 * n2w, "rank1": 16.0 * n2w, "fused": 16.0 * n2w,
+    alg = {"gemv": 8.0 * n2w, "rank1": 16.0 * n2w, "fused": 16.0 * n2w, "apply": 16.0 * n2w, "apply_gemv": 16.0 * n2w,
            "stable_fwd": 8.0 * n * n, "stable_bwd": 4.0 * n * n, "stable_factor": 12.0 * n * n}
+
+    def byte_model(sched, dep):
+        """algorithmic bytes ONE update moves per GPU-share under a schedule / depth, and its description"""
+        if dep == 1:
+            if sched == "pipelined":
+                return 16.0 * n2w, "16*n^2 B/update (rank-1 pass of cut k fused with the GEMV of cut k+1)"
+            return 24.0 * n2w, "24*n^2 B/update (GEMV pass 8 + rank-1 pass 16; SURVEY 8d)"
+        if sched == "pipelined":
+            return 9.0 * n2w, ("9*n^2 B/update (deferred shrink, depth 8: seven read-only GEMV passes of 8*n^2 + one "
+                               "apply+GEMV pass of 16*n^2 per 8 updates)")
+        return 10.0 * n2w, ("10*n^2 B/update (deferred shrink, depth 8: eight read-only GEMV passes of 8*n^2 + one "
+                            "apply pass of 16*n^2 per 8 updates)")
 
     def kernel_table(pr):
         tab = {}
@@ -253,17 +281,17 @@ def main() -> None:
         return tab
 
     per_kernel = kernel_table(prof)
-    # bytes one update moves under the schedule that was timed
+    # bytes one update moves under the schedule that was timed (each schedule has its OWN byte model;
+    # nothing is credited against the 24*n^2 two-pass model)
     if variant != "ell":
         bytes_update, model = 24.0 * n * n, "24*n^2 B per update (EllStable: fwd 8 + bwd 4 + factor 12)"
-    elif fused:
-        bytes_update, model = 16.0 * n2w, ("16*n^2 B per update per GPU-share (pipelined: the rank-1 pass of cut k and the "
-                                           "GEMV of cut k+1 share one read of Q; NOT credited against the 24*n^2 model)")
     else:
-        bytes_update, model = 24.0 * n2w, "24*n^2 B per update per GPU-share (GEMV pass 8 + rank-1 pass 16)"
+        bytes_update, model = byte_model("pipelined" if fused else "two-pass", depth)
     roofline = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None, "byte_model": model}
     if variant == "ell":
-        dom = "fused" if fused else "rank1"
+        # dominant = the kernel class with the largest total time in the profiled steps
+        cands = [k for k in per_kernel if k in alg]
+        dom = max(cands, key=lambda k: per_kernel[k]["avg_ms"] * per_kernel[k]["launches"]) if cands else None
     else:
         cands = [k for k in per_kernel if k in alg]
         dom = max(cands, key=lambda k: per_kernel[k]["avg_ms"]) if cands else None
@@ -286,11 +314,12 @@ def main() -> None:
                                 "frac": upd_gbps / HBM_PEAK_GBS}
     if "achieved" not in roofline:
         roofline.update({"kernel": "whole_update", "achieved": upd_gbps, "frac": upd_gbps / HBM_PEAK_GBS})
-    if other:
-        ob = (24.0 if other["schedule"] == "two-pass" else 16.0) * n2w
-        og = ob / (other["ms_per_step"] * 1e-3) / 1e9
-        other["whole_update"] = {"alg_bytes_per_gpu": ob, "GBps_per_gpu": og, "frac": og / HBM_PEAK_GBS}
-        other["per_kernel"] = kernel_table(other.pop("prof"))
+    for o in others:
+        ob, omodel = byte_model(o["schedule"], o["defer_depth"])
+        og = ob / (o["ms_per_step"] * 1e-3) / 1e9
+        o["byte_model"] = omodel
+        o["whole_update"] = {"alg_bytes_per_gpu": ob, "GBps_per_gpu": og, "frac": og / HBM_PEAK_GBS}
+        o["per_kernel"] = kernel_table(o.pop("prof"))
 
     out = {
         "metric": "ellipsoid updates/sec at n=%d; achieved HBM GB/s vs peak" % n,
@@ -307,12 +336,13 @@ def main() -> None:
         "data": "synthetic",
         "config": {"workload": args.workload, "n": n, "space": variant, "cuts": cutgen,
                    "schedule": ("pipelined" if fused else "two-pass") if variant == "ell" else "ellstable",
+                   "defer_depth": depth,
                    "description": desc, "partition": f"row-block x{world}" if world > 1 else "none",
                    "q_bytes_per_gpu": 8.0 * n * n / world},
         "roofline": roofline,
     }
-    if other:
-        out["other_schedule"] = other
+    if others:
+        out["other_schedules"] = others
     if host_path:
         out["host_call_path"] = host_path
     if world == 1 and not args.no_cpu_baseline:

@@ -57,8 +57,19 @@ struct DevState {
     int halted_in;          // snapshot of `halted` for kernels whose lead workgroup rewrites it
     double kappa_in;        // snapshot of kappa taken by k_scalar_dot for k_scalar_apply
     int solve_err;          // EllStable persistent solves: nonzero if a bounded flag wait timed out
-    int pad_;
+    int npend;              // deferred mode: number of rank-1 updates recorded but not yet applied to Q
 };
+
+// Deferred rank-1 updates ("lazy shrink").  Instead of rewriting Q after every cut, up to MAXPEND
+// updates are kept as pairs (c_j = sigma_j/omega_j, v_j = the gt of that cut):
+//     Q_true = Q_base - sum_j c_j v_j v_j^T
+// The GEMV of the next cut needs only Q_base*g (a READ-ONLY pass) plus O(n * pending) corrections
+//     gt = Q_base*g - sum_j (c_j (v_j.g)) v_j ,   omega = g.gt = g.(Q_base*g) - sum_j c_j (v_j.g)^2
+// and one pass applies all pending updates element by element IN ORDER, so every matrix element goes
+// through exactly the roundings of the reference's one-update-at-a-time loop (src/ell.rs:117-128).
+// Per update: 8 n^2 (1 + 1/MAXPEND) + ... bytes instead of 16 n^2 (pipelined) or 24 n^2 (two-pass).
+// Unused slots hold c_j = 0 and v_j = 0, which makes every formula above an exact no-op for them.
+constexpr int MAXPEND = 8;
 
 typedef double double2_t __attribute__((ext_vector_type(2)));
 
@@ -244,6 +255,113 @@ __global__ __launch_bounds__(256) void k_sweep(const double* Q, double* Qout, lo
     }
 }
 
+// ----------------------------------------------------------------------------- k_sweep_apply ---
+// Deferred mode: apply the MAXPEND pending rank-1 updates to the local rows in one pass (and, when GV,
+// accumulate the GEMV of the next gradient on the freshly written values).  pend: MAXPEND vectors of
+// length n (stride n); cpend: their coefficients.  Same mapping and summation shape as k_sweep.
+template <int RW, int UNR, int VEC, bool NT, bool GV>
+__global__ __launch_bounds__(256) void k_sweep_apply(const double* Q, double* Qout, long long ld, long long n,
+                                                     long long nrows, long long row0,
+                                                     const double* __restrict__ pend,
+                                                     const double* __restrict__ cpend,
+                                                     const double* __restrict__ gvec,
+                                                     double* __restrict__ gv_out,
+                                                     const DevState* __restrict__ st, int reverse) {
+    __shared__ double red[4][RW];
+    if (st->halted) return;
+    using V = typename VecT<VEC>::type;
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const long long tile = reverse ? (long long)gridDim.x - 1 - blockIdx.x : (long long)blockIdx.x;
+    const long long row_base = tile * RW;
+    if (row_base >= nrows) return;
+
+    double ratio[MAXPEND];
+#pragma unroll
+    for (int j = 0; j < MAXPEND; ++j) ratio[j] = cpend[j];
+    const double* rp[RW];
+    double* wp[RW];
+    long long grow[RW];
+    double gtr[MAXPEND][RW], rgr[MAXPEND][RW], acc[RW];
+    bool valid[RW];
+#pragma unroll
+    for (int r = 0; r < RW; ++r) {
+        long long rr = row_base + r;
+        valid[r] = rr < nrows;
+        if (!valid[r]) rr = nrows - 1;
+        rp[r] = Q + rr * ld;
+        wp[r] = Qout + rr * ld;
+        grow[r] = row0 + rr;
+        acc[r] = 0.0;
+#pragma unroll
+        for (int j = 0; j < MAXPEND; ++j) {
+            gtr[j][r] = pend[(long long)j * n + grow[r]];
+            rgr[j][r] = ratio[j] * gtr[j][r];  // r_qg of src/ell.rs:119, update j
+        }
+    }
+    constexpr long long STEP = 256 * VEC;
+    for (long long c = (long long)threadIdx.x * VEC; c < n; c += STEP * UNR) {
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const long long cc = c + u * STEP;
+            if (cc >= n) break;
+            V vj[MAXPEND];
+#pragma unroll
+            for (int j = 0; j < MAXPEND; ++j) vj[j] = *reinterpret_cast<const V*>(pend + (long long)j * n + cc);
+            V hv;
+            if (GV) hv = *reinterpret_cast<const V*>(gvec + cc);
+            V qv[RW];
+#pragma unroll
+            for (int r = 0; r < RW; ++r) qv[r] = ld_stream<NT, V>(rp[r] + cc);
+#pragma unroll
+            for (int r = 0; r < RW; ++r) {
+                V o;
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) {
+                    const long long col = cc + v;
+                    const bool lower = col <= grow[r];
+                    double x = VecT<VEC>::get(qv[r], v);
+#pragma unroll
+                    for (int j = 0; j < MAXPEND; ++j) {  // in recording order: the reference's roundings
+                        const double gc = VecT<VEC>::get(vj[j], v);
+                        const double upd = lower ? rgr[j][r] * gc : (ratio[j] * gc) * gtr[j][r];
+                        x = x - upd;
+                    }
+                    VecT<VEC>::set(o, v, x);
+                }
+                if (valid[r]) st_stream<false, V>(wp[r] + cc, o);
+                if (GV) {
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) acc[r] += VecT<VEC>::get(o, v) * VecT<VEC>::get(hv, v);
+                }
+            }
+        }
+    }
+    if (GV) {
+#pragma unroll
+        for (int r = 0; r < RW; ++r) {
+            const double s = wave_allreduce_sum(acc[r]);
+            if (lane == 0) red[wave][r] = s;
+        }
+        __syncthreads();
+        if (threadIdx.x < RW && row_base + threadIdx.x < nrows) {
+            const int r = threadIdx.x;
+            gv_out[row_base + r] = ((red[0][r] + red[1][r]) + red[2][r]) + red[3][r];
+        }
+    }
+}
+
+// After a flush: forget the pending updates (unused slots must read as exact zeros).
+__global__ __launch_bounds__(256) void k_pend_reset(double* __restrict__ pend, double* __restrict__ cpend,
+                                                    long long total, DevState* __restrict__ st) {
+    if (st->halted) return;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x)
+        pend[i] = 0.0;
+    if (blockIdx.x == 0 && threadIdx.x < MAXPEND) cpend[threadIdx.x] = 0.0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) st->npend = 0;
+}
+
 // ---------------------------------------------------------------------------------- k_scalar ---
 // The scalar stage between the two passes, spread over G workgroups (one CU moves only ~70 GB/s, and
 // the stage touches ~56 n bytes) in two launches:
@@ -352,6 +470,135 @@ __global__ __launch_bounds__(256) void k_scalar_apply(long long n, const double*
     const long long lo = (long long)blockIdx.x * m;
     const long long hi = (lo + m < n) ? lo + m : n;
     for (long long i = lo + tid; i < hi; i += 256) xc[i] = xc[i] - roo * gt[i];  // :113-115
+}
+
+// Deferred-mode scalar stage (see MAXPEND above).  y = Q_base*g comes from the GEMV pass.
+//   k_scalar_dot_def    partial[b][0] = slice of g.y ; partial[b][1+j] = slice of v_j.g
+//   k_scalar_apply_def  every workgroup: gy, d_j = v_j.g; omega = gy - sum_j c_j d_j^2; tsq, EllCalc; its slice
+//                       of gt = y - sum_j (c_j d_j) v_j is recorded as the new pending vector and applied
+//                       to xc; workgroup 0 records c = sigma/omega, bumps npend, publishes kappa / status.
+__global__ __launch_bounds__(256) void k_scalar_dot_def(long long n, const double* __restrict__ g,
+                                                        const double* __restrict__ y,
+                                                        const double* __restrict__ pend,
+                                                        double* __restrict__ partial, DevState* __restrict__ st) {
+    __shared__ double red[4][MAXPEND + 1];
+    const int tid = threadIdx.x;
+    const int halted = st->halted;
+    if (blockIdx.x == 0 && tid == 0) {
+        st->halted_in = halted;
+        st->kappa_in = st->kappa;
+    }
+    if (halted) return;
+    const long long m = scalar_slice(n);
+    const long long lo = (long long)blockIdx.x * m;
+    const long long hi = (lo + m < n) ? lo + m : n;
+    double s[MAXPEND + 1];
+#pragma unroll
+    for (int k = 0; k <= MAXPEND; ++k) s[k] = 0.0;
+    for (long long i = lo + tid; i < hi; i += 256) {
+        const double gi = g[i];
+        s[0] += gi * y[i];
+#pragma unroll
+        for (int j = 0; j < MAXPEND; ++j) s[1 + j] += pend[(long long)j * n + i] * gi;
+    }
+#pragma unroll
+    for (int k = 0; k <= MAXPEND; ++k) {
+        const double w = wave_allreduce_sum(s[k]);
+        if ((tid & 63) == 0) red[tid >> 6][k] = w;
+    }
+    __syncthreads();
+    if (tid <= MAXPEND)
+        partial[(long long)blockIdx.x * (MAXPEND + 1) + tid] = ((red[0][tid] + red[1][tid]) + red[2][tid]) + red[3][tid];
+}
+
+__global__ __launch_bounds__(256) void k_scalar_apply_def(long long n, const double* __restrict__ y,
+                                                          double* __restrict__ xc, double* __restrict__ pend,
+                                                          double* __restrict__ cpend,
+                                                          const double* __restrict__ partial,
+                                                          DevState* __restrict__ st, EllCalcDev calc,
+                                                          const CutParams* __restrict__ cp_dev, CutParams cp_val,
+                                                          int slot, int queue_mode, int* __restrict__ q_status,
+                                                          double* __restrict__ q_tsq) {
+    // `slot` = number of updates already pending = index of the (all-zero) slot this cut records into.
+    // The host passes it: it equals the device's count as long as the queue has not halted, and a halted
+    // queue ignores every later launch.
+    __shared__ double bc_roo;
+    __shared__ double bc_cd[MAXPEND];
+    __shared__ int bc_status;
+    const int tid = threadIdx.x;
+    const bool lead = blockIdx.x == 0;
+    if (st->halted_in) {
+        if (lead && tid == 0 && q_status) {
+            *q_status = ST_UNKNOWN;
+            *q_tsq = st->tsq;
+        }
+        return;
+    }
+    if (tid == 0) {
+        const int G = scalar_groups(n);
+        double d[MAXPEND + 1];
+#pragma unroll
+        for (int k = 0; k <= MAXPEND; ++k) d[k] = 0.0;
+        for (int b = 0; b < G; ++b)
+#pragma unroll
+            for (int k = 0; k <= MAXPEND; ++k) d[k] += partial[(long long)b * (MAXPEND + 1) + k];
+        double omega = d[0];  // g.(Q_base g)
+#pragma unroll
+        for (int j = 0; j < MAXPEND; ++j) {
+            // slot `slot` is being written by the lead workgroup in this very launch: it is empty by
+            // definition, so it is not read
+            const double cd = (j == slot) ? 0.0 : cpend[j] * d[1 + j];  // c_j (v_j.g)
+            bc_cd[j] = cd;
+            omega = omega - cd * d[1 + j];
+        }
+        const double kappa = st->kappa_in;
+        const double tsq = kappa * omega;  // src/ell.rs:105
+        Coef cf;
+        const CutParams cp = cp_dev ? *cp_dev : cp_val;
+        const int status = calc.dispatch(cp.kind, cp.b0, cp.has_b1, cp.b1, tsq, cf);  // :106
+        double roo = 0.0;
+        if (status == ST_SUCCESS) roo = cf.rho / omega;  // :112
+        if (lead) {
+            st->tsq = tsq;
+            st->omega = omega;
+            st->status = status;
+            if (status == ST_SUCCESS) {
+                st->rho_over_omega = roo;
+                st->ratio = cf.sigma / omega;   // :117
+                st->kappa = kappa * cf.delta;   // :130 (deferred mode never runs with no_defer_trick)
+                st->scale = 1.0;
+                st->apply = 1;
+                cpend[slot] = cf.sigma / omega;
+                st->npend = slot + 1;
+            } else {
+                st->apply = 0;  // :107-109
+                if (queue_mode) st->halted = 1;
+            }
+            if (q_status) {
+                *q_status = status;
+                *q_tsq = tsq;
+            }
+        }
+        bc_roo = roo;
+        bc_status = status;
+    }
+    __syncthreads();
+    if (bc_status != ST_SUCCESS) return;
+    const double roo = bc_roo;
+    double cd[MAXPEND];
+#pragma unroll
+    for (int j = 0; j < MAXPEND; ++j) cd[j] = bc_cd[j];
+    double* vnew = pend + (long long)slot * n;
+    const long long m = scalar_slice(n);
+    const long long lo = (long long)blockIdx.x * m;
+    const long long hi = (lo + m < n) ? lo + m : n;
+    for (long long i = lo + tid; i < hi; i += 256) {
+        double gt = y[i];
+#pragma unroll
+        for (int j = 0; j < MAXPEND; ++j) gt = gt - cd[j] * pend[(long long)j * n + i];
+        vnew[i] = gt;                    // slot `slot` was all zeros until now: its own term above was an exact 0
+        xc[i] = xc[i] - roo * gt;        // :113-115
+    }
 }
 
 constexpr long long SCALAR_SPLIT_N = 8192;

@@ -57,7 +57,7 @@ int env_int(const char* name, int dflt) {
     return (s && *s) ? atoi(s) : dflt;
 }
 
-enum : int { CLS_GEMV = 0, CLS_SCALAR = 1, CLS_RANK1 = 2, CLS_ST_FWD = 3, CLS_ST_BWD = 4, CLS_ST_FACTOR = 5, CLS_FUSED = 6 };
+enum : int { CLS_GEMV = 0, CLS_SCALAR = 1, CLS_RANK1 = 2, CLS_ST_FWD = 3, CLS_ST_BWD = 4, CLS_ST_FACTOR = 5, CLS_FUSED = 6, CLS_APPLY = 7, CLS_APPLY_GEMV = 8 };
 
 struct Shape {
     int rw = 0, unr = 0, nt = 0;
@@ -78,6 +78,10 @@ struct ellhip_space {
     double* d_gt[2] = {nullptr, nullptr};      // buffers in use (own or caller's)
     double* d_work = nullptr;        // EllStable vectors: w, z, gg, q, beta2
     double* d_partial = nullptr;     // per-workgroup partial sums of omega (64)
+    double* d_pend = nullptr;        // deferred mode: MAXPEND pending gt vectors (n each)
+    double* d_cpend = nullptr;       // deferred mode: their coefficients sigma/omega
+    int defer = 1;                   // 1 = shrink Q at every cut; MAXPEND = record and apply in batches
+    int npend = 0;                   // updates recorded since the last flush (host view, optimistic in queue mode)
     int* d_flags = nullptr;          // EllStable persistent solves: block-ready flags (forward | backward)
     int epoch = 0;                   // hand-off epoch, bumped per persistent launch
     int stable_persist = 1;          // one-launch flag-chained solves (0: one launch per block)
@@ -124,7 +128,7 @@ struct ellhip_space {
     long long prof_cnt[ELLHIP_NKERNEL_CLASSES] = {0};
 
     // launch shapes per role (tunable through the environment for experiments)
-    Shape sh_gemv, sh_rank1, sh_fused;
+    Shape sh_gemv, sh_rank1, sh_fused, sh_apply;
 };
 
 namespace {
@@ -202,6 +206,10 @@ void pick_shape(ellhip_space* s) {
         s->sh_rank1 = {2, 8, 1};
         s->sh_fused = {2, 8, 1};
     }
+    s->sh_apply = {2, 2, s->sh_fused.nt};
+    s->sh_apply.rw = env_int("ELLHIP_APPLY_RW", s->sh_apply.rw);
+    s->sh_apply.unr = env_int("ELLHIP_APPLY_UNR", s->sh_apply.unr);
+    s->sh_apply.nt = env_int("ELLHIP_APPLY_NT", s->sh_apply.nt);
     s->sh_gemv.rw = env_int("ELLHIP_GEMV_RW", s->sh_gemv.rw);
     s->sh_gemv.unr = env_int("ELLHIP_GEMV_UNR", s->sh_gemv.unr);
     s->sh_gemv.nt = env_int("ELLHIP_GEMV_NT", s->sh_gemv.nt);
@@ -251,6 +259,55 @@ int launch_sweep(ellhip_space* s, const Shape& sh, const double* gt_r1, const do
     if (rc) return rc;
     HIPCHK(hipGetLastError());
     s->dir ^= 1;  // the next pass over Q runs the other way
+    return 0;
+}
+
+// Deferred mode is in force for Ell with depth > 1, except while the reference semantics need Q itself
+// to be rewritten at once (no_defer_trick scaling; the one-off mirror of a non-symmetric input).
+bool deferring(const ellhip_space* s) {
+    return s->variant == ELLHIP_SPACE_ELL && s->defer > 1 && !s->no_defer_trick && !s->needs_mirror;
+}
+
+template <int VEC, bool NT, bool GV>
+int launch_apply_t(ellhip_space* s, const double* gvec, double* gv_out) {
+    const Shape& sh = s->sh_apply;
+    const long long nr = s->nrows;
+    const unsigned grid = (unsigned)((nr + sh.rw - 1) / sh.rw);
+    double* out = gv_out ? gv_out + s->row0 : nullptr;
+#define APPLY_CASE(RW, UNR)                                                                                   \
+    if (sh.rw == RW && sh.unr == UNR) {                                                                       \
+        hipLaunchKernelGGL((k_sweep_apply<RW, UNR, VEC, NT, GV>), dim3(grid), dim3(256), 0, s->stream,        \
+                           (const double*)s->d_Q, s->d_Q, s->ld, s->n, nr, s->row0, (const double*)s->d_pend, \
+                           (const double*)s->d_cpend, gvec, out, s->d_st, s->dir);                            \
+        return 0;                                                                                             \
+    }
+    APPLY_CASE(1, 2) APPLY_CASE(1, 4) APPLY_CASE(2, 1) APPLY_CASE(2, 2) APPLY_CASE(2, 4) APPLY_CASE(4, 1) APPLY_CASE(4, 2)
+#undef APPLY_CASE
+    return fail(ELLHIP_E_INVALID, "unsupported ELLHIP_APPLY_RW/UNR shape (supported: 1x2 1x4 2x1 2x2 2x4 4x1 4x2)");
+}
+
+// Apply every pending update to Q (one pass), optionally fused with the GEMV of `gvec`; then clear the slots.
+int flush_pending(ellhip_space* s, const double* gvec, double* gv_out) {
+    {
+        ProfScope ps(s, gvec ? CLS_APPLY_GEMV : CLS_APPLY);
+        const bool even = (s->n % 2) == 0;
+        const bool nt = even && s->sh_apply.nt;
+        int rc;
+        if (gvec)
+            rc = !even ? launch_apply_t<1, false, true>(s, gvec, gv_out)
+                       : (nt ? launch_apply_t<2, true, true>(s, gvec, gv_out) : launch_apply_t<2, false, true>(s, gvec, gv_out));
+        else
+            rc = !even ? launch_apply_t<1, false, false>(s, nullptr, nullptr)
+                       : (nt ? launch_apply_t<2, true, false>(s, nullptr, nullptr)
+                             : launch_apply_t<2, false, false>(s, nullptr, nullptr));
+        if (rc) return rc;
+        HIPCHK(hipGetLastError());
+        s->dir ^= 1;
+    }
+    hipLaunchKernelGGL(k_pend_reset, dim3(64), dim3(256), 0, s->stream, s->d_pend, s->d_cpend,
+                       (long long)MAXPEND * s->n, s->d_st);
+    HIPCHK(hipGetLastError());
+    s->npend = 0;
     return 0;
 }
 
@@ -359,6 +416,18 @@ int do_cut(ellhip_space* s, const double* g_dev, const CutParams* cp_dev, CutPar
     EllCalcDev calc = EllCalcDev::make(s->n, s->use_parallel_cut);
     const unsigned G = (unsigned)scalar_groups(s->n);
     const double* gt = s->d_gt[s->cur];
+    if (deferring(s)) {
+        // gt currently holds y = Q_base * g; the stage corrects it with the pending updates and records the
+        // cut as pending update number s->npend (optimistically counted; see ellhip_queue_results / callers)
+        hipLaunchKernelGGL(k_scalar_dot_def, dim3(G), dim3(256), 0, s->stream, s->n, g_dev, gt,
+                           (const double*)s->d_pend, s->d_partial, s->d_st);
+        hipLaunchKernelGGL(k_scalar_apply_def, dim3(G), dim3(256), 0, s->stream, s->n, gt, s->d_xc, s->d_pend,
+                           s->d_cpend, (const double*)s->d_partial, s->d_st, calc, cp_dev, cp_val, s->npend, queue_mode,
+                           qst, qtsq);
+        HIPCHK(hipGetLastError());
+        s->npend += 1;
+        return 0;
+    }
     if (s->n < SCALAR_SPLIT_N) {
         hipLaunchKernelGGL(k_scalar, dim3(1), dim3(1024), 0, s->stream, s->n, g_dev, gt, s->d_xc, s->d_st, calc,
                            cp_dev, cp_val, s->no_defer_trick, queue_mode, qst, qtsq);
@@ -377,6 +446,13 @@ int do_cut(ellhip_space* s, const double* g_dev, const CutParams* cp_dev, CutPar
 // the GEMV pass of `gnext_dev` (into the other slot) when that is given.
 int do_commit(ellhip_space* s, bool shrink, const double* gnext_dev) {
     if (s->variant != ELLHIP_SPACE_ELL) return 0;
+    if (deferring(s)) {
+        // nothing to shrink now: the cut was recorded.  When the slots are full, one pass applies them all
+        // (and carries the next GEMV); otherwise the next gradient only needs a read-only pass.
+        if (s->npend >= MAXPEND) return flush_pending(s, gnext_dev, gnext_dev ? s->d_gt[s->cur ^ 1] : nullptr);
+        if (gnext_dev) return do_prime(s, gnext_dev, s->cur ^ 1);
+        return 0;
+    }
     if (shrink) {
         int rc = launch_mirror_if_needed(s);
         if (rc) return rc;
@@ -433,6 +509,14 @@ int ensure_committed(ellhip_space* s) {
     return 0;
 }
 
+// For observers of Q itself (get_mq, clone, mode switches): also apply what deferred mode has recorded.
+int make_q_current(ellhip_space* s) {
+    int rc = ensure_committed(s);
+    if (rc) return rc;
+    if (s->npend > 0) return flush_pending(s, nullptr, nullptr);
+    return 0;
+}
+
 void drop_prime(ellhip_space* s) {
     s->primed = false;
     s->g_cur = nullptr;
@@ -454,7 +538,13 @@ int alloc_common(ellhip_space* s) {
         HIPCHK(hipMemsetAsync(s->d_gt_own[k], 0, vbytes, s->stream));
     }
     HIPCHK(hipMalloc(&s->d_st, sizeof(DevState)));
-    HIPCHK(hipMalloc(&s->d_partial, 64 * sizeof(double)));
+    HIPCHK(hipMalloc(&s->d_partial, 64 * (MAXPEND + 1) * sizeof(double)));
+    if (s->variant == ELLHIP_SPACE_ELL) {
+        HIPCHK(hipMalloc(&s->d_pend, (size_t)MAXPEND * vbytes));
+        HIPCHK(hipMalloc(&s->d_cpend, MAXPEND * sizeof(double)));
+        HIPCHK(hipMemsetAsync(s->d_pend, 0, (size_t)MAXPEND * vbytes, s->stream));
+        HIPCHK(hipMemsetAsync(s->d_cpend, 0, MAXPEND * sizeof(double), s->stream));
+    }
     if (s->variant == ELLHIP_SPACE_ELL_STABLE) {
         HIPCHK(hipMalloc(&s->d_flags, 512 * sizeof(int)));
         HIPCHK(hipMemsetAsync(s->d_flags, 0, 512 * sizeof(int), s->stream));
@@ -682,6 +772,8 @@ void ellhip_destroy(ellhip_space* s) {
     }
     if (s->d_work) (void)hipFree(s->d_work);
     if (s->d_partial) (void)hipFree(s->d_partial);
+    if (s->d_pend) (void)hipFree(s->d_pend);
+    if (s->d_cpend) (void)hipFree(s->d_cpend);
     if (s->d_flags) (void)hipFree(s->d_flags);
     if (s->d_st) (void)hipFree(s->d_st);
     if (s->h_result) (void)hipHostFree(s->h_result);
@@ -698,7 +790,7 @@ int ellhip_clone(const ellhip_space* src_c, ellhip_space** out) {
     *out = nullptr;
     ellhip_space* src = const_cast<ellhip_space*>(src_c);  // committing a pending shrink is not observable
     DeviceGuard guard(src->device);
-    int rc = ensure_committed(src);
+    int rc = make_q_current(src);
     if (rc) return rc;
     ellhip_space* s = new (std::nothrow) ellhip_space();
     if (!s) return fail(ELLHIP_E_NOMEM, "host allocation failed");
@@ -717,6 +809,8 @@ int ellhip_clone(const ellhip_space* src_c, ellhip_space** out) {
     s->sh_gemv = src->sh_gemv;
     s->sh_rank1 = src->sh_rank1;
     s->sh_fused = src->sh_fused;
+    s->sh_apply = src->sh_apply;
+    s->defer = src->defer;
     rc = alloc_common(s);
     if (rc) {
         ellhip_destroy(s);
@@ -772,7 +866,8 @@ int ellhip_cut(ellhip_space* s, int kind, double beta0, int has_beta1, double be
     rc = read_back(s);
     if (rc) return rc;
     const int status = s->h_result->status;
-    s->shrink_pending = (status == ELLHIP_SUCCESS) && s->variant == ELLHIP_SPACE_ELL;
+    s->npend = s->h_result->npend;  // deferred mode: a failed cut records nothing
+    s->shrink_pending = (status == ELLHIP_SUCCESS) && s->variant == ELLHIP_SPACE_ELL && !deferring(s);
     s->primed = false;  // the gradient has been consumed; gt[cur] stays valid for the pending shrink
     return status;
 }
@@ -833,6 +928,8 @@ int ellhip_update_end(ellhip_space* s) {
     rc = read_back(s);
     if (rc) return rc;
     const int status = s->h_result->status;
+    if (s->variant == ELLHIP_SPACE_ELL && s->npend > 0 && status != ELLHIP_SUCCESS && s->h_result->npend < s->npend)
+        s->npend = s->h_result->npend;  // deferred mode: the failed cut recorded nothing
     if (status == ELLHIP_SUCCESS) s->needs_mirror = false;
     return status;
 }
@@ -871,7 +968,7 @@ int ellhip_get_mq(const ellhip_space* s_c, double* mq_out) {
     if (!s_c || !mq_out) return fail(ELLHIP_E_INVALID, "NULL argument");
     ellhip_space* s = const_cast<ellhip_space*>(s_c);
     DeviceGuard guard(s->device);
-    int rc = ensure_committed(s);
+    int rc = make_q_current(s);
     if (rc) return rc;
     HIPCHK(hipMemcpy2DAsync(mq_out, (size_t)s->n * sizeof(double), s->d_Q, (size_t)s->ld * sizeof(double),
                             (size_t)s->n * sizeof(double), (size_t)s->nrows, hipMemcpyDeviceToHost, s->stream));
@@ -882,9 +979,25 @@ int ellhip_get_mq(const ellhip_space* s_c, double* mq_out) {
 int ellhip_set_no_defer_trick(ellhip_space* s, int flag) {
     if (!s) return fail(ELLHIP_E_INVALID, "NULL handle");
     if (s->variant != ELLHIP_SPACE_ELL) return fail(ELLHIP_E_INVALID, "no_defer_trick exists on Ell only");
+    DeviceGuard guard(s->device);
+    int rc = make_q_current(s);  // recorded updates belong to the old mode
+    if (rc) return rc;
     s->no_defer_trick = flag ? 1 : 0;
     return 0;
 }
+
+int ellhip_set_defer_depth(ellhip_space* s, int depth) {
+    if (!s) return fail(ELLHIP_E_INVALID, "NULL handle");
+    if (s->variant != ELLHIP_SPACE_ELL) return fail(ELLHIP_E_INVALID, "deferred shrink exists on Ell only");
+    if (depth != 1 && depth != MAXPEND) return fail(ELLHIP_E_INVALID, "defer depth must be 1 or 8");
+    DeviceGuard guard(s->device);
+    int rc = make_q_current(s);
+    if (rc) return rc;
+    s->defer = depth;
+    return 0;
+}
+
+int ellhip_defer_depth(const ellhip_space* s) { return s ? s->defer : 0; }
 
 int ellhip_set_use_parallel_cut(ellhip_space* s, int flag) {
     if (!s) return fail(ELLHIP_E_INVALID, "NULL handle");
@@ -1017,6 +1130,7 @@ int ellhip_queue_results(ellhip_space* s, int32_t* status_out, double* tsq_out) 
     DeviceGuard guard(s->device);
     int rc = read_back(s);
     if (rc) return rc;
+    if (s->variant == ELLHIP_SPACE_ELL && s->h_result->halted) s->npend = s->h_result->npend;
     std::vector<int32_t> st((size_t)s->qk);
     HIPCHK(hipMemcpy(st.data(), s->d_qstatus, (size_t)s->qk * sizeof(int), hipMemcpyDeviceToHost));
     if (status_out) memcpy(status_out, st.data(), (size_t)s->qk * sizeof(int));

@@ -228,6 +228,15 @@ class Ell(_SpaceBase):
         capi.check(self._lib.ellhip_set_no_defer_trick(self._h, int(flag)))
         self._ndt = bool(flag)
 
+    @property
+    def defer_depth(self) -> int:
+        """1 = shrink Q at every cut (reference data flow); 8 = record cuts and apply them in batches."""
+        return self._lib.ellhip_defer_depth(self._h)
+
+    @defer_depth.setter
+    def defer_depth(self, depth: int) -> None:
+        capi.check(self._lib.ellhip_set_defer_depth(self._h, int(depth)), "ellhip_set_defer_depth")
+
     def clone(self):
         c = super().clone()
         c._ndt = self.no_defer_trick

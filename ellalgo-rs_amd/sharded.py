@@ -79,6 +79,9 @@ class HipShardEngine:
     def end(self) -> int:
         return capi.check(self._lib.ellhip_update_end(self.h), "ellhip_update_end")
 
+    def set_defer_depth(self, depth):
+        capi.check(self._lib.ellhip_set_defer_depth(self.h, int(depth)), "ellhip_set_defer_depth")
+
     def queue_upload(self, k, kinds, grads, b0, has1, b1):
         capi.check(self._lib.ellhip_queue_upload(self.h, k, _p(kinds), _p(grads), _p(b0), _p(has1), _p(b1)),
                    "ellhip_queue_upload")
@@ -220,6 +223,10 @@ class ShardedEll:
     def mq_rows(self) -> np.ndarray:
         """This rank's row block of Q."""
         return self.engine.mq_rows()
+
+    def set_defer_depth(self, depth: int) -> None:
+        """See ellhip_set_defer_depth: 1 = immediate shrink, 8 = recorded and applied in batches."""
+        self.engine.set_defer_depth(depth)
 
     # ---- device-resident cut queue (every rank uploads the same cuts)
     def queue_upload(self, kinds, grads, beta0, beta1=None) -> int:

@@ -153,6 +153,20 @@ int ellhip_prime(ellhip_space *s, const double *grad);
 int ellhip_cut(ellhip_space *s, int kind, double beta0, int has_beta1, double beta1);
 int ellhip_commit(ellhip_space *s, const double *next_grad);
 
+/* ---- deferred shrink: 8 n^2 (1 + 1/8) bytes per update (Ell) -----------------------------------
+ * depth = 1 (default): Q is rewritten at every successful cut, exactly as src/ell.rs:117-128 does.
+ * depth = 8: successful cuts are RECORDED as pairs (sigma/omega, gt); the next GEMV reads the unchanged
+ * matrix (a read-only pass) and is corrected with the recorded pairs,
+ *     gt = Q_base*g - sum_j c_j (v_j.g) v_j ,   omega = g.(Q_base*g) - sum_j c_j (v_j.g)^2 ,
+ * and every 8th cut one pass applies the 8 recorded updates element by element in order, i.e. with the
+ * same sequence of roundings per element as the reference loop.  xc, kappa, tsq and status are always
+ * current; Q is made current before ellhip_get_mq / ellhip_clone return.  Results stay within the
+ * 1e-10 parity tolerance of depth 1 (gt is the same vector computed in a different order); they are
+ * bit-identical across schedules, row partitions and GPU counts for a given depth.  Not used while
+ * no_defer_trick is set or before a non-symmetric input matrix has been mirrored.  Ell only. */
+int ellhip_set_defer_depth(ellhip_space *s, int depth);
+int ellhip_defer_depth(const ellhip_space *s);
+
 /* ---- device-resident cut queue (benchmarks, replay of recorded cut sequences) ---------------
  * Uploads k cuts once; run/begin/end then execute them without touching host memory, stopping
  * (all later cuts become no-ops with status ELLHIP_UNKNOWN) at the first non-Success one, like the
@@ -184,8 +198,9 @@ int ellhip_synchronize(ellhip_space *s);
  * launch stream.  ellhip_profile_read waits for them and returns accumulated milliseconds and
  * launch counts per kernel class, then resets.  Classes: 0 = GEMV pass (Q*g), 1 = scalar stage,
  * 2 = rank-1 pass, 3 = EllStable forward, 4 = EllStable backward, 5 = EllStable factor update,
- * 6 = fused pass (rank-1 of cut k + GEMV of cut k+1). */
-#define ELLHIP_NKERNEL_CLASSES 7
+ * 6 = fused pass (rank-1 of cut k + GEMV of cut k+1), 7 = deferred apply pass (8 recorded updates),
+ * 8 = deferred apply pass fused with the next GEMV. */
+#define ELLHIP_NKERNEL_CLASSES 9
 int ellhip_profile_enable(ellhip_space *s, int flag);
 int ellhip_profile_read(ellhip_space *s, double *ms_out, int64_t *count_out);
 

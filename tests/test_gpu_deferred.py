@@ -1,0 +1,162 @@
+"""GPU: deferred shrink (ellhip_set_defer_depth(8)): cuts are recorded as (sigma/omega, gt) pairs, GEMVs are
+corrected with the recorded pairs, one pass applies 8 of them.  Must stay within the 1e-10 parity
+tolerance of the CPU oracle, and be bit-identical across schedules and row partitions for that depth."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from util import assert_state_close, run_mixed
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("n", [2, 3, 5, 16, 64, 127, 130, 257, 1000, 1024, 2048])
+def test_deferred_mixed_sequence_matches_oracle(gpu, orc, n):
+    xc0 = np.linspace(-1.0, 1.0, n)
+    g = gpu.Ell.new_with_scalar(2.0, xc0)
+    g.defer_depth = 8
+    assert g.defer_depth == 8
+    o = orc.OracleEll.new_with_scalar(2.0, xc0)
+    nsucc = run_mixed(g, o, 52, seed=500 + n, check_every=5)   # 5 is coprime to 8: get_mq flushes at every phase
+    assert nsucc >= 26
+    assert_state_close(g, o, what=f"deferred n={n}")
+
+
+@pytest.mark.parametrize("n", [4096, 8192])
+def test_deferred_deep_cuts_large(gpu, orc, n):
+    from ellalgo_rs_amd import synth
+    k = 11
+    kinds, grads, b0, _ = synth.deep_cuts(n, k)
+    g = gpu.Ell.new_with_scalar(1.0, np.zeros(n))
+    g.defer_depth = 8
+    o = orc.OracleEll.new_with_scalar(1.0, np.zeros(n))
+    for i in range(k):
+        assert int(g.update_bias_cut((grads[i], float(b0[i])))) == o.update(0, grads[i], b0[i]) == 0
+        assert abs(g.tsq() - o.tsq) <= 1e-10 * abs(o.tsq)
+    assert_state_close(g, o, what=f"deferred n={n}")
+
+
+def test_deferred_all_schedules_bit_identical(gpu):
+    """direct updates == two-pass queue == pipelined queue == prime/cut/commit, for depth 8."""
+    from ellalgo_rs_amd import synth
+    n, k = 640, 21
+    kinds, grads, b0, b1 = synth.parallel_cuts(n, k)
+    spaces = [gpu.Ell.new_with_scalar(1.0, np.zeros(n)) for _ in range(4)]
+    for s in spaces:
+        s.defer_depth = 8
+    a, b, c, d = spaces
+    for i in range(k):
+        assert int(a._update(int(kinds[i]), (grads[i], (b0[i], b1[i])))) == 0
+    b.queue_upload(kinds, grads, b0, b1)
+    b.queue_run(0, k)
+    c.queue_upload(kinds, grads, b0, b1)
+    c.queue_run(0, 5, fused=True)
+    c.queue_run(5, k - 5, fused=True)
+    d.prime(grads[0])
+    for i in range(k):
+        assert int(d.cut(int(kinds[i]), (b0[i], b1[i]))) == 0
+        d.commit(grads[i + 1] if i + 1 < k else None)
+    sb, tb = b.queue_results()
+    sc, tc = c.queue_results()
+    assert np.all(sb == 0) and np.array_equal(sb, sc) and np.array_equal(tb, tc)
+    qa = a.mq
+    for s in (b, c, d):
+        assert s.kappa == a.kappa and s.tsq() == a.tsq()
+        assert np.array_equal(s.xc(), a.xc())
+        assert np.array_equal(s.mq, qa)
+    assert np.array_equal(qa, qa.T)
+
+
+def test_deferred_failed_cuts_record_nothing(gpu, orc):
+    n = 48
+    rng = np.random.default_rng(21)
+    g = gpu.Ell.new_with_scalar(1.0, np.zeros(n))
+    g.defer_depth = 8
+    o = orc.OracleEll.new_with_scalar(1.0, np.zeros(n))
+    for i in range(30):
+        gr = rng.standard_normal(n)
+        beta = 1e6 if i % 4 == 3 else 0.01     # every 4th cut fails
+        assert int(g.update_bias_cut((gr, beta))) == o.update(0, gr, beta)
+    assert_state_close(g, o, what="deferred with failures")
+
+
+def test_deferred_queue_halts_and_recovers(gpu, orc):
+    n, k = 64, 14
+    rng = np.random.default_rng(22)
+    grads = rng.standard_normal((k, n))
+    kinds = np.zeros(k, dtype=np.int32)
+    b0 = np.full(k, 0.01)
+    b0[10] = 1e9
+    g = gpu.Ell.new_with_scalar(1.0, np.zeros(n))
+    g.defer_depth = 8
+    o = orc.OracleEll.new_with_scalar(1.0, np.zeros(n))
+    g.queue_upload(kinds, grads, b0)
+    g.queue_run(0, k, fused=True)
+    st, _ = g.queue_results()
+    assert list(st) == [0] * 10 + [1] + [3] * 3
+    for i in range(10):
+        o.update(0, grads[i], b0[i])
+    o.update(0, grads[10], b0[10])
+    assert_state_close(g, o, what="after halt")
+    assert int(g.update_bias_cut((grads[11], 0.01))) == o.update(0, grads[11], 0.01) == 0
+    assert_state_close(g, o, what="after recovery")
+
+
+def test_deferred_clone_and_mode_switches(gpu, orc):
+    n = 80
+    rng = np.random.default_rng(23)
+    g = gpu.Ell.new_with_scalar(1.0, np.zeros(n))
+    g.defer_depth = 8
+    o = orc.OracleEll.new_with_scalar(1.0, np.zeros(n))
+    for i in range(5):
+        gr = rng.standard_normal(n)
+        g.update_bias_cut((gr, 0.01)), o.update(0, gr, 0.01)
+    c = g.clone()                      # flushes the source, copies the depth
+    assert c.defer_depth == 8
+    assert_state_close(c, o, what="clone")
+    g.defer_depth = 1                  # back to the immediate data flow
+    g.no_defer_trick = True
+    o.set_no_defer_trick(True)
+    for i in range(3):
+        gr = rng.standard_normal(n)
+        g.update_central_cut((gr, 0.0)), o.update(1, gr, 0.0)
+    assert_state_close(g, o, what="after mode switches")
+
+
+def test_deferred_row_shards_bit_identical_to_unsharded(gpu):
+    pkg = gpu
+    L = pkg.capi.load()
+    n, half = 256, 128
+    rng = np.random.default_rng(9)
+    ref = pkg.Ell.new_with_scalar(1.5, np.zeros(n))
+    ref.defer_depth = 8
+    hs = []
+    for r in range(2):
+        h = C.c_void_p()
+        pkg.capi.check(L.ellhip_create_shard(C.byref(h), n, r * half, half, 1.5, None, None, None, -1))
+        pkg.capi.check(L.ellhip_set_defer_depth(h, 8))
+        hs.append(h)
+    pkg.capi.check(L.ellhip_set_gt_dev(hs[1], L.ellhip_gt_dev(hs[0]), None))
+    try:
+        for i in range(19):
+            g = np.ascontiguousarray(rng.standard_normal(n))
+            gp = g.ctypes.data_as(C.c_void_p)
+            for h in hs:
+                pkg.capi.check(L.ellhip_update_begin(h, 0, gp, 0.02, 0, 0.0))
+            for h in hs:
+                pkg.capi.check(L.ellhip_synchronize(h))
+            assert [pkg.capi.check(L.ellhip_update_end(h)) for h in hs] == [0, 0]
+            assert int(ref.update_bias_cut((g, 0.02))) == 0
+        q = np.empty((n, n))
+        for r, h in enumerate(hs):
+            blk = np.empty((half, n))
+            pkg.capi.check(L.ellhip_get_mq(h, blk.ctypes.data_as(C.c_void_p)))
+            q[r * half:(r + 1) * half] = blk
+            x = np.empty(n)
+            pkg.capi.check(L.ellhip_get_xc(h, x.ctypes.data_as(C.c_void_p)))
+            assert np.array_equal(x, ref.xc()) and L.ellhip_kappa(h) == ref.kappa
+        assert np.array_equal(q, ref.mq)
+    finally:
+        for h in hs:
+            L.ellhip_destroy(h)
