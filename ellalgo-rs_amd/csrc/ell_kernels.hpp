@@ -299,6 +299,8 @@ __global__ __launch_bounds__(256) void k_sweep_apply(const double* Q, double* Qo
             rgr[j][r] = ratio[j] * gtr[j][r];  // r_qg of src/ell.rs:119, update j
         }
     }
+    const long long grow_min = row0 + row_base;           // rows of this tile: grow_min .. grow_max
+    const long long grow_max = grow[RW - 1];
     constexpr long long STEP = 256 * VEC;
     for (long long c = (long long)threadIdx.x * VEC; c < n; c += STEP * UNR) {
 #pragma unroll
@@ -313,26 +315,58 @@ __global__ __launch_bounds__(256) void k_sweep_apply(const double* Q, double* Qo
             V qv[RW];
 #pragma unroll
             for (int r = 0; r < RW; ++r) qv[r] = ld_stream<NT, V>(rp[r] + cc);
+            // Which triangle the thread's VEC columns lie in, for ALL rows of the tile: away from the
+            // diagonal (almost everywhere) the per-element select and the unused product disappear.
+            const bool all_lower = cc + VEC - 1 <= grow_min;  // col <= row for every (row, col) here
+            const bool all_upper = cc > grow_max;             // col >  row for every (row, col) here
+            V o[RW];
+            if (all_lower) {
+#pragma unroll
+                for (int r = 0; r < RW; ++r)
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) {
+                        double x = VecT<VEC>::get(qv[r], v);
+#pragma unroll
+                        for (int j = 0; j < MAXPEND; ++j) x = x - rgr[j][r] * VecT<VEC>::get(vj[j], v);
+                        VecT<VEC>::set(o[r], v, x);
+                    }
+            } else if (all_upper) {
+                V rv[MAXPEND];  // (ratio_j * gt_j[col]): the mirrored element's r_qg
+#pragma unroll
+                for (int j = 0; j < MAXPEND; ++j)
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) VecT<VEC>::set(rv[j], v, ratio[j] * VecT<VEC>::get(vj[j], v));
+#pragma unroll
+                for (int r = 0; r < RW; ++r)
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) {
+                        double x = VecT<VEC>::get(qv[r], v);
+#pragma unroll
+                        for (int j = 0; j < MAXPEND; ++j) x = x - VecT<VEC>::get(rv[j], v) * gtr[j][r];
+                        VecT<VEC>::set(o[r], v, x);
+                    }
+            } else {
+#pragma unroll
+                for (int r = 0; r < RW; ++r)
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) {
+                        const bool lower = cc + v <= grow[r];
+                        double x = VecT<VEC>::get(qv[r], v);
+#pragma unroll
+                        for (int j = 0; j < MAXPEND; ++j) {  // in recording order: the reference's roundings
+                            const double gc = VecT<VEC>::get(vj[j], v);
+                            const double upd = lower ? rgr[j][r] * gc : (ratio[j] * gc) * gtr[j][r];
+                            x = x - upd;
+                        }
+                        VecT<VEC>::set(o[r], v, x);
+                    }
+            }
 #pragma unroll
             for (int r = 0; r < RW; ++r) {
-                V o;
-#pragma unroll
-                for (int v = 0; v < VEC; ++v) {
-                    const long long col = cc + v;
-                    const bool lower = col <= grow[r];
-                    double x = VecT<VEC>::get(qv[r], v);
-#pragma unroll
-                    for (int j = 0; j < MAXPEND; ++j) {  // in recording order: the reference's roundings
-                        const double gc = VecT<VEC>::get(vj[j], v);
-                        const double upd = lower ? rgr[j][r] * gc : (ratio[j] * gc) * gtr[j][r];
-                        x = x - upd;
-                    }
-                    VecT<VEC>::set(o, v, x);
-                }
-                if (valid[r]) st_stream<false, V>(wp[r] + cc, o);
+                if (valid[r]) st_stream<false, V>(wp[r] + cc, o[r]);
                 if (GV) {
 #pragma unroll
-                    for (int v = 0; v < VEC; ++v) acc[r] += VecT<VEC>::get(o, v) * VecT<VEC>::get(hv, v);
+                    for (int v = 0; v < VEC; ++v) acc[r] += VecT<VEC>::get(o[r], v) * VecT<VEC>::get(hv, v);
                 }
             }
         }

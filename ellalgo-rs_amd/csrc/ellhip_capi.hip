@@ -206,7 +206,7 @@ void pick_shape(ellhip_space* s) {
         s->sh_rank1 = {2, 8, 1};
         s->sh_fused = {2, 8, 1};
     }
-    s->sh_apply = {2, 2, s->sh_fused.nt};
+    s->sh_apply = {4, 1, s->sh_fused.nt};  // 8 pending vectors per column step: more rows per workgroup amortise them
     s->sh_apply.rw = env_int("ELLHIP_APPLY_RW", s->sh_apply.rw);
     s->sh_apply.unr = env_int("ELLHIP_APPLY_UNR", s->sh_apply.unr);
     s->sh_apply.nt = env_int("ELLHIP_APPLY_NT", s->sh_apply.nt);
