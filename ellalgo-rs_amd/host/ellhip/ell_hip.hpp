@@ -101,6 +101,9 @@ class SpaceHip {
         return out;
     }
     void set_no_defer_trick(bool f) { check(ellhip_set_no_defer_trick(h_, f ? 1 : 0), "ellhip_set_no_defer_trick"); }
+    // 1 = rewrite Q at every cut (reference data flow); 8 = record cuts, apply them to Q in batches of 8
+    void set_defer_depth(int depth) { check(ellhip_set_defer_depth(h_, depth), "ellhip_set_defer_depth"); }
+    int defer_depth() const { return ellhip_defer_depth(h_); }
     std::size_t ndim() const { return n_; }
     ellhip_space* handle() { return h_; }
 

@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <limits>
 #include <string>
+#include <type_traits>
 
 #include "example_oracles.hpp"
 #ifdef BACKEND_HIP
@@ -33,9 +34,22 @@ static void emit(const std::string& name, size_t niter, bool has_x, const Arr* x
 }
 
 static bool g_pipelined = false;  // --pipelined: drive Ell through prime / cut / commit (HIP backend only)
+static int g_defer = 1;           // --defer8: deferred shrink (HIP backend only)
+
+template <class Space>
+static void apply_defer(Space& space) {
+#ifdef BACKEND_HIP
+    if constexpr (std::is_same_v<Space, ellhip::EllHip>) {
+        if (g_defer != 1) space.set_defer_depth(g_defer);
+    }
+#else
+    (void)space;
+#endif
+}
 
 template <class Space, class Oracle>
 static void run_optim(const std::string& name, Space space, Oracle omega, double gamma, Options opt) {
+    apply_defer(space);
 #ifdef BACKEND_HIP
     if (g_pipelined) {
         auto [x, niter] = cutting_plane_optim_pipelined(omega, space, gamma, opt);
@@ -49,6 +63,7 @@ static void run_optim(const std::string& name, Space space, Oracle omega, double
 
 template <class Space, class Oracle>
 static std::pair<std::optional<Arr>, std::size_t> run_feas(Oracle& omega, Space& space, const Options& opt) {
+    apply_defer(space);
 #ifdef BACKEND_HIP
     if (g_pipelined) return cutting_plane_feas_pipelined(omega, space, opt);
 #endif
@@ -60,6 +75,7 @@ int main(int argc, char** argv) {
     for (int i = 1; i < argc; ++i) {
         if (std::string(argv[i]) == "--no-stable") with_stable = false;
         if (std::string(argv[i]) == "--pipelined") g_pipelined = true;
+        if (std::string(argv[i]) == "--defer8") g_defer = 8;
     }
     const double NEG_INF = -std::numeric_limits<double>::infinity();
     const double INF = std::numeric_limits<double>::infinity();

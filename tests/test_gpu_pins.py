@@ -47,6 +47,17 @@ def test_pipelined_drivers_equal_plain_drivers(results, results_pipelined):
         assert got["x"] == want["x"] and got["gamma"] == want["gamma"], case   # bit-identical engine paths
 
 
+@pytest.fixture(scope="module")
+def results_deferred(gpu):
+    return run_json_lines(build_runner("pins_runner.cpp", "hip"), "--pipelined", "--defer8")
+
+
+@pytest.mark.parametrize("case", sorted(pins.PINNED))
+def test_pinned_case_hip_deferred_shrink(results_deferred, case):
+    """Deferred shrink (depth 8) + pipelined drivers still reproduce every pinned answer."""
+    pins.check_case(case, results_deferred[case])
+
+
 def test_solutions_match_oracle_backend(results, results_oracle):
     for case, want in results_oracle.items():
         got = results[case]
