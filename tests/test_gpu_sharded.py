@@ -27,7 +27,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, backend, n, k, fused, errq):
+def _worker(rank, world, port, backend, n, k, fused, defer, errq):
     try:
         for p in (ROOT, HERE):
             if p not in sys.path:
@@ -55,6 +55,9 @@ def _worker(rank, world, port, backend, n, k, fused, errq):
         kinds, grads, b0, b1 = synth.parallel_cuts(n, k)
         ref = pkg.Ell.new_with_scalar(1.0, np.zeros(n), device=0)
         sh = ShardedEll.new_with_scalar(1.0, np.zeros(n), device=0, exchange=None if backend == "nccl" else bounce)
+        if defer != 1:
+            ref.defer_depth = defer
+            sh.set_defer_depth(defer)
         half = k // 2
         for i in range(half):  # direct, synchronous updates
             cut = (grads[i], (b0[i], b1[i]))
@@ -78,11 +81,11 @@ def _worker(rank, world, port, backend, n, k, fused, errq):
         raise
 
 
-def _run(world, backend, n, k, fused=False):
+def _run(world, backend, n, k, fused=False, defer=1):
     ctx = mp.get_context("spawn")
     errq = ctx.SimpleQueue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, backend, n, k, fused, errq)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, backend, n, k, fused, defer, errq)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
@@ -104,6 +107,14 @@ def test_two_ranks_one_gpu_gloo_transport(gpu):
 
 def test_two_ranks_one_gpu_pipelined_schedule(gpu):
     _run(2, "gloo", 512, 12, fused=True)
+
+
+def test_two_ranks_one_gpu_deferred_shrink(gpu):
+    _run(2, "gloo", 512, 40, fused=True, defer=8)
+
+
+def test_one_rank_rccl_deferred_shrink(gpu):
+    _run(1, "nccl", 1024, 40, fused=True, defer=8)
 
 
 def test_one_rank_rccl_in_place_allgather(gpu):
