@@ -254,6 +254,7 @@ def main() -> None:
     value = K / elapsed
     # algorithmic bytes per launch of each kernel class (per GPU)
     alg = {"gemv": 8.0 * n2w, "rank1": 16.0 * n2w, "fused": 16.0 * n2w, "apply": 16.0 * n2w, "apply_gemv": 16.0 * n2w,
+           "symv": 4.0 * n2w,
            "stable_fwd": 8.0 * n * n, "stable_bwd": 4.0 * n * n, "stable_factor": 12.0 * n * n}
 
     def byte_model(sched, dep):
@@ -262,6 +263,9 @@ def main() -> None:
             if sched == "pipelined":
                 return 16.0 * n2w, "16*n^2 B/update (rank-1 pass of cut k fused with the GEMV of cut k+1)"
             return 24.0 * n2w, "24*n^2 B/update (GEMV pass 8 + rank-1 pass 16; SURVEY 8d)"
+        if not sharded and n % 2 == 0 and n >= 10240:
+            return 6.0 * n2w, ("6*n^2 B/update (deferred shrink, depth 8, unsharded: eight lower-triangle GEMV passes of "
+                               "4*n^2 + one apply pass of 16*n^2 per 8 updates)")
         if sched == "pipelined":
             return 9.0 * n2w, ("9*n^2 B/update (deferred shrink, depth 8: seven read-only GEMV passes of 8*n^2 + one "
                                "apply+GEMV pass of 16*n^2 per 8 updates)")

@@ -255,6 +255,139 @@ __global__ __launch_bounds__(256) void k_sweep(const double* Q, double* Qout, lo
     }
 }
 
+// ------------------------------------------------------------------------------------ k_symv ---
+// GEMV through the lower triangle only (deferred mode, unsharded handle, Q bit-symmetric -- which the
+// update formula guarantees): y = Q g with every stored element Q[r][c], c < r, used twice,
+//     y[r] += Q[r][c] g[c]   (row sums)        y[c] += Q[r][c] g[r]   (column sums),
+// so a pass reads 4 n^2 bytes instead of 8 n^2.  Tiles: strip I = SYMV_H rows, segment J = SYMV_SEG
+// columns (only segments that reach the diagonal or lie left of it).  A workgroup keeps, per thread,
+// the column sums of its own columns over the strip's rows (no cross-thread traffic) and reduces each
+// row's partial sum once; it writes
+//     rowpart[J][r]  = sum over the segment's columns c <= r of Q[r][c] g[c]
+//     colpart[I][c]  = sum over the strip's rows r > c of Q[r][c] g[r]
+// and k_symv_reduce forms y[i] = sum_J rowpart[J][i] + sum_{I >= i/H} colpart[I][i] in a fixed order.
+constexpr int SYMV_H = 64;
+constexpr int SYMV_SEG = 2048;
+constexpr int SYMV_NCH = SYMV_SEG / 512;  // 16-byte column chunks per thread
+
+template <int RW, bool NT, int ABL = 0>  // ABL: timing-only ablations for tools/tune_ell.hip (0 = the real kernel)
+__global__ __launch_bounds__(256) void k_symv(const double* __restrict__ Q, long long ld, long long n,
+                                              const double* __restrict__ g, double* __restrict__ rowpart,
+                                              double* __restrict__ colpart, const DevState* __restrict__ st) {
+    __shared__ double red[4][SYMV_H];
+    if (st->halted) return;
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    // grid = (strips, segments), strips in descending order (the widest first).  Measured alternative: making
+    // the segment index the fast one (row-major traversal) is 19 % slower (profiles/r01/tune_symv.txt).
+    const long long I = (long long)gridDim.x - 1 - blockIdx.x;
+    const long long J = blockIdx.y;
+    const long long r0 = I * SYMV_H;
+    const long long c0 = J * SYMV_SEG;
+    if (r0 >= n || c0 > r0 + SYMV_H - 1) return;  // nothing at or left of the diagonal in this segment
+    const long long rlast = (r0 + SYMV_H - 1 < n - 1) ? r0 + SYMV_H - 1 : n - 1;
+    const bool full = c0 + SYMV_SEG - 1 < r0;  // every column of the segment is strictly left of every row
+
+    long long ck[SYMV_NCH];
+    double2_t gc[SYMV_NCH], accc[SYMV_NCH];
+#pragma unroll
+    for (int k = 0; k < SYMV_NCH; ++k) {
+        ck[k] = c0 + 512 * k + 2 * (long long)threadIdx.x;
+        const bool in = ck[k] <= rlast;  // n is even and ck is even: ck <= n - 2, so the pair is inside the matrix
+        gc[k] = in ? *reinterpret_cast<const double2_t*>(g + ck[k]) : double2_t{0.0, 0.0};
+        accc[k] = double2_t{0.0, 0.0};
+    }
+    for (int rg = 0; rg < SYMV_H / RW; ++rg) {
+        double accr[RW];
+        double gr[RW];
+        long long rr[RW];
+        double2_t q[RW][SYMV_NCH];
+#pragma unroll
+        for (int r = 0; r < RW; ++r) {
+            rr[r] = r0 + rg * RW + r;
+            const bool rv = rr[r] < n;
+            gr[r] = rv ? g[rr[r]] : 0.0;
+            accr[r] = 0.0;
+            const double* row = Q + (rv ? rr[r] : n - 1) * ld;
+#pragma unroll
+            for (int k = 0; k < SYMV_NCH; ++k) {
+                // load the pair when its first column is at or left of the diagonal of this row
+                if (rv && (full || ck[k] <= rr[r])) q[r][k] = ld_stream<NT, double2_t>(row + ck[k]);
+                else q[r][k] = double2_t{0.0, 0.0};
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < RW; ++r) {
+#pragma unroll
+            for (int k = 0; k < SYMV_NCH; ++k) {
+                double qx = q[r][k].x, qy = q[r][k].y;
+                if (!full) {
+                    // pair loaded iff ck <= r; its second element is above the diagonal when ck + 1 > r
+                    if (ck[k] + 1 > rr[r]) qy = 0.0;
+                }
+                accr[r] += qx * gc[k].x;
+                accr[r] += qy * gc[k].y;
+                // column sums take strictly-below-diagonal elements only (the diagonal is counted once, in the row sum)
+                const double cx = (full || ck[k] < rr[r]) ? qx : 0.0;
+                const double cy = (full || ck[k] + 1 < rr[r]) ? qy : 0.0;
+                if (ABL != 2) {
+                    accc[k].x += cx * gr[r];
+                    accc[k].y += cy * gr[r];
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < RW; ++r) {
+            const double s = (ABL == 1) ? accr[r] : wave_allreduce_sum(accr[r]);
+            if (lane == 0) red[wave][rg * RW + r] = s;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < SYMV_H && r0 + threadIdx.x < n) {
+        const int r = threadIdx.x;
+        rowpart[J * n + r0 + r] = ((red[0][r] + red[1][r]) + red[2][r]) + red[3][r];
+    }
+#pragma unroll
+    for (int k = 0; k < SYMV_NCH; ++k)
+        if (ck[k] <= rlast) *reinterpret_cast<double2_t*>(colpart + I * n + ck[k]) = accc[k];
+}
+
+// y[i] = sum_{J <= i/SEG} rowpart[J][i] + sum_{I >= i/H} colpart[I][i]   (fixed order)
+// One workgroup per 128 columns: lane = column pair (16-byte loads, 1 KiB per wave-instruction), wave w
+// takes the strips I0 + w, I0 + w + 4, ...; the four wave sums are combined as ((w0+w1)+w2)+w3.
+__global__ __launch_bounds__(256) void k_symv_reduce(long long n, const double* __restrict__ rowpart,
+                                                     const double* __restrict__ colpart,
+                                                     double* __restrict__ y, const DevState* __restrict__ st) {
+    __shared__ double2_t part[4][64];
+    if (st->halted) return;
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const long long i = (long long)blockIdx.x * 128 + 2 * lane;  // columns i, i+1 (n is even)
+    const long long nstrips = (n + SYMV_H - 1) / SYMV_H;
+    double2_t s = {0.0, 0.0};
+    if (i < n) {
+        for (long long I = i / SYMV_H + wave; I < nstrips; I += 4) {
+            const double2_t v = *reinterpret_cast<const double2_t*>(colpart + I * n + i);
+            s.x += v.x;
+            s.y += v.y;
+        }
+    }
+    part[wave][lane] = s;
+    __syncthreads();
+    if (wave == 0 && i < n) {
+        double2_t r = {0.0, 0.0};
+        for (long long J = 0; J <= i / SYMV_SEG; ++J) {
+            const double2_t v = *reinterpret_cast<const double2_t*>(rowpart + J * n + i);
+            r.x += v.x;
+            r.y += v.y;
+        }
+        const double2_t c0 = part[0][lane], c1 = part[1][lane], c2 = part[2][lane], c3 = part[3][lane];
+        r.x += ((c0.x + c1.x) + c2.x) + c3.x;
+        r.y += ((c0.y + c1.y) + c2.y) + c3.y;
+        *reinterpret_cast<double2_t*>(y + i) = r;
+    }
+}
+
 // ----------------------------------------------------------------------------- k_sweep_apply ---
 // Deferred mode: apply the MAXPEND pending rank-1 updates to the local rows in one pass (and, when GV,
 // accumulate the GEMV of the next gradient on the freshly written values).  pend: MAXPEND vectors of

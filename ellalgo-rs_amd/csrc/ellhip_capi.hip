@@ -57,7 +57,7 @@ int env_int(const char* name, int dflt) {
     return (s && *s) ? atoi(s) : dflt;
 }
 
-enum : int { CLS_GEMV = 0, CLS_SCALAR = 1, CLS_RANK1 = 2, CLS_ST_FWD = 3, CLS_ST_BWD = 4, CLS_ST_FACTOR = 5, CLS_FUSED = 6, CLS_APPLY = 7, CLS_APPLY_GEMV = 8 };
+enum : int { CLS_GEMV = 0, CLS_SCALAR = 1, CLS_RANK1 = 2, CLS_ST_FWD = 3, CLS_ST_BWD = 4, CLS_ST_FACTOR = 5, CLS_FUSED = 6, CLS_APPLY = 7, CLS_APPLY_GEMV = 8, CLS_SYMV = 9 };
 
 struct Shape {
     int rw = 0, unr = 0, nt = 0;
@@ -80,6 +80,11 @@ struct ellhip_space {
     double* d_partial = nullptr;     // per-workgroup partial sums of omega (64)
     double* d_pend = nullptr;        // deferred mode: MAXPEND pending gt vectors (n each)
     double* d_cpend = nullptr;       // deferred mode: their coefficients sigma/omega
+    double* d_rowpart = nullptr;     // symmetric GEMV: per-segment row partial sums  [n/SYMV_SEG][n]
+    double* d_colpart = nullptr;     // symmetric GEMV: per-strip column partial sums [n/SYMV_H][n]
+    int symv = 1;                    // allow the lower-triangle GEMV in deferred mode (ELLHIP_SYMV=0 disables)
+    int symv_rw = 2;
+    long long symv_min_n = 10240;    // below this the full-row pass is faster (few, small triangle tiles)
     int defer = 1;                   // 1 = shrink Q at every cut; MAXPEND = record and apply in batches
     int npend = 0;                   // updates recorded since the last flush (host view, optimistic in queue mode)
     int* d_flags = nullptr;          // EllStable persistent solves: block-ready flags (forward | backward)
@@ -206,6 +211,9 @@ void pick_shape(ellhip_space* s) {
         s->sh_rank1 = {2, 8, 1};
         s->sh_fused = {2, 8, 1};
     }
+    s->symv = env_int("ELLHIP_SYMV", 1);
+    s->symv_rw = env_int("ELLHIP_SYMV_RW", 2);
+    s->symv_min_n = env_int("ELLHIP_SYMV_MIN_N", 10240);
     s->sh_apply = {4, 1, s->sh_fused.nt};  // 8 pending vectors per column step: more rows per workgroup amortise them
     s->sh_apply.rw = env_int("ELLHIP_APPLY_RW", s->sh_apply.rw);
     s->sh_apply.unr = env_int("ELLHIP_APPLY_UNR", s->sh_apply.unr);
@@ -401,9 +409,39 @@ int ellstable_issue(ellhip_space* s, const double* g_dev, const CutParams* cp_de
 
 // ---- the three primitives --------------------------------------------------------------------
 
+// Lower-triangle GEMV: deferred mode (Q_base is bit-symmetric and only read), whole matrix on this GPU.
+bool symv_ok(const ellhip_space* s) {
+    return deferring(s) && s->symv && !s->sharded && (s->n % 2) == 0 && s->n >= s->symv_min_n && s->d_rowpart;
+}
+
+int launch_symv(ellhip_space* s, const double* g_dev, double* y_out) {
+    ProfScope ps(s, CLS_SYMV);
+    const unsigned nstrips = (unsigned)((s->n + SYMV_H - 1) / SYMV_H);
+    const unsigned nsegs = (unsigned)((s->n + SYMV_SEG - 1) / SYMV_SEG);
+    const bool nt = s->sh_gemv.nt != 0;
+#define SYMV_CASE(RW)                                                                                         \
+    if (s->symv_rw == RW) {                                                                                   \
+        if (nt)                                                                                               \
+            hipLaunchKernelGGL((k_symv<RW, true>), dim3(nstrips, nsegs), dim3(256), 0, s->stream,             \
+                               (const double*)s->d_Q, s->ld, s->n, g_dev, s->d_rowpart, s->d_colpart, s->d_st); \
+        else                                                                                                  \
+            hipLaunchKernelGGL((k_symv<RW, false>), dim3(nstrips, nsegs), dim3(256), 0, s->stream,            \
+                               (const double*)s->d_Q, s->ld, s->n, g_dev, s->d_rowpart, s->d_colpart, s->d_st); \
+    }
+    SYMV_CASE(1) SYMV_CASE(2) SYMV_CASE(4) SYMV_CASE(8)
+#undef SYMV_CASE
+    if (s->symv_rw != 1 && s->symv_rw != 2 && s->symv_rw != 4 && s->symv_rw != 8)
+        return fail(ELLHIP_E_INVALID, "unsupported ELLHIP_SYMV_RW (1, 2, 4, 8)");
+    hipLaunchKernelGGL(k_symv_reduce, dim3((unsigned)((s->n + 127) / 128)), dim3(256), 0, s->stream, s->n,
+                       (const double*)s->d_rowpart, (const double*)s->d_colpart, y_out, s->d_st);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
 // gt[slot] = Q * g  (Ell only; EllStable has no separate first pass)
 int do_prime(ellhip_space* s, const double* g_dev, int slot) {
     if (s->variant != ELLHIP_SPACE_ELL) return 0;
+    if (symv_ok(s)) return launch_symv(s, g_dev, s->d_gt[slot]);
     ProfScope ps(s, CLS_GEMV);
     return launch_sweep<false, true>(s, s->sh_gemv, nullptr, g_dev, s->d_gt[slot]);
 }
@@ -449,7 +487,11 @@ int do_commit(ellhip_space* s, bool shrink, const double* gnext_dev) {
     if (deferring(s)) {
         // nothing to shrink now: the cut was recorded.  When the slots are full, one pass applies them all
         // (and carries the next GEMV); otherwise the next gradient only needs a read-only pass.
-        if (s->npend >= MAXPEND) return flush_pending(s, gnext_dev, gnext_dev ? s->d_gt[s->cur ^ 1] : nullptr);
+        if (s->npend >= MAXPEND) {
+            if (gnext_dev && !symv_ok(s)) return flush_pending(s, gnext_dev, s->d_gt[s->cur ^ 1]);
+            int rc = flush_pending(s, nullptr, nullptr);  // the next GEMV runs on the lower triangle afterwards
+            if (rc) return rc;
+        }
         if (gnext_dev) return do_prime(s, gnext_dev, s->cur ^ 1);
         return 0;
     }
@@ -774,6 +816,8 @@ void ellhip_destroy(ellhip_space* s) {
     if (s->d_partial) (void)hipFree(s->d_partial);
     if (s->d_pend) (void)hipFree(s->d_pend);
     if (s->d_cpend) (void)hipFree(s->d_cpend);
+    if (s->d_rowpart) (void)hipFree(s->d_rowpart);
+    if (s->d_colpart) (void)hipFree(s->d_colpart);
     if (s->d_flags) (void)hipFree(s->d_flags);
     if (s->d_st) (void)hipFree(s->d_st);
     if (s->h_result) (void)hipHostFree(s->h_result);
@@ -810,7 +854,9 @@ int ellhip_clone(const ellhip_space* src_c, ellhip_space** out) {
     s->sh_rank1 = src->sh_rank1;
     s->sh_fused = src->sh_fused;
     s->sh_apply = src->sh_apply;
-    s->defer = src->defer;
+    s->symv = src->symv;
+    s->symv_rw = src->symv_rw;
+    s->symv_min_n = src->symv_min_n;
     rc = alloc_common(s);
     if (rc) {
         ellhip_destroy(s);
@@ -828,6 +874,13 @@ int ellhip_clone(const ellhip_space* src_c, ellhip_space** out) {
     if (e != hipSuccess) {
         ellhip_destroy(s);
         return fail(ELLHIP_E_HIP, "clone copy", e);
+    }
+    if (src->defer > 1) {
+        rc = ellhip_set_defer_depth(s, src->defer);
+        if (rc) {
+            ellhip_destroy(s);
+            return rc;
+        }
     }
     *out = s;
     return 0;
@@ -993,6 +1046,11 @@ int ellhip_set_defer_depth(ellhip_space* s, int depth) {
     DeviceGuard guard(s->device);
     int rc = make_q_current(s);
     if (rc) return rc;
+    if (depth > 1 && !s->sharded && !s->d_rowpart && (s->n % 2) == 0 && s->n >= 512) {
+        const size_t nsegs = (size_t)((s->n + SYMV_SEG - 1) / SYMV_SEG), nstrips = (size_t)((s->n + SYMV_H - 1) / SYMV_H);
+        HIPCHK(hipMalloc(&s->d_rowpart, nsegs * (size_t)s->n * sizeof(double)));
+        HIPCHK(hipMalloc(&s->d_colpart, nstrips * (size_t)s->n * sizeof(double)));
+    }
     s->defer = depth;
     return 0;
 }

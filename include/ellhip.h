@@ -163,7 +163,11 @@ int ellhip_commit(ellhip_space *s, const double *next_grad);
  * current; Q is made current before ellhip_get_mq / ellhip_clone return.  Results stay within the
  * 1e-10 parity tolerance of depth 1 (gt is the same vector computed in a different order); they are
  * bit-identical across schedules, row partitions and GPU counts for a given depth.  Not used while
- * no_defer_trick is set or before a non-symmetric input matrix has been mirrored.  Ell only. */
+ * no_defer_trick is set or before a non-symmetric input matrix has been mirrored.  Ell only.
+ * On an unsharded handle (even n) depth 8 also computes Q_base*g through the lower triangle only
+ * (every stored element is used for a row sum and a column sum: 4 n^2 bytes per GEMV pass); a
+ * row-partitioned handle keeps the full-row GEMV, so its bits differ from an unsharded handle's at
+ * depth 8 (both stay within the parity tolerance; shards agree with each other bit for bit). */
 int ellhip_set_defer_depth(ellhip_space *s, int depth);
 int ellhip_defer_depth(const ellhip_space *s);
 
@@ -199,8 +203,9 @@ int ellhip_synchronize(ellhip_space *s);
  * launch counts per kernel class, then resets.  Classes: 0 = GEMV pass (Q*g), 1 = scalar stage,
  * 2 = rank-1 pass, 3 = EllStable forward, 4 = EllStable backward, 5 = EllStable factor update,
  * 6 = fused pass (rank-1 of cut k + GEMV of cut k+1), 7 = deferred apply pass (8 recorded updates),
- * 8 = deferred apply pass fused with the next GEMV. */
-#define ELLHIP_NKERNEL_CLASSES 9
+ * 8 = deferred apply pass fused with the next GEMV, 9 = symmetric GEMV pass (lower triangle only,
+ * 4 n^2 bytes; deferred mode on an unsharded handle) including its partial-sum reduction. */
+#define ELLHIP_NKERNEL_CLASSES 10
 int ellhip_profile_enable(ellhip_space *s, int flag);
 int ellhip_profile_read(ellhip_space *s, double *ms_out, int64_t *count_out);
 

@@ -23,6 +23,19 @@ def test_deferred_mixed_sequence_matches_oracle(gpu, orc, n):
     assert_state_close(g, o, what=f"deferred n={n}")
 
 
+@pytest.mark.parametrize("n", [512, 1000, 2112, 4096])
+def test_deferred_symv_mixed_sequence_matches_oracle(gpu, orc, n, monkeypatch):
+    """Depth 8 with the lower-triangle GEMV forced on at small sizes (default threshold n >= 10240)."""
+    monkeypatch.setenv("ELLHIP_SYMV_MIN_N", "512")
+    xc0 = np.linspace(-1.0, 1.0, n)
+    g = gpu.Ell.new_with_scalar(2.0, xc0)
+    g.defer_depth = 8
+    o = orc.OracleEll.new_with_scalar(2.0, xc0)
+    nsucc = run_mixed(g, o, 44, seed=900 + n, check_every=11)
+    assert nsucc >= 22
+    assert_state_close(g, o, what=f"deferred+symv n={n}")
+
+
 @pytest.mark.parametrize("n", [4096, 8192])
 def test_deferred_deep_cuts_large(gpu, orc, n):
     from ellalgo_rs_amd import synth
@@ -124,19 +137,26 @@ def test_deferred_clone_and_mode_switches(gpu, orc):
     assert_state_close(g, o, what="after mode switches")
 
 
-def test_deferred_row_shards_bit_identical_to_unsharded(gpu):
+def test_deferred_row_shards_bit_identical_to_one_shard_and_close_to_unsharded(gpu, monkeypatch):
+    """Row partitions agree bit for bit with each other (2 shards == 1 shard holding all rows: both use the
+    full-row GEMV).  The unsharded handle takes the lower-triangle GEMV at depth 8, so it matches to
+    rounding, not to the bit."""
     pkg = gpu
     L = pkg.capi.load()
-    n, half = 256, 128
+    n, half = 1024, 512
     rng = np.random.default_rng(9)
+    monkeypatch.setenv("ELLHIP_SYMV_MIN_N", "512")
     ref = pkg.Ell.new_with_scalar(1.5, np.zeros(n))
     ref.defer_depth = 8
-    hs = []
-    for r in range(2):
+
+    def shard(row0, nrows):
         h = C.c_void_p()
-        pkg.capi.check(L.ellhip_create_shard(C.byref(h), n, r * half, half, 1.5, None, None, None, -1))
+        pkg.capi.check(L.ellhip_create_shard(C.byref(h), n, row0, nrows, 1.5, None, None, None, -1))
         pkg.capi.check(L.ellhip_set_defer_depth(h, 8))
-        hs.append(h)
+        return h
+
+    hs = [shard(0, half), shard(half, half)]
+    one = shard(0, n)
     pkg.capi.check(L.ellhip_set_gt_dev(hs[1], L.ellhip_gt_dev(hs[0]), None))
     try:
         for i in range(19):
@@ -147,16 +167,47 @@ def test_deferred_row_shards_bit_identical_to_unsharded(gpu):
             for h in hs:
                 pkg.capi.check(L.ellhip_synchronize(h))
             assert [pkg.capi.check(L.ellhip_update_end(h)) for h in hs] == [0, 0]
+            assert pkg.capi.check(L.ellhip_update(one, 0, gp, 0.02, 0, 0.0)) == 0
             assert int(ref.update_bias_cut((g, 0.02))) == 0
         q = np.empty((n, n))
+        q1 = np.empty((n, n))
+        pkg.capi.check(L.ellhip_get_mq(one, q1.ctypes.data_as(C.c_void_p)))
+        x1 = np.empty(n)
+        pkg.capi.check(L.ellhip_get_xc(one, x1.ctypes.data_as(C.c_void_p)))
         for r, h in enumerate(hs):
             blk = np.empty((half, n))
             pkg.capi.check(L.ellhip_get_mq(h, blk.ctypes.data_as(C.c_void_p)))
             q[r * half:(r + 1) * half] = blk
             x = np.empty(n)
             pkg.capi.check(L.ellhip_get_xc(h, x.ctypes.data_as(C.c_void_p)))
-            assert np.array_equal(x, ref.xc()) and L.ellhip_kappa(h) == ref.kappa
-        assert np.array_equal(q, ref.mq)
+            assert np.array_equal(x, x1) and L.ellhip_kappa(h) == L.ellhip_kappa(one)
+        assert np.array_equal(q, q1)                                   # partitions: bit-identical
+        qr = ref.mq
+        assert np.max(np.abs(q - qr)) <= 1e-12 * np.max(np.abs(qr))    # vs the lower-triangle GEMV: rounding only
+        assert np.max(np.abs(x1 - ref.xc())) <= 1e-12 * np.max(np.abs(x1))
+        assert abs(L.ellhip_kappa(one) - ref.kappa) <= 1e-13 * abs(ref.kappa)
     finally:
-        for h in hs:
+        for h in hs + [one]:
             L.ellhip_destroy(h)
+
+
+def test_symv_equals_full_gemv_to_rounding(gpu, monkeypatch):
+    """The lower-triangle GEMV (4 n^2 bytes) against the full-row GEMV on the same deferred sequence."""
+    from ellalgo_rs_amd import synth
+    n, k = 2048 + 64, 20          # not a multiple of the segment width: exercises the ragged diagonal segment
+    kinds, grads, b0, b1 = synth.parallel_cuts(n, k)
+    monkeypatch.setenv("ELLHIP_SYMV_MIN_N", "512")   # the default threshold (10240) would skip it at this size
+    a = gpu.Ell.new_with_scalar(1.0, np.zeros(n))
+    a.defer_depth = 8
+    monkeypatch.setenv("ELLHIP_SYMV", "0")
+    b = gpu.Ell.new_with_scalar(1.0, np.zeros(n))
+    b.defer_depth = 8
+    monkeypatch.delenv("ELLHIP_SYMV")
+    for i in range(k):
+        cut = (grads[i], (b0[i], b1[i]))
+        assert int(a._update(int(kinds[i]), cut)) == int(b._update(int(kinds[i]), cut)) == 0
+        assert abs(a.tsq() - b.tsq()) <= 1e-13 * abs(b.tsq())
+    qa, qb = a.mq, b.mq
+    assert np.array_equal(qa, qa.T)
+    assert np.max(np.abs(qa - qb)) <= 1e-12 * np.max(np.abs(qb))
+    assert np.max(np.abs(a.xc() - b.xc())) <= 1e-12 * np.max(np.abs(b.xc()))

@@ -73,10 +73,33 @@ def test_pipelined_equals_two_pass_at_full_size(gpu, cuts):
     assert np.array_equal(qa, qa.T)
 
 
+def test_deferred_symv_equals_immediate_path_at_full_size(gpu, cuts):
+    """Default fast configuration (depth 8, lower-triangle GEMV, pipelined) against the reference data flow
+    (depth 1, two-pass) on the same cuts: same statuses, state equal to rounding."""
+    from ellalgo_rs_amd import synth
+    k = 20
+    kinds, grads, b0, b1 = synth.parallel_cuts(N, k)
+    a = gpu.Ell.new_with_scalar(1.0, np.zeros(N))
+    b = gpu.Ell.new_with_scalar(1.0, np.zeros(N))
+    b.defer_depth = 8
+    a.queue_upload(kinds, grads, b0, b1)
+    b.queue_upload(kinds, grads, b0, b1)
+    a.queue_run(0, k)
+    b.queue_run(0, k, fused=True)
+    sa, ta = a.queue_results()
+    sb, tb = b.queue_results()
+    assert np.array_equal(sa, sb) and np.all(sa == 0)
+    assert np.max(np.abs(ta - tb) / np.abs(ta)) <= 1e-12
+    assert abs(a.kappa - b.kappa) <= 1e-12 * abs(a.kappa)
+    assert np.max(np.abs(a.xc() - b.xc())) <= 1e-12 * np.max(np.abs(a.xc()))
+    qa, qb = a.mq, b.mq
+    assert np.array_equal(qb, qb.T)
+    assert np.max(np.abs(qa - qb)) <= 1e-12 * np.max(np.abs(qa))
+
+
 def test_ellstable_first_update_closed_form(gpu, orc):
-    """EllStable from the identity factor: w = g, z = g, omega = g.g, q = z (the scratch triangle is
-    zero-weighted... no: S[i][j] = U[j][i]*w[j] = 0), so xc and kappa follow the oracle's coefficients and
-    the factor update adds beta2_j * S[l][j] = 0: the buffer keeps a unit... diagonal scaled by t_{j-1}/t_j."""
+    """EllStable from the identity factor: w = g, z = g, every parked product U[j][i]*w[j] is 0, so the
+    off-diagonal part of the buffer stays exactly zero and only the diagonal is rescaled (t_{j-1}/t_j)."""
     n = 4096
     from ellalgo_rs_amd import synth
     kinds, grads, b0, _ = synth.deep_cuts(n, 1)

@@ -59,10 +59,17 @@ def _worker(rank, world, port, backend, n, k, fused, defer, errq):
             ref.defer_depth = defer
             sh.set_defer_depth(defer)
         half = k // 2
+        # depth 8: the unsharded reference takes the lower-triangle GEMV, a shard the full-row one: same
+        # vector to rounding.  depth 1: identical kernels, identical bits.
+        exact = defer == 1
+
+        def same(a, b):
+            return np.array_equal(a, b) if exact else np.max(np.abs(np.asarray(a) - np.asarray(b))) <= 1e-12 * np.max(np.abs(b))
+
         for i in range(half):  # direct, synchronous updates
             cut = (grads[i], (b0[i], b1[i]))
             assert int(sh._update(int(kinds[i]), cut)) == int(ref._update(int(kinds[i]), cut)) == 0
-            assert sh.tsq() == ref.tsq()
+            assert same([sh.tsq()], [ref.tsq()])
         # then the device-resident queue
         sh.queue_upload(kinds[half:], grads[half:], b0[half:], b1[half:])
         ref.queue_upload(kinds[half:], grads[half:], b0[half:], b1[half:])
@@ -71,9 +78,9 @@ def _worker(rank, world, port, backend, n, k, fused, defer, errq):
         ref.queue_run(0, k - half)
         st_s, ts_s = sh.queue_results()
         st_r, ts_r = ref.queue_results()
-        assert np.array_equal(st_s, st_r) and np.array_equal(ts_s, ts_r) and np.all(st_r == 0)
-        assert np.array_equal(sh.mq_rows, ref.mq[sh.row0:sh.row0 + sh.nrows]), "Q rows differ from unsharded engine"
-        assert np.array_equal(sh.xc(), ref.xc()) and sh.kappa == ref.kappa
+        assert np.array_equal(st_s, st_r) and same(ts_s, ts_r) and np.all(st_r == 0)
+        assert same(sh.mq_rows, ref.mq[sh.row0:sh.row0 + sh.nrows]), "Q rows differ from unsharded engine"
+        assert same(sh.xc(), ref.xc()) and same([sh.kappa], [ref.kappa])
         dist.barrier()
         dist.destroy_process_group()
     except Exception:

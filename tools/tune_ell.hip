@@ -82,6 +82,18 @@ int main(int argc, char** argv) {
     SWEEP(8, 2, true, true, true, false) SWEEP(1, 8, false, true, true, false) SWEEP(4, 4, false, true, true, false)
     SWEEP(2, 8, true, true, true, true) SWEEP(2, 4, true, true, true, true)
 
+    double *rowpart, *colpart;
+    CK(hipMalloc(&rowpart, (size_t)((n + SYMV_SEG - 1) / SYMV_SEG) * n * 8));
+    CK(hipMalloc(&colpart, (size_t)((n + SYMV_H - 1) / SYMV_H) * n * 8));
+#define SYMVV(RW, NT, ABL)                                                                                   \
+    vs.push_back({std::string("symv  RW" #RW) + (NT ? " nt" : "   ") + " abl" #ABL, 4.0 * n2, [=](hipStream_t q, int) { \
+                      dim3 grid((unsigned)((n + SYMV_H - 1) / SYMV_H), (unsigned)((n + SYMV_SEG - 1) / SYMV_SEG));       \
+                      hipLaunchKernelGGL((k_symv<RW, NT, ABL>), grid, dim3(256), 0, q, Q, ld, n, g, rowpart, colpart, st); \
+                  }, {}});
+    SYMVV(2, true, 0) SYMVV(2, true, 1) SYMVV(2, true, 2) SYMVV(4, true, 0) SYMVV(4, true, 1) SYMVV(2, false, 0)
+    vs.push_back({"symv reduce", 0.0, [=](hipStream_t q, int) {
+                      hipLaunchKernelGGL(k_symv_reduce, dim3((unsigned)((n + 127) / 128)), dim3(256), 0, q, n, rowpart, colpart, gt2, st);
+                  }, {}});
     hipEvent_t a, b;
     CK(hipEventCreate(&a));
     CK(hipEventCreate(&b));
