@@ -300,7 +300,8 @@ def main() -> None:
         cands = [k for k in per_kernel if k in alg]
         dom = max(cands, key=lambda k: per_kernel[k]["avg_ms"]) if cands else None
     if dom in per_kernel:
-        roofline.update({"kernel": "k_sweep:" + dom if variant == "ell" else "k_st_" + dom[7:],
+        kname = {"symv": "k_symv", "apply": "k_sweep_apply", "apply_gemv": "k_sweep_apply"}.get(dom, "k_sweep:" + dom)
+        roofline.update({"kernel": kname if variant == "ell" else "k_st_" + dom[7:],
                          "achieved": per_kernel[dom]["GBps"], "frac": per_kernel[dom]["GBps"] / HBM_PEAK_GBS,
                          "alg_bytes_per_launch": per_kernel[dom]["alg_bytes"],
                          "avg_launch_ms": per_kernel[dom]["avg_ms"]})

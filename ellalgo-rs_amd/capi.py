@@ -13,9 +13,9 @@ SUCCESS, NOSOLN, NOEFFECT, UNKNOWN = 0, 1, 2, 3
 CUT_BIAS, CUT_CENTRAL, CUT_Q = 0, 1, 2
 SPACE_ELL, SPACE_ELL_STABLE = 0, 1
 E_INVALID, E_HIP, E_NODEVICE, E_NOMEM, E_STATE = -1, -2, -3, -4, -5
-NKERNEL_CLASSES = 10
+NKERNEL_CLASSES = 11
 KERNEL_CLASS_NAMES = ("gemv", "scalar", "rank1", "stable_fwd", "stable_bwd", "stable_factor", "fused", "apply",
-                      "apply_gemv", "symv")
+                      "apply_gemv", "symv", "symv_reduce")
 
 # every symbol include/ellhip.h declares
 EXPORTS = [

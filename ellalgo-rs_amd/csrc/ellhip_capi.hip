@@ -57,7 +57,7 @@ int env_int(const char* name, int dflt) {
     return (s && *s) ? atoi(s) : dflt;
 }
 
-enum : int { CLS_GEMV = 0, CLS_SCALAR = 1, CLS_RANK1 = 2, CLS_ST_FWD = 3, CLS_ST_BWD = 4, CLS_ST_FACTOR = 5, CLS_FUSED = 6, CLS_APPLY = 7, CLS_APPLY_GEMV = 8, CLS_SYMV = 9 };
+enum : int { CLS_GEMV = 0, CLS_SCALAR = 1, CLS_RANK1 = 2, CLS_ST_FWD = 3, CLS_ST_BWD = 4, CLS_ST_FACTOR = 5, CLS_FUSED = 6, CLS_APPLY = 7, CLS_APPLY_GEMV = 8, CLS_SYMV = 9, CLS_SYMV_REDUCE = 10 };
 
 struct Shape {
     int rw = 0, unr = 0, nt = 0;
@@ -415,6 +415,7 @@ bool symv_ok(const ellhip_space* s) {
 }
 
 int launch_symv(ellhip_space* s, const double* g_dev, double* y_out) {
+  {
     ProfScope ps(s, CLS_SYMV);
     const unsigned nstrips = (unsigned)((s->n + SYMV_H - 1) / SYMV_H);
     const unsigned nsegs = (unsigned)((s->n + SYMV_SEG - 1) / SYMV_SEG);
@@ -432,6 +433,9 @@ int launch_symv(ellhip_space* s, const double* g_dev, double* y_out) {
 #undef SYMV_CASE
     if (s->symv_rw != 1 && s->symv_rw != 2 && s->symv_rw != 4 && s->symv_rw != 8)
         return fail(ELLHIP_E_INVALID, "unsupported ELLHIP_SYMV_RW (1, 2, 4, 8)");
+    HIPCHK(hipGetLastError());
+  }
+    ProfScope ps(s, CLS_SYMV_REDUCE);
     hipLaunchKernelGGL(k_symv_reduce, dim3((unsigned)((s->n + 127) / 128)), dim3(256), 0, s->stream, s->n,
                        (const double*)s->d_rowpart, (const double*)s->d_colpart, y_out, s->d_st);
     HIPCHK(hipGetLastError());
