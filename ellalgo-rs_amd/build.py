@@ -11,7 +11,8 @@ LIB_PATH = os.path.join(PKG_DIR, "libellhip.so")
 REPO_ROOT = os.path.dirname(PKG_DIR)
 
 SOURCES = ["ellhip_capi.hip"]
-HEADERS = ["ell_kernels.hpp", "ellstable_kernels.hpp", "ellcalc_device.hpp"]
+HEADERS = ["ell_kernels.hpp", "ellstable_kernels.hpp", "ellcalc_device.hpp", "lowpass_kernels.hpp",
+           "lowpass_capi.inc.hpp"]
 
 # -ffp-contract=off: the reference never fuses a*b+c (two roundings per multiply-add); keeping
 # that makes the rank-1 pass bit-identical to the CPU arithmetic for the same gt.

@@ -13,9 +13,9 @@ SUCCESS, NOSOLN, NOEFFECT, UNKNOWN = 0, 1, 2, 3
 CUT_BIAS, CUT_CENTRAL, CUT_Q = 0, 1, 2
 SPACE_ELL, SPACE_ELL_STABLE = 0, 1
 E_INVALID, E_HIP, E_NODEVICE, E_NOMEM, E_STATE = -1, -2, -3, -4, -5
-NKERNEL_CLASSES = 11
+NKERNEL_CLASSES = 13
 KERNEL_CLASS_NAMES = ("gemv", "scalar", "rank1", "stable_fwd", "stable_bwd", "stable_factor", "fused", "apply",
-                      "apply_gemv", "symv", "symv_reduce")
+                      "apply_gemv", "symv", "symv_reduce", "lp_scan", "lp_final")
 
 # every symbol include/ellhip.h declares
 EXPORTS = [
@@ -27,6 +27,9 @@ EXPORTS = [
     "ellhip_queue_prime", "ellhip_queue_cut", "ellhip_queue_commit", "ellhip_queue_results", "ellhip_set_stream",
     "ellhip_synchronize", "ellhip_profile_enable", "ellhip_profile_read", "ellhip_device_count",
     "ellhip_last_error", "ellhip_version",
+    # include/ellhip_lowpass.h
+    "ellhip_lowpass_create", "ellhip_lowpass_destroy", "ellhip_lowpass_assess_feas", "ellhip_lowpass_assess_optim",
+    "ellhip_lowpass_state", "ellhip_lowpass_get_spectrum", "ellhip_lowpass_optim", "ellhip_lowpass_feas",
 ]
 
 
@@ -92,6 +95,15 @@ def load():
         "ellhip_device_count": (i32, []),
         "ellhip_last_error": (C.c_char_p, []),
         "ellhip_version": (C.c_char_p, []),
+        "ellhip_lowpass_create": (i32, [C.POINTER(vp), i64, dbl, dbl, dbl, dbl, dbl, vp, i32]),
+        "ellhip_lowpass_destroy": (None, [vp]),
+        "ellhip_lowpass_assess_feas": (i32, [vp, vp, vp, C.POINTER(dbl), C.POINTER(i32), C.POINTER(dbl)]),
+        "ellhip_lowpass_assess_optim": (i32, [vp, vp, C.POINTER(dbl), vp, C.POINTER(dbl), C.POINTER(i32),
+                                              C.POINTER(dbl), C.POINTER(i32)]),
+        "ellhip_lowpass_state": (i32, [vp, vp, vp]),
+        "ellhip_lowpass_get_spectrum": (i32, [vp, vp]),
+        "ellhip_lowpass_optim": (i32, [vp, vp, C.POINTER(dbl), i64, dbl, vp, C.POINTER(i32), C.POINTER(i64)]),
+        "ellhip_lowpass_feas": (i32, [vp, vp, i64, dbl, vp, C.POINTER(i32), C.POINTER(i64)]),
     }
     for name in EXPORTS:
         fn = getattr(L, name)  # AttributeError if the library does not export it

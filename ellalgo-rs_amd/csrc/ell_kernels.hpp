@@ -58,7 +58,28 @@ struct DevState {
     double kappa_in;        // snapshot of kappa taken by k_scalar_dot for k_scalar_apply
     int solve_err;          // EllStable persistent solves: nonzero if a bounded flag wait timed out
     int npend;              // deferred mode: number of rank-1 updates recorded but not yet applied to Q
+    // device-resident cutting-plane loops (lowpass_kernels.hpp; src/cutting_plane.rs:205-227,286-313)
+    int stop;               // why the loop halted: 0 running, 1 cut not Success, 2 tsq < tol, 3 oracle: feasible
+    double tol;             // Options::tolerance; negative = no tolerance test (plain queues)
+    long long niter;        // iterations completed without stopping = the `niter` the reference returns
 };
+constexpr int STOP_NONE = 0, STOP_STATUS = 1, STOP_TOL = 2, STOP_FEASIBLE = 3;
+
+// Queue-mode bookkeeping of one cut (lead thread of the scalar stage): the loop test of
+// src/cutting_plane.rs:222,308 `status != Success || tsq < tolerance`, evaluated on the device so
+// that a whole batch of iterations can be enqueued without a host round trip.
+__device__ __forceinline__ void queue_bookkeeping(DevState* st, int status, double tsq, int queue_mode) {
+    if (!queue_mode) return;
+    if (status != 0) {
+        st->halted = 1;
+        st->stop = STOP_STATUS;
+    } else if (tsq < st->tol) {
+        st->halted = 1;  // this cut's shrink still has to be applied: see lowpass driver / DevState.apply
+        st->stop = STOP_TOL;
+    } else {
+        st->niter += 1;
+    }
+}
 
 // Deferred rank-1 updates ("lazy shrink").  Instead of rewriting Q after every cut, up to MAXPEND
 // updates are kept as pairs (c_j = sigma_j/omega_j, v_j = the gt of that cut):
@@ -620,8 +641,8 @@ __global__ __launch_bounds__(256) void k_scalar_apply(long long n, const double*
                 st->apply = 1;
             } else {
                 st->apply = 0;  // :107-109  Q, xc, kappa untouched
-                if (queue_mode) st->halted = 1;
             }
+            queue_bookkeeping(st, status, tsq, queue_mode);
             if (q_status) {
                 *q_status = status;
                 *q_tsq = tsq;
@@ -739,8 +760,8 @@ __global__ __launch_bounds__(256) void k_scalar_apply_def(long long n, const dou
                 st->npend = slot + 1;
             } else {
                 st->apply = 0;  // :107-109
-                if (queue_mode) st->halted = 1;
             }
+            queue_bookkeeping(st, status, tsq, queue_mode);
             if (q_status) {
                 *q_status = status;
                 *q_tsq = tsq;
@@ -823,8 +844,8 @@ __global__ __launch_bounds__(1024) void k_scalar(long long n, const double* __re
             st->apply = 1;
         } else {
             st->apply = 0;  // :107-109  Q, xc, kappa untouched
-            if (queue_mode) st->halted = 1;
         }
+        queue_bookkeeping(st, status, tsq, queue_mode);
         if (q_status) {
             *q_status = status;
             *q_tsq = tsq;

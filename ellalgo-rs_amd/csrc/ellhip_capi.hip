@@ -17,7 +17,9 @@
 #include <cstddef>
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
 #include <cstring>
+#include <memory>
 #include <new>
 #include <string>
 #include <vector>
@@ -57,7 +59,7 @@ int env_int(const char* name, int dflt) {
     return (s && *s) ? atoi(s) : dflt;
 }
 
-enum : int { CLS_GEMV = 0, CLS_SCALAR = 1, CLS_RANK1 = 2, CLS_ST_FWD = 3, CLS_ST_BWD = 4, CLS_ST_FACTOR = 5, CLS_FUSED = 6, CLS_APPLY = 7, CLS_APPLY_GEMV = 8, CLS_SYMV = 9, CLS_SYMV_REDUCE = 10 };
+enum : int { CLS_GEMV = 0, CLS_SCALAR = 1, CLS_RANK1 = 2, CLS_ST_FWD = 3, CLS_ST_BWD = 4, CLS_ST_FACTOR = 5, CLS_FUSED = 6, CLS_APPLY = 7, CLS_APPLY_GEMV = 8, CLS_SYMV = 9, CLS_SYMV_REDUCE = 10, CLS_LP_SCAN = 11, CLS_LP_FINAL = 12 };
 
 struct Shape {
     int rw = 0, unr = 0, nt = 0;
@@ -612,6 +614,7 @@ int write_state(ellhip_space* s) {
     st.tsq = s->tsq;
     st.scale = 1.0;
     st.status = ELLHIP_SUCCESS;
+    st.tol = -1.0;
     *s->h_result = st;
     HIPCHK(hipMemcpyAsync(s->d_st, s->h_result, sizeof(DevState), hipMemcpyHostToDevice, s->stream));
     HIPCHK(hipStreamSynchronize(s->stream));
@@ -1207,6 +1210,7 @@ int ellhip_queue_results(ellhip_space* s, int32_t* status_out, double* tsq_out) 
     // a halted queue stays halted until its results have been read; then direct updates work again
     if (s->h_result->halted) {
         s->h_result->halted = 0;
+        s->h_result->stop = STOP_NONE;
         HIPCHK(hipMemcpyAsync(s->d_st, s->h_result, sizeof(DevState), hipMemcpyHostToDevice, s->stream));
         HIPCHK(hipStreamSynchronize(s->stream));
         drop_prime(s);  // whatever was primed beyond the failing cut never ran
@@ -1253,3 +1257,5 @@ int ellhip_profile_read(ellhip_space* s, double* ms_out, int64_t* count_out) {
 }
 
 }  // extern "C"
+
+#include "lowpass_capi.inc.hpp"

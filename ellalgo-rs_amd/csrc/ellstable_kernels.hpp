@@ -438,9 +438,12 @@ __global__ __launch_bounds__(1024) void k_st_mid(double* __restrict__ M, long lo
     __shared__ int bc_status;
     const int tid = threadIdx.x;
     if (st->halted) {
-        if (tid == 0 && q_status) {
-            *q_status = ST_UNKNOWN;
-            *q_tsq = st->tsq;
+        if (tid == 0) {
+            st->apply = 0;  // a tolerance stop leaves apply = 1 for the update that triggered it only
+            if (q_status) {
+                *q_status = ST_UNKNOWN;
+                *q_tsq = st->tsq;
+            }
         }
         return;
     }
@@ -484,8 +487,8 @@ __global__ __launch_bounds__(1024) void k_st_mid(double* __restrict__ M, long lo
             st->apply = 1;
         } else {
             st->apply = 0;  // :88-90 (the scratch triangle has already been rewritten, as in the reference)
-            if (queue_mode) st->halted = 1;
         }
+        queue_bookkeeping(st, status, tsq, queue_mode);
         if (q_status) {
             *q_status = status;
             *q_tsq = tsq;

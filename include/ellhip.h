@@ -204,8 +204,9 @@ int ellhip_synchronize(ellhip_space *s);
  * 2 = rank-1 pass, 3 = EllStable forward, 4 = EllStable backward, 5 = EllStable factor update,
  * 6 = fused pass (rank-1 of cut k + GEMV of cut k+1), 7 = deferred apply pass (8 recorded updates),
  * 8 = deferred apply pass fused with the next GEMV, 9 = symmetric GEMV pass (lower triangle only,
- * 4 n^2 bytes; deferred mode on an unsharded handle), 10 = the partial-sum reduction that follows it. */
-#define ELLHIP_NKERNEL_CLASSES 11
+ * 4 n^2 bytes; deferred mode on an unsharded handle), 10 = the partial-sum reduction that follows it,
+ * 11 = LowpassOracle scan (ellhip_lowpass.h), 12 = LowpassOracle finish (cut assembly). */
+#define ELLHIP_NKERNEL_CLASSES 13
 int ellhip_profile_enable(ellhip_space *s, int flag);
 int ellhip_profile_read(ellhip_space *s, double *ms_out, int64_t *count_out);
 

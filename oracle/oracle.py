@@ -20,9 +20,8 @@ CUT_BIAS, CUT_CENTRAL, CUT_Q = 0, 1, 2
 
 def build(force: bool = False) -> str:
     """Compile the oracle with gcc (oracle/Makefile)."""
-    src = os.path.join(_HERE, "ell_oracle.c")
-    stale = (not os.path.exists(_LIB_PATH)) or os.path.getmtime(_LIB_PATH) < max(
-        os.path.getmtime(src), os.path.getmtime(os.path.join(_HERE, "ell_oracle.h")))
+    srcs = [os.path.join(_HERE, f) for f in ("ell_oracle.c", "ell_oracle.h", "lowpass_oracle.c", "lowpass_oracle.h")]
+    stale = (not os.path.exists(_LIB_PATH)) or os.path.getmtime(_LIB_PATH) < max(os.path.getmtime(f) for f in srcs)
     if force or stale:
         subprocess.check_call(["make", "-C", _HERE, "-B", "libell_oracle.so"],
                               stdout=subprocess.DEVNULL)
@@ -33,6 +32,14 @@ class _Calc(C.Structure):
     _fields_ = [("n_f", C.c_double), ("n_plus_1", C.c_double), ("half_n", C.c_double),
                 ("inv_n", C.c_double), ("cst1", C.c_double), ("cst2", C.c_double),
                 ("use_parallel_cut", C.c_int)]
+
+
+class _Lowpass(C.Structure):
+    _fields_ = [("more_alt", C.c_int), ("idx1", C.c_int), ("spectrum", C.POINTER(C.c_double)),
+                ("ndim", C.c_int64), ("mdim", C.c_int64), ("nwpass", C.c_int), ("nwstop", C.c_int),
+                ("lp_sq", C.c_double), ("up_sq", C.c_double), ("sp_sq", C.c_double),
+                ("idx2", C.c_int), ("idx3", C.c_int), ("fmax", C.c_double), ("kmax", C.c_int),
+                ("rows_visited", C.c_int64)]
 
 
 _lib = None
@@ -85,6 +92,23 @@ def lib():
         L.orc_ellstable_set_corrected.argtypes = [C.c_void_p, C.c_int]
         L.orc_rows_gemv.argtypes = [C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_rows_gemv.restype = None
+        L.orc_lowpass_new.argtypes = [C.c_int64] + [C.c_double] * 5
+        L.orc_lowpass_new.restype = C.POINTER(_Lowpass)
+        L.orc_lowpass_free.argtypes = [C.POINTER(_Lowpass)]
+        L.orc_lowpass_free.restype = None
+        L.orc_lowpass_case.argtypes = [C.c_int, C.c_double * 5]
+        L.orc_lowpass_case.restype = None
+        ip = C.POINTER(C.c_int)
+        L.orc_lowpass_assess_feas.argtypes = [C.POINTER(_Lowpass), C.c_void_p, C.c_void_p, _dp, ip, _dp]
+        L.orc_lowpass_assess_feas.restype = C.c_int
+        L.orc_lowpass_assess_optim.argtypes = [C.POINTER(_Lowpass), C.c_void_p, _dp, C.c_void_p, _dp, ip, _dp, ip]
+        L.orc_lowpass_assess_optim.restype = C.c_int
+        L.orc_lowpass_cutting_plane_optim.argtypes = [C.POINTER(_Lowpass), C.c_int, C.c_void_p, _dp, C.c_int64,
+                                                      C.c_double, C.c_void_p, ip, ip]
+        L.orc_lowpass_cutting_plane_optim.restype = C.c_int64
+        L.orc_lowpass_cutting_plane_feas.argtypes = [C.POINTER(_Lowpass), C.c_int, C.c_void_p, C.c_int64, C.c_double,
+                                                     C.c_void_p, ip, ip]
+        L.orc_lowpass_cutting_plane_feas.restype = C.c_int64
         _lib = L
     return _lib
 
@@ -230,3 +254,79 @@ def rows_gemv(n, row0, nrows, mq_local, grad, gt_full):
     grad = _arr(grad, n)
     assert gt_full.dtype == np.float64 and gt_full.size == n and gt_full.flags.c_contiguous
     lib().orc_rows_gemv(n, row0, nrows, _ptr(mq_local), _ptr(grad), _ptr(gt_full))
+
+
+def lowpass_case(corrected: bool = False):
+    """(wpass, wstop, lp_sq, up_sq, sp_sq) of create_lowpass_case (src/oracles/lowpass_oracle.rs:153-167);
+    corrected=True: the constants the reference evidently meant (see lowpass_oracle.h)."""
+    out = (C.c_double * 5)()
+    lib().orc_lowpass_case(int(corrected), out)
+    return tuple(out)
+
+
+class OracleLowpass:
+    """LowpassOracle (src/oracles/lowpass_oracle.rs) as restated by the oracle."""
+
+    def __init__(self, ndim, wpass, wstop, lp_sq, up_sq, sp_sq):
+        self.n = int(ndim)
+        self.p = lib().orc_lowpass_new(self.n, wpass, wstop, lp_sq, up_sq, sp_sq)
+        assert self.p
+
+    @classmethod
+    def create_case(cls, ndim, corrected=False):
+        return cls(ndim, *lowpass_case(corrected))
+
+    def __del__(self):
+        p, self.p = getattr(self, "p", None), None
+        if p and _lib is not None:
+            _lib.orc_lowpass_free(p)
+
+    @property
+    def s(self):
+        return self.p.contents
+
+    @property
+    def spectrum(self):
+        return np.ctypeslib.as_array(self.s.spectrum, shape=(int(self.s.mdim), self.n))
+
+    def state(self):
+        c = self.s
+        return dict(more_alt=c.more_alt, idx1=c.idx1, idx2=c.idx2, idx3=c.idx3, kmax=c.kmax, nwpass=c.nwpass,
+                    nwstop=c.nwstop, fmax=c.fmax, sp_sq=c.sp_sq)
+
+    def assess_feas(self, x):
+        """None, or (grad, (beta0, beta1 or None))"""
+        x = _arr(x, self.n)
+        g = np.empty(self.n)
+        b0, b1, h = C.c_double(), C.c_double(), C.c_int()
+        if not lib().orc_lowpass_assess_feas(self.p, _ptr(x), _ptr(g), C.byref(b0), C.byref(h), C.byref(b1)):
+            return None
+        return g, (b0.value, b1.value if h.value else None)
+
+    def assess_optim(self, x, gamma):
+        """((grad, (beta0, beta1 or None)), shrunk, gamma)"""
+        x = _arr(x, self.n)
+        g = np.empty(self.n)
+        b0, b1, h, sh, gm = C.c_double(), C.c_double(), C.c_int(), C.c_int(), C.c_double(gamma)
+        rc = lib().orc_lowpass_assess_optim(self.p, _ptr(x), C.byref(gm), _ptr(g), C.byref(b0), C.byref(h),
+                                            C.byref(b1), C.byref(sh))
+        if rc < 0:
+            raise IndexError("feasible point without a stopband maximum")
+        return (g, (b0.value, b1.value if h.value else None)), bool(sh.value), gm.value
+
+    def cutting_plane_optim(self, space, gamma, max_iters, tol):
+        """(x_best or None, niter, gamma, last_status) -- src/cutting_plane.rs:286-313"""
+        kind = 0 if isinstance(space, OracleEll) else 1
+        xb = np.zeros(self.n)
+        hb, ls, gm = C.c_int(), C.c_int(), C.c_double(gamma)
+        niter = lib().orc_lowpass_cutting_plane_optim(self.p, kind, space.h, C.byref(gm), int(max_iters), float(tol),
+                                                      _ptr(xb), C.byref(hb), C.byref(ls))
+        return (xb if hb.value else None), int(niter), gm.value, ls.value
+
+    def cutting_plane_feas(self, space, max_iters, tol):
+        kind = 0 if isinstance(space, OracleEll) else 1
+        xb = np.zeros(self.n)
+        hb, ls = C.c_int(), C.c_int()
+        niter = lib().orc_lowpass_cutting_plane_feas(self.p, kind, space.h, int(max_iters), float(tol), _ptr(xb),
+                                                     C.byref(hb), C.byref(ls))
+        return (xb if hb.value else None), int(niter), ls.value

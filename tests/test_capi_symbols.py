@@ -11,9 +11,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def declared_functions():
-    src = open(os.path.join(ROOT, "include", "ellhip.h")).read()
-    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    return sorted(set(re.findall(r"\b(ellhip_[a-z0-9_]+)\s*\(", src)))
+    names = set()
+    for header in ("ellhip.h", "ellhip_lowpass.h"):
+        src = open(os.path.join(ROOT, "include", header)).read()
+        src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+        names.update(re.findall(r"\b(ellhip_[a-z0-9_]+)\s*\(", src))
+    return sorted(names)
 
 
 def test_header_declares_what_the_binding_lists():
@@ -48,6 +51,10 @@ def test_no_device_means_loud_failure_not_fallback():
         pkg.Ell.new_with_scalar(1.0, np.zeros(4))
     with pytest.raises(pkg.capi.EllHipError):
         pkg.EllStable.new_with_scalar(1.0, np.zeros(4))
+    o = C.c_void_p()
+    assert lib.ellhip_lowpass_create(C.byref(o), 8, 0.12, 0.2, 0.9, 1.1, 0.01, None, -1) == pkg.capi.E_NODEVICE
+    with pytest.raises(pkg.capi.EllHipError):
+        pkg.create_lowpass_case(8)
 
 
 def test_product_package_never_imports_the_oracle():
@@ -58,6 +65,6 @@ def test_product_package_never_imports_the_oracle():
         for f in files:
             if f.endswith((".py", ".hpp", ".hip", ".h", ".cpp")):
                 text = open(os.path.join(base, f), errors="replace").read()
-                if re.search(r"(from|import)\s+oracle\b|ell_oracle\.h|libell_oracle", text):
+                if re.search(r"(from|import)\s+oracle\b|ell_oracle\.h|lowpass_oracle\.h|libell_oracle", text):
                     offenders.append(os.path.join(base, f))
     assert not offenders, offenders
