@@ -46,8 +46,135 @@ WORKLOADS = {
 }
 
 
+# the reference's large-n caller of the path (LowpassOracle + cutting_plane_optim), run as
+# a device-resident loop.  Not the headline metric: `--workload lowpass-n4096` prints its own JSON line.
+LOWPASS_WORKLOADS = {"lowpass-n4096": 4096, "lowpass-n2048": 2048, "lowpass-n1024": 1024, "lowpass-n256": 256}
+
+
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
+
+
+def lowpass_bench(args, real_stdout) -> None:
+    """cutting_plane_optim(LowpassOracle, Ell) iterations/s with everything on the device
+    (include/ellhip_lowpass.h), the oracle's scan priced against the HBM roofline with the rows the
+    reference's walk visits as algorithmic bytes, and the CPU oracle loop timed on the first iterations."""
+    import torch
+    if args.gpus != 1 or int(os.environ.get("WORLD_SIZE", "1")) != 1:
+        raise SystemExit("the device-resident loop does not shard: replicas only (run it with --gpus 1)")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device: the engine has no CPU path")
+    import ellalgo_rs_amd as pkg
+    n = LOWPASS_WORKLOADS[args.workload]
+    K, W, P = args.steps, args.warmup, args.profile_steps
+    c = pkg.lowpass_case_constants(corrected=True)
+    kappa0 = 40.0
+
+    def fresh():
+        t0 = time.perf_counter()
+        o = pkg.LowpassOracle(n, *c)
+        sp = pkg.Ell.new_with_scalar(kappa0, np.zeros(n))
+        sp.defer_depth = args.defer
+        log(f"[lowpass] table {15 * n} x {n} ({15 * n * n * 8 / 2**30:.2f} GiB) + Q built in {time.perf_counter() - t0:.1f}s")
+        return o, sp
+
+    oracle, space = fresh()
+    gamma = c[4]
+    _, nit, gamma = oracle.cutting_plane_optim(space, gamma, W, 0.0)
+    assert nit == W, f"warm-up stopped after {nit} iterations"
+    oracle.rows_visited(reset=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    _, nit, gamma = oracle.cutting_plane_optim(space, gamma, K, 0.0)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    assert nit == K, f"timed region stopped after {nit} iterations"
+    rows_timed = oracle.rows_visited(reset=True)
+
+    per_kernel, rows_prof = {}, 0
+    if P > 0:
+        space.profile_enable(True)
+        _, nit, gamma = oracle.cutting_plane_optim(space, gamma, P, 0.0)
+        assert nit == P
+        prof = space.profile_read()
+        space.profile_enable(False)
+        rows_prof = oracle.rows_visited(reset=True)
+        for name, (ms, cnt) in prof.items():
+            if cnt:
+                per_kernel[name] = {"avg_ms": ms / cnt, "launches": cnt}
+    n2 = float(n) * n
+    scan_bytes_prof = rows_prof / max(P, 1) * n * 8.0
+    alg = {"lp_scan": scan_bytes_prof, "gemv": 8.0 * n2, "symv": 4.0 * n2, "rank1": 16.0 * n2, "fused": 16.0 * n2,
+           "apply": 16.0 * n2, "apply_gemv": 16.0 * n2}
+    for name, e in per_kernel.items():
+        if name in alg:
+            e["alg_bytes"] = alg[name]
+            e["GBps"] = alg[name] / (e["avg_ms"] * 1e-3) / 1e9
+    ms_per_step = elapsed / K * 1e3
+    roofline = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None, "kernel": "k_lp_scan",
+                "byte_model": "rows the reference's walk visits (early exit at the first violated constraint) x n x 8 B; "
+                              "the device reads those rows plus at most one grid-wide round of 16-row chunks",
+                "per_kernel": per_kernel}
+    if "lp_scan" in per_kernel:
+        roofline.update({"achieved": per_kernel["lp_scan"]["GBps"], "frac": per_kernel["lp_scan"]["GBps"] / HBM_PEAK_GBS,
+                         "alg_bytes_per_launch": scan_bytes_prof, "avg_launch_ms": per_kernel["lp_scan"]["avg_ms"],
+                         "rows_visited_per_call": rows_prof / max(P, 1), "rows_in_table": 15 * n})
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            pmc = json.load(f).get(args.workload)
+        if pmc:
+            roofline["traffic"] = pmc.get("lp_scan")
+            roofline["traffic_source"] = pmc.get("source")
+    except OSError:
+        pass
+    upd_bytes = {1: 16.0, 8: 9.0}[args.defer] * n2
+    whole = rows_timed / K * n * 8.0 + upd_bytes
+    roofline["whole_iteration"] = {"alg_bytes": whole, "GBps": whole / (ms_per_step * 1e-3) / 1e9,
+                                   "frac": whole / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                   "model": f"oracle rows {rows_timed / K:.0f} x n x 8 + ellipsoid update "
+                                            f"{upd_bytes / n2:.0f}*n^2 (defer depth {args.defer}, shrink fused with the next GEMV)"}
+    out = {
+        "metric": "cutting-plane iterations/sec, LowpassOracle + Ell device-resident loop at n=%d" % n,
+        "value": K / elapsed, "unit": "iterations/s", "n_gpus": 1, "steps": K, "warmup": W,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {"workload": args.workload, "n": n, "space": "ell", "defer_depth": args.defer,
+                   "oracle": "LowpassOracle, corrected create_lowpass_case constants (parity unpinned by the reference, "
+                             "see oracle/lowpass_oracle.h)", "table_bytes": 15.0 * n2 * 8.0, "kappa0": kappa0,
+                   "gamma_after": gamma},
+        "roofline": roofline,
+    }
+    if not args.no_cpu_baseline:
+        from oracle import oracle as O
+        log("[lowpass] timing the CPU oracle loop (bounded sample) ...")
+        t0 = time.perf_counter()
+        co = O.OracleLowpass(n, *c)
+        ce = O.OracleEll.new_with_scalar(kappa0, np.zeros(n))
+        t_init = time.perf_counter() - t0
+        cg, done, t_used = c[4], 0, 0.0
+        step = 4 if n >= 2048 else 64
+        while t_used < args.cpu_budget:
+            t1 = time.perf_counter()
+            _, nit, cg, last = co.cutting_plane_optim(ce, cg, step, 0.0)
+            t_used += time.perf_counter() - t1
+            assert nit == step and last == 0
+            done += step
+        # the same first iterations on the device, from a fresh start
+        o2, s2 = fresh()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        _, nit, g2 = o2.cutting_plane_optim(s2, c[4], done, 0.0)
+        torch.cuda.synchronize()
+        t_gpu = time.perf_counter() - t1
+        assert nit == done
+        out["cpu_baseline"] = {
+            "value": done / t_used, "unit": "iterations/s", "cores": 1, "kind": "port",
+            "sample": f"first {done} iterations of the same run at n={n}: oracle/lowpass_oracle.c + oracle/ell_oracle.c, "
+                      f"1 thread, {t_used:.1f} s (+{t_init:.1f} s table init); the device runs the same {done} "
+                      f"iterations in {t_gpu * 1e3:.1f} ms ({done / t_gpu:.0f} iterations/s), gamma {g2:.6e} vs {cg:.6e}",
+            "host_cpus": os.cpu_count(), "gpu_same_sample_iterations_per_s": done / t_gpu,
+        }
+    print(json.dumps(out), file=real_stdout, flush=True)
 
 
 def cpu_baseline(n: int, variant: str, kinds, grads, b0, b1, budget_s: float = 20.0):
@@ -91,7 +218,7 @@ def main() -> None:
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default=os.environ.get("ELLHIP_BENCH_WORKLOAD", "n16384-parallel"),
-                    choices=sorted(WORKLOADS))
+                    choices=sorted(WORKLOADS) + sorted(LOWPASS_WORKLOADS))
     ap.add_argument("--profile-steps", type=int, default=40, help="extra steps with per-kernel HIP events")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
@@ -109,6 +236,9 @@ def main() -> None:
     ap.add_argument("--force-sharded", action="store_true",
                     help="run the row-partitioned (multi-GPU) code path even with one rank (rehearsal)")
     args = ap.parse_args()
+
+    if args.workload in LOWPASS_WORKLOADS:
+        return lowpass_bench(args, real_stdout)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

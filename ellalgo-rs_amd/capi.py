@@ -29,7 +29,7 @@ EXPORTS = [
     "ellhip_last_error", "ellhip_version",
     # include/ellhip_lowpass.h
     "ellhip_lowpass_create", "ellhip_lowpass_destroy", "ellhip_lowpass_assess_feas", "ellhip_lowpass_assess_optim",
-    "ellhip_lowpass_state", "ellhip_lowpass_get_spectrum", "ellhip_lowpass_optim", "ellhip_lowpass_feas",
+    "ellhip_lowpass_state", "ellhip_lowpass_rows_visited", "ellhip_lowpass_get_spectrum", "ellhip_lowpass_optim", "ellhip_lowpass_feas",
 ]
 
 
@@ -101,6 +101,7 @@ def load():
         "ellhip_lowpass_assess_optim": (i32, [vp, vp, C.POINTER(dbl), vp, C.POINTER(dbl), C.POINTER(i32),
                                               C.POINTER(dbl), C.POINTER(i32)]),
         "ellhip_lowpass_state": (i32, [vp, vp, vp]),
+        "ellhip_lowpass_rows_visited": (i64, [vp, i32]),
         "ellhip_lowpass_get_spectrum": (i32, [vp, vp]),
         "ellhip_lowpass_optim": (i32, [vp, vp, C.POINTER(dbl), i64, dbl, vp, C.POINTER(i32), C.POINTER(i64)]),
         "ellhip_lowpass_feas": (i32, [vp, vp, i64, dbl, vp, C.POINTER(i32), C.POINTER(i64)]),

@@ -14,6 +14,7 @@ struct ellhip_lowpass {
     int device = 0;
     LpParams P{};
     bool nt = false;
+    bool wide = false;  // k_lp_scan_wide (4 positions per workgroup step) instead of k_lp_scan (16)
     unsigned grid = 1;
     double* d_A = nullptr;
     double* d_vals = nullptr;
@@ -50,15 +51,19 @@ int lp_issue(ellhip_lowpass* o, hipStream_t st, const double* x_dev, int mode, D
         std::unique_ptr<ProfScope> ps;
         if (prof) ps.reset(new ProfScope(prof, CLS_LP_SCAN));
         const bool vec2 = (o->P.n % 2) == 0;
-        if (vec2 && o->nt)
-            hipLaunchKernelGGL((k_lp_scan<2, true>), dim3(o->grid), dim3(256), 0, st, (const double*)o->d_A, o->P, x_dev,
-                               o->d_vals, o->d_ls, halted);
-        else if (vec2)
-            hipLaunchKernelGGL((k_lp_scan<2, false>), dim3(o->grid), dim3(256), 0, st, (const double*)o->d_A, o->P, x_dev,
-                               o->d_vals, o->d_ls, halted);
-        else
-            hipLaunchKernelGGL((k_lp_scan<1, false>), dim3(o->grid), dim3(256), 0, st, (const double*)o->d_A, o->P, x_dev,
-                               o->d_vals, o->d_ls, halted);
+#define LP_LAUNCH(KERNEL)                                                                                          \
+    hipLaunchKernelGGL(KERNEL, dim3(o->grid), dim3(256), 0, st, (const double*)o->d_A, o->P, x_dev, o->d_vals, \
+                       o->d_ls, halted)
+        if (o->wide) {
+            if (vec2 && o->nt) LP_LAUNCH((k_lp_scan_wide<2, true>));
+            else if (vec2) LP_LAUNCH((k_lp_scan_wide<2, false>));
+            else LP_LAUNCH((k_lp_scan_wide<1, false>));
+        } else {
+            if (vec2 && o->nt) LP_LAUNCH((k_lp_scan<2, true>));
+            else if (vec2) LP_LAUNCH((k_lp_scan<2, false>));
+            else LP_LAUNCH((k_lp_scan<1, false>));
+        }
+#undef LP_LAUNCH
         HIPCHK(hipGetLastError());
     }
     std::unique_ptr<ProfScope> ps;
@@ -245,7 +250,9 @@ int ellhip_lowpass_create(ellhip_lowpass** out, int64_t ndim, double wpass, doub
     o->P.up_sq = up_sq;
     const double a_bytes = (double)mdim * (double)o->P.ld * 8.0;
     o->nt = a_bytes > 200.0 * 1024 * 1024;  // same rule as the Q stream: larger than the Infinity Cache share
-    const long long nchunks = (mdim + LP_CHUNK - 1) / LP_CHUNK;
+    o->wide = env_int("ELLHIP_LP_WIDE", ndim >= LP_WIDE_N ? 1 : 0) != 0;
+    const long long per_step = o->wide ? LP_RPW : LP_CHUNK;
+    const long long nchunks = (mdim + per_step - 1) / per_step;
     o->grid = (unsigned)(nchunks < 1024 ? nchunks : 1024);
     o->grid = (unsigned)env_int("ELLHIP_LP_GRID", (int)o->grid);
     if (o->grid < 1) o->grid = 1;
@@ -363,6 +370,19 @@ int ellhip_lowpass_state(ellhip_lowpass* o, int32_t* ints7, double* doubles2) {
         doubles2[1] = o->h_ls->sp_sq;
     }
     return 0;
+}
+
+int64_t ellhip_lowpass_rows_visited(ellhip_lowpass* o, int reset) {
+    if (!o) return fail(ELLHIP_E_INVALID, "NULL handle");
+    DeviceGuard guard(o->device);
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(o->h_ls, o->d_ls, sizeof(LpState), hipMemcpyDeviceToHost));
+    const long long total = o->h_ls->rows_total;
+    if (reset) {
+        o->h_ls->rows_total = 0;
+        HIPCHK(hipMemcpy(o->d_ls, o->h_ls, sizeof(LpState), hipMemcpyHostToDevice));
+    }
+    return total;
 }
 
 int ellhip_lowpass_get_spectrum(ellhip_lowpass* o, double* out) {

@@ -46,6 +46,7 @@ struct LpState {
     int error;             // 1: feasible point but kmax = -1 (the reference would index spectrum[-1] and panic)
     double fmax;           // :19
     double sp_sq;          // :15 (and the caller's gamma in assess_optim)
+    long long rows_total;  // rows the reference's walk visits, summed over calls (work measure for the roofline)
 };
 
 constexpr unsigned LP_NONE = 0xffffffffu;
@@ -129,6 +130,76 @@ __global__ __launch_bounds__(256) void k_lp_scan(const double* __restrict__ A, L
                 vals[rows[r]] = val;
                 if (lp_violates(P, sp_sq, bands[r], val)) atomicMin(&ls->pos, p0 + (unsigned)(wave * LP_RPW + r));
             }
+        }
+    }
+}
+
+// Long rows (n >= LP_WIDE_N): the 4 waves of a workgroup split the COLUMNS of LP_RPW rows (16 B per lane,
+// 4 KiB of each row per step), so a workgroup step covers 4 visiting positions instead of 16 and takes a
+// quarter of the time: the early exit is four times finer grained (a grid-wide round of chunks is what a
+// walk that stops early pays on top of the rows it needs).  Row sums: per thread ascending columns, xor
+// butterfly, ((w0+w1)+w2)+w3 -- the shape of the GEMV pass.
+constexpr long long LP_WIDE_N = 1024;
+
+template <int VEC, bool NT>
+__global__ __launch_bounds__(256) void k_lp_scan_wide(const double* __restrict__ A, LpParams P,
+                                                      const double* __restrict__ x, double* __restrict__ vals,
+                                                      LpState* __restrict__ ls, const int* __restrict__ halted) {
+    if (*halted) return;
+    using V = typename VecT<VEC>::type;
+    __shared__ double red[4][LP_RPW];
+    __shared__ unsigned s_pos;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int idx1 = ls->idx1, idx2 = ls->idx2, idx3 = ls->idx3;
+    const double sp_sq = ls->sp_sq;
+    const unsigned total = (unsigned)P.mdim;
+    const unsigned nchunks = (total + LP_RPW - 1) / LP_RPW;
+    for (unsigned c = blockIdx.x; c < nchunks; c += gridDim.x) {
+        const unsigned p0 = c * LP_RPW;
+        if (tid == 0) s_pos = __hip_atomic_load(&ls->pos, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();  // one decision per workgroup (also fences the reuse of red[])
+        if (s_pos < p0) return;
+        const double* rowp[LP_RPW];
+        int rows[LP_RPW], bands[LP_RPW];
+        bool valid[LP_RPW];
+#pragma unroll
+        for (int r = 0; r < LP_RPW; ++r) {
+            const unsigned p = p0 + (unsigned)r;
+            valid[r] = p < total;
+            rows[r] = lp_row_of(P, idx1, idx2, idx3, valid[r] ? p : p0, bands[r]);
+            rowp[r] = A + (long long)rows[r] * P.ld;
+        }
+        double acc[LP_RPW];
+#pragma unroll
+        for (int r = 0; r < LP_RPW; ++r) acc[r] = 0.0;
+#pragma unroll 2
+        for (long long j = (long long)VEC * tid; j < P.n; j += 256 * VEC) {
+            const V xv = *reinterpret_cast<const V*>(x + j);
+#pragma unroll
+            for (int r = 0; r < LP_RPW; ++r) {
+                const V av = ld_stream<NT, V>(rowp[r] + j);
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) acc[r] += VecT<VEC>::get(av, e) * VecT<VEC>::get(xv, e);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < LP_RPW; ++r) {
+            const double w = wave_allreduce_sum(acc[r]);
+            if (lane == 0) red[wave][r] = w;
+        }
+        __syncthreads();
+        if (tid < LP_RPW && valid[tid]) {
+            const double val = ((red[0][tid] + red[1][tid]) + red[2][tid]) + red[3][tid];
+            // rows[] / bands[] are indexed with a compile-time r above; pick this thread's entry
+            int row = rows[0], band = bands[0];
+#pragma unroll
+            for (int r = 1; r < LP_RPW; ++r)
+                if (tid == r) {
+                    row = rows[r];
+                    band = bands[r];
+                }
+            vals[row] = val;
+            if (lp_violates(P, sp_sq, band, val)) atomicMin(&ls->pos, p0 + (unsigned)tid);
         }
     }
 }
@@ -290,6 +361,7 @@ __global__ __launch_bounds__(256) void k_lp_final(const double* __restrict__ A, 
         ls->has_cut = has_cut;
         if (copy_x) ls->has_best = 1;
         ls->pos = LP_NONE;  // ready for the next scan
+        ls->rows_total += (pos == LP_NONE) ? (long long)P.mdim : (long long)pos + 1;
         *cp = c;
         sh_row = row;
         sh_sign = sign;

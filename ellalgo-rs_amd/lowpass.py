@@ -58,6 +58,10 @@ class LowpassOracle:
         return dict(more_alt=int(ints[0]), idx1=int(ints[1]), idx2=int(ints[2]), idx3=int(ints[3]), kmax=int(ints[4]),
                     nwpass=int(ints[5]), nwstop=int(ints[6]), fmax=float(dbl[0]), sp_sq=float(dbl[1]))
 
+    def rows_visited(self, reset: bool = False) -> int:
+        """rows the reference's walk visits, summed over calls (work measure)"""
+        return int(capi.check(self._lib.ellhip_lowpass_rows_visited(self._h, int(reset)), "ellhip_lowpass_rows_visited"))
+
     @property
     def spectrum(self) -> np.ndarray:
         out = np.empty((15 * self.n, self.n), dtype=np.float64)

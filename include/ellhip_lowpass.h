@@ -51,6 +51,10 @@ int ellhip_lowpass_assess_optim(ellhip_lowpass *o, const double *x, double *gamm
  * doubles2 = {fmax, sp_sq}.  After a call that returned a cut from the passband, fmax / kmax keep
  * their previous values; otherwise they cover the stopband rows the walk visited (:86-103). */
 int ellhip_lowpass_state(ellhip_lowpass *o, int32_t *ints7, double *doubles2);
+/* Work measure: number of rows the reference's walk visits (row.x products it computes), summed over
+ * all calls since creation / the last reset; negative = failure.  The device reads these rows plus at
+ * most one grid-wide round of 16-row chunks per call. */
+int64_t ellhip_lowpass_rows_visited(ellhip_lowpass *o, int reset);
 /* The table, row-major (15*ndim) x ndim (the `spectrum` field). */
 int ellhip_lowpass_get_spectrum(ellhip_lowpass *o, double *out);
 

@@ -84,6 +84,21 @@ def test_early_exit_across_grid_rounds(gpu, orc, grid, monkeypatch):
         compare_call(dev_o, cpu_o, x, f"grid={grid} call {it}")
 
 
+@pytest.mark.parametrize("n,grid", [(9, 2), (33, 5), (64, 1), (64, 16), (128, 1024)])
+def test_wide_scan_kernel_at_small_sizes(gpu, orc, n, grid, monkeypatch):
+    """k_lp_scan_wide (the n >= 1024 kernel: 4 positions per workgroup step, columns split over the waves)
+    forced on where the oracle is cheap, over several rounds of chunks."""
+    monkeypatch.setenv("ELLHIP_LP_WIDE", "1")
+    monkeypatch.setenv("ELLHIP_LP_GRID", str(grid))
+    rng = np.random.default_rng(grid + n)
+    for cset in ("very_loose", "loose", "corrected"):
+        c = CONSTANT_SETS[cset]
+        dev_o = gpu.LowpassOracle(n, *c)
+        cpu_o = orc.OracleLowpass(n, *c)
+        for it, x in enumerate(probe_points(n, rng, 40)):
+            compare_call(dev_o, cpu_o, x, f"wide {cset} n={n} grid={grid} call {it}")
+
+
 @pytest.mark.parametrize("n", [1024, 2048])
 def test_assess_optim_large(gpu, orc, n):
     c = CONSTANT_SETS["corrected"]

@@ -12,7 +12,7 @@ for path in sys.argv[1:]:
     r = d["roofline"]
     pk = {k: (round(v["avg_ms"], 4), round(v.get("GBps", 0))) for k, v in r["per_kernel"].items()}
     print(f'{d["config"]["workload"]:18s} {d["config"].get("schedule","")[:9]:9s} d{d["config"].get("defer_depth",1)} gpus={d["n_gpus"]} upd/s={d["value"]:9.1f} '
-          f'ms={d["ms_per_step"]:.4f} dom={r.get("kernel")} frac={r.get("frac", 0):.3f} whole={r["whole_update"]["frac"]:.3f} {pk}')
+          f'ms={d["ms_per_step"]:.4f} dom={r.get("kernel")} frac={r.get("frac", 0):.3f} whole={(r.get("whole_update") or r.get("whole_iteration"))["frac"]:.3f} {pk}')
     for o in d.get("other_schedules", []):
         pk = {k: (round(v["avg_ms"], 4), round(v.get("GBps", 0))) for k, v in o["per_kernel"].items()}
         print(f'{"":18s} {o["schedule"][:9]:9s} d{o["defer_depth"]}        upd/s={o["updates_per_s"]:9.1f} ms={o["ms_per_step"]:.4f} '
@@ -20,5 +20,7 @@ for path in sys.argv[1:]:
     if "host_call_path" in d:
         print(f'{"":18s} host-call path {d["host_call_path"]["updates_per_s"]:.1f} upd/s', end="")
     if "cpu_baseline" in d:
-        print(f'   cpu {d["cpu_baseline"]["value"]:.3f} upd/s', end="")
+        print(f'   cpu {d["cpu_baseline"]["value"]:.3f} /s', end="")
+        if "gpu_same_sample_iterations_per_s" in d["cpu_baseline"]:
+            print(f'   (device on the same sample {d["cpu_baseline"]["gpu_same_sample_iterations_per_s"]:.1f} /s)', end="")
     print()
