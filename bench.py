@@ -88,7 +88,9 @@ def lowpass_bench(args, real_stdout) -> None:
     _, nit, gamma = oracle.cutting_plane_optim(space, gamma, K, 0.0)
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    assert nit == K, f"timed region stopped after {nit} iterations"
+    if nit != K:
+        raise SystemExit(f"the run reached its natural end after {W + nit} iterations (no further improvement of gamma "
+                         f"is possible: NoSoln): use fewer --steps for {args.workload}")
     rows_timed = oracle.rows_visited(reset=True)
 
     per_kernel, rows_prof = {}, 0

@@ -297,3 +297,46 @@ def test_loop_argument_checks(gpu):
     g = gpu.Ell.new_with_scalar(1.0, np.zeros(16))
     xb, niter, gamma = dev_o.cutting_plane_optim(g, 0.1, 0, 1e-8)
     assert xb is None and niter == 0 and gamma == 0.1
+
+
+# ---- through the C++ host mirror (ellalgo-rs_amd/host/ellhip/lowpass_oracle.hpp) ---------------------------
+
+def test_cpp_host_mirror_three_drivers_agree_with_the_oracle_loop(gpu, orc):
+    import cpp_build
+    exe = cpp_build.build_runner("lowpass_runner.cpp", "hip")
+    res = cpp_build.run_json_lines(exe)
+    _, _, lp_sq, up_sq, sp_sq = orc.lowpass_case(False)
+    # the reference's own runs: (None, 0) with gamma untouched
+    for case, g0 in [("run_lowpass_host", sp_sq), ("run_lowpass_device", sp_sq), ("stress_high_dimension_device", sp_sq),
+                     ("stress_many_iterations_device", 1e-12)]:
+        r = res[case]
+        assert r["niter"] == 0 and not r["has_x"] and r["gamma"] == g0, case
+    r = res["oracle_zero"]  # assess_feas(0): row 0 negated, ParallelCut(lp_sq, Some(up_sq))
+    assert r["has_x"] and r["gamma"] == lp_sq and r["tsq"] == up_sq
+    assert r["x"] == [-1.0] + [-2.0] * 31
+    assert res["oracle_direct"]["has_x"] and math.isfinite(res["oracle_direct"]["gamma"])
+    # corrected constants: 200 iterations through the three drivers vs the oracle loop
+    c = CONSTANT_SETS["corrected"]
+    cpu_o, o, xbo, nitero, gammao, last = cpu_lockstep(orc, "ell", 32, c, 40.0, 200, False)
+    tol = max(1e-10, 100.0 * sensitivity(orc, "ell", 32, c, 40.0, 200))
+    for case in ("corrected_host", "corrected_pipelined", "corrected_device"):
+        r = res[case]
+        assert r["niter"] == nitero == 200 and r["has_x"] == (xbo is not None), case
+        assert abs(r["gamma"] - gammao) <= tol * gammao, case
+        assert abs(r["tsq"] - o.tsq) <= tol * o.tsq, case
+        if xbo is not None:
+            assert rel_inf(np.array(r["x"]), xbo) <= tol, case
+    # the three drivers issue the same arithmetic on the device: identical bits
+    assert res["corrected_host"]["x"] == res["corrected_device"]["x"]
+    assert res["corrected_host"]["tsq"] == res["corrected_device"]["tsq"]
+    assert res["corrected_pipelined"]["tsq"] == res["corrected_device"]["tsq"]
+    # feasibility loop
+    cl = CONSTANT_SETS["loose"]
+    fo = orc.OracleLowpass(32, *cl)
+    fe = orc.OracleEll.new_with_scalar(40.0, np.zeros(32))
+    xo, nitero, last = fo.cutting_plane_feas(fe, 2000, 1e-14)
+    for case in ("feas_host", "feas_device"):
+        r = res[case]
+        assert r["niter"] == nitero and r["has_x"] == (xo is not None), case
+        assert rel_inf(np.array(r["x"]), xo) <= 1e-8
+    assert res["feas_host"]["x"] == res["feas_device"]["x"]
