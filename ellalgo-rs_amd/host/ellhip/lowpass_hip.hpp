@@ -1,4 +1,4 @@
-// lowpass_oracle.hpp -- `LowpassOracle` (src/oracles/lowpass_oracle.rs:7-167) backed by the device-side
+// lowpass_hip.hpp -- `LowpassOracle` (src/oracles/lowpass_oracle.rs:7-167) backed by the device-side
 // oracle of include/ellhip_lowpass.h, plus the device-resident forms of the two driver loops it is used
 // with.  Same constructor arguments, method names and return shapes as the reference, so it plugs into
 // the generic drivers of cutting_plane.hpp (`cutting_plane_optim(omega, space, gamma, options)`) exactly

@@ -6,7 +6,7 @@
 #include <cstdio>
 #include <string>
 
-#include "../../ellalgo-rs_amd/host/ellhip/lowpass_oracle.hpp"
+#include "../../ellalgo-rs_amd/host/ellhip/lowpass_hip.hpp"
 
 using namespace ellhip;
 

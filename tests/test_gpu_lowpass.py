@@ -299,7 +299,7 @@ def test_loop_argument_checks(gpu):
     assert xb is None and niter == 0 and gamma == 0.1
 
 
-# ---- through the C++ host mirror (ellalgo-rs_amd/host/ellhip/lowpass_oracle.hpp) ---------------------------
+# ---- through the C++ host mirror (ellalgo-rs_amd/host/ellhip/lowpass_hip.hpp) ---------------------------
 
 def test_cpp_host_mirror_three_drivers_agree_with_the_oracle_loop(gpu, orc):
     import cpp_build
