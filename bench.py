@@ -55,6 +55,101 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
+# many independent small ellipsoids (BASELINE config 1 is n = 16) in one launch.
+BATCH_WORKLOADS = {"batch-n16": (16, 65536, 8), "batch-n32": (32, 32768, 8), "batch-n64": (64, 8192, 8),
+                   "batch-n128": (128, 2048, 8)}
+
+
+def batch_bench(args, real_stdout) -> None:
+    """B ellipsoids of dimension n, K central cuts each per launch (include/ellhip_batch.h), all inputs resident
+    in HBM; value = ellipsoid updates/s summed over the batch."""
+    import torch
+    if args.gpus != 1 or int(os.environ.get("WORLD_SIZE", "1")) != 1:
+        raise SystemExit("independent ellipsoids: replicas only (run with --gpus 1)")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device: the engine has no CPU path")
+    import ellalgo_rs_amd as pkg
+    n, B, K = BATCH_WORKLOADS[args.workload]
+    S, W = args.steps, args.warmup
+    rng = np.random.default_rng(0x5EED)
+    grads = rng.standard_normal((K, B, n))
+    grads /= np.linalg.norm(grads, axis=2, keepdims=True)
+    kinds = np.full((K, B), 1, dtype=np.int32)  # update_central_cut: succeeds however small the ellipsoid gets
+    b0 = np.zeros((K, B))
+    hb1 = np.zeros((K, B), dtype=np.int32)
+    b1 = np.zeros((K, B))
+    batch = pkg.EllBatch.new_with_scalar(1.0, np.zeros((B, n)))
+    dev = torch.device("cuda", 0)
+    t = {k: torch.from_numpy(v).to(dev) for k, v in dict(kinds=kinds, grads=grads, b0=b0, hb1=hb1, b1=b1).items()}
+    status = torch.full((K, B), -1, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+
+    def launch():
+        batch.update_dev(K, t["kinds"].data_ptr(), t["grads"].data_ptr(), t["b0"].data_ptr(), t["hb1"].data_ptr(),
+                         t["b1"].data_ptr(), status.data_ptr(), None)
+
+    for _ in range(W):
+        launch()
+    batch.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(S):
+        launch()
+    batch.synchronize()
+    elapsed = time.perf_counter() - t0
+    assert bool((status == 0).all().item()), "a cut did not succeed"
+    # kernel duration with HIP events on the launch stream (torch.cuda.Event only sees torch's stream)
+    stream = torch.cuda.ExternalStream(batch._lib.ellhip_batch_stream(batch._h))
+    evs = []
+    for _ in range(min(S, 20)):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(stream)
+        launch()
+        b.record(stream)
+        evs.append((a, b))
+    batch.synchronize()
+    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
+    alg = B * (16.0 * n * n + K * (n * 8.0 + 24.0) + 16.0 * n + 32.0)
+    gbps = alg / (kern_ms * 1e-3) / 1e9
+    out = {
+        "metric": "ellipsoid updates/sec, %d independent ellipsoids of n=%d (batched engine)" % (B, n),
+        "value": S * K * B / elapsed, "unit": "updates/s", "n_gpus": 1, "steps": S, "warmup": W,
+        "ms_per_step": elapsed / S * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {"workload": args.workload, "n": n, "ellipsoids": B, "cuts_per_launch": K, "space": "ell",
+                   "cuts": "central, random unit gradients", "q_bytes_total": 8.0 * n * n * B},
+        "roofline": {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "kernel": "k_batch_update",
+                     "achieved": gbps, "frac": gbps / HBM_PEAK_GBS, "traffic": None, "alg_bytes_per_launch": alg,
+                     "avg_launch_ms": kern_ms,
+                     "byte_model": "per ellipsoid and launch: Q in + out 16*n^2, K gradients K*n*8, cut values and "
+                                   "results K*24, xc in + out 16*n: the matrix stays in LDS for the K cuts"},
+    }
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            pmc = json.load(f).get(args.workload)
+        if pmc:
+            out["roofline"]["traffic"] = pmc.get("batch")
+            out["roofline"]["traffic_source"] = pmc.get("source")
+    except OSError:
+        pass
+    if not args.no_cpu_baseline:
+        from oracle import oracle as O
+        log("[batch] timing the CPU oracle (bounded sample) ...")
+        Bs = min(B, 2048)
+        sl = (slice(None), slice(0, Bs))
+        O.ell_batch_run(kinds[sl], grads[sl], b0[sl], hb1[sl], b1[sl], want_state=False)  # warm
+        done, t_used = 0, 0.0
+        while t_used < args.cpu_budget:
+            t1 = time.perf_counter()
+            ok, _, _, _, _ = O.ell_batch_run(kinds[sl], grads[sl], b0[sl], hb1[sl], b1[sl], want_state=False)
+            t_used += time.perf_counter() - t1
+            assert ok == K * Bs
+            done += K * Bs
+        out["cpu_baseline"] = {"value": done / t_used, "unit": "updates/s", "cores": 1, "kind": "port",
+                               "sample": f"{done} updates: {Bs} of the ellipsoids x {K} cuts, repeated, oracle/ell_oracle.c "
+                                         f"orc_ell_batch_run, 1 thread, {t_used:.1f} s", "host_cpus": os.cpu_count()}
+    print(json.dumps(out), file=real_stdout, flush=True)
+
+
 def lowpass_bench(args, real_stdout) -> None:
     """cutting_plane_optim(LowpassOracle, Ell) iterations/s with everything on the device
     (include/ellhip_lowpass.h), the oracle's scan priced against the HBM roofline with the rows the
@@ -220,7 +315,7 @@ def main() -> None:
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default=os.environ.get("ELLHIP_BENCH_WORKLOAD", "n16384-parallel"),
-                    choices=sorted(WORKLOADS) + sorted(LOWPASS_WORKLOADS))
+                    choices=sorted(WORKLOADS) + sorted(LOWPASS_WORKLOADS) + sorted(BATCH_WORKLOADS))
     ap.add_argument("--profile-steps", type=int, default=40, help="extra steps with per-kernel HIP events")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
@@ -241,6 +336,8 @@ def main() -> None:
 
     if args.workload in LOWPASS_WORKLOADS:
         return lowpass_bench(args, real_stdout)
+    if args.workload in BATCH_WORKLOADS:
+        return batch_bench(args, real_stdout)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

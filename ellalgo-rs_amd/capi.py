@@ -30,6 +30,11 @@ EXPORTS = [
     # include/ellhip_lowpass.h
     "ellhip_lowpass_create", "ellhip_lowpass_destroy", "ellhip_lowpass_assess_feas", "ellhip_lowpass_assess_optim",
     "ellhip_lowpass_state", "ellhip_lowpass_rows_visited", "ellhip_lowpass_get_spectrum", "ellhip_lowpass_optim", "ellhip_lowpass_feas",
+    # include/ellhip_batch.h
+    "ellhip_batch_create", "ellhip_batch_from_space", "ellhip_batch_destroy", "ellhip_batch_update",
+    "ellhip_batch_update_dev", "ellhip_batch_synchronize", "ellhip_batch_stream", "ellhip_batch_get_xc",
+    "ellhip_batch_set_xc", "ellhip_batch_get_mq", "ellhip_batch_get_kappa", "ellhip_batch_get_tsq",
+    "ellhip_batch_size", "ellhip_batch_ndim", "ellhip_batch_set_no_defer_trick", "ellhip_batch_set_use_parallel_cut",
 ]
 
 
@@ -105,6 +110,22 @@ def load():
         "ellhip_lowpass_get_spectrum": (i32, [vp, vp]),
         "ellhip_lowpass_optim": (i32, [vp, vp, C.POINTER(dbl), i64, dbl, vp, C.POINTER(i32), C.POINTER(i64)]),
         "ellhip_lowpass_feas": (i32, [vp, vp, i64, dbl, vp, C.POINTER(i32), C.POINTER(i64)]),
+        "ellhip_batch_create": (i32, [C.POINTER(vp), i64, i64, vp, vp, vp, vp, i32]),
+        "ellhip_batch_from_space": (i32, [C.POINTER(vp), vp, i64]),
+        "ellhip_batch_destroy": (None, [vp]),
+        "ellhip_batch_update": (i32, [vp, i64, vp, vp, vp, vp, vp, vp, vp]),
+        "ellhip_batch_update_dev": (i32, [vp, i64, vp, vp, vp, vp, vp, vp, vp]),
+        "ellhip_batch_synchronize": (i32, [vp]),
+        "ellhip_batch_stream": (vp, [vp]),
+        "ellhip_batch_get_xc": (i32, [vp, vp]),
+        "ellhip_batch_set_xc": (i32, [vp, vp]),
+        "ellhip_batch_get_mq": (i32, [vp, vp]),
+        "ellhip_batch_get_kappa": (i32, [vp, vp]),
+        "ellhip_batch_get_tsq": (i32, [vp, vp]),
+        "ellhip_batch_size": (i64, [vp]),
+        "ellhip_batch_ndim": (i64, [vp]),
+        "ellhip_batch_set_no_defer_trick": (i32, [vp, i32]),
+        "ellhip_batch_set_use_parallel_cut": (i32, [vp, i32]),
     }
     for name in EXPORTS:
         fn = getattr(L, name)  # AttributeError if the library does not export it

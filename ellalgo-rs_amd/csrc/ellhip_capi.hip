@@ -1259,3 +1259,4 @@ int ellhip_profile_read(ellhip_space* s, double* ms_out, int64_t* count_out) {
 }  // extern "C"
 
 #include "lowpass_capi.inc.hpp"
+#include "batch_capi.inc.hpp"

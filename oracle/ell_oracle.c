@@ -410,3 +410,27 @@ double orc_ellstable_tsq(const orc_ellstable *e) { return e->tsq; }
 double *orc_ellstable_mq(orc_ellstable *e) { return e->mq; }
 double *orc_ellstable_xc(orc_ellstable *e) { return e->xc; }
 void orc_ellstable_set_corrected(orc_ellstable *e, int flag) { e->corrected = flag; }
+
+/* B independent Ell spaces (identity, kappa0, xc = 0), K cuts each, as a plain loop over orc_ell_update:
+ * the CPU statement of what the batched engine (include/ellhip_batch.h) does.  kinds/b0/has_b1/b1 are [K][B],
+ * grads [K][B][n]; outputs may be NULL.  Returns the number of Success cuts. */
+int64_t orc_ell_batch_run(int64_t B, int64_t n, int64_t K, const int32_t *kinds, const double *grads,
+                          const double *b0, const int32_t *has_b1, const double *b1, double kappa0,
+                          int32_t *status_out, double *mq_out, double *xc_out, double *kappa_out) {
+    int64_t ok = 0;
+    for (int64_t b = 0; b < B; ++b) {
+        orc_ell *e = orc_ell_new(n, kappa0, NULL, NULL, NULL);
+        if (!e) return -1;
+        for (int64_t k = 0; k < K; ++k) {
+            const int64_t c = k * B + b;
+            const int st = orc_ell_update(e, kinds[c], grads + c * n, b0[c], has_b1[c], b1[c]);
+            if (status_out) status_out[c] = st;
+            ok += st == ORC_SUCCESS;
+        }
+        if (mq_out) memcpy(mq_out + b * n * n, e->mq, (size_t)(n * n) * sizeof(double));
+        if (xc_out) memcpy(xc_out + b * n, e->xc, (size_t)n * sizeof(double));
+        if (kappa_out) kappa_out[b] = e->kappa;
+        orc_ell_free(e);
+    }
+    return ok;
+}

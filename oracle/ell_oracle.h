@@ -90,6 +90,12 @@ void orc_ell_set_use_parallel_cut(orc_ell *e, int flag);
 void orc_rows_gemv(int64_t n, int64_t row0, int64_t nrows, const double *mq_local,
                    const double *grad, double *gt_full);
 
+/* B independent Ell spaces (identity, kappa0, xc = 0), K cuts each: a loop over orc_ell_update.
+ * kinds/b0/has_b1/b1 [K][B], grads [K][B][n]; outputs may be NULL.  Returns the number of Success cuts. */
+int64_t orc_ell_batch_run(int64_t B, int64_t n, int64_t K, const int32_t *kinds, const double *grads,
+                          const double *b0, const int32_t *has_b1, const double *b1, double kappa0,
+                          int32_t *status_out, double *mq_out, double *xc_out, double *kappa_out);
+
 /* EllStable (src/ell_stable.rs:9-15): one n*n buffer, diag = D entries, strict upper = L^T,
  * strict lower = scratch. corrected != 0 selects the mathematically consistent variant
  * (back-substitution on the factor, running v in the rank-one update); 0 = as the reference. */

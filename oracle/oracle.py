@@ -92,6 +92,8 @@ def lib():
         L.orc_ellstable_set_corrected.argtypes = [C.c_void_p, C.c_int]
         L.orc_rows_gemv.argtypes = [C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_rows_gemv.restype = None
+        L.orc_ell_batch_run.argtypes = [C.c_int64, C.c_int64, C.c_int64] + [C.c_void_p] * 5 + [C.c_double] + [C.c_void_p] * 4
+        L.orc_ell_batch_run.restype = C.c_int64
         L.orc_lowpass_new.argtypes = [C.c_int64] + [C.c_double] * 5
         L.orc_lowpass_new.restype = C.POINTER(_Lowpass)
         L.orc_lowpass_free.argtypes = [C.POINTER(_Lowpass)]
@@ -330,3 +332,20 @@ class OracleLowpass:
         niter = lib().orc_lowpass_cutting_plane_feas(self.p, kind, space.h, int(max_iters), float(tol), _ptr(xb),
                                                      C.byref(hb), C.byref(ls))
         return (xb if hb.value else None), int(niter), ls.value
+
+
+def ell_batch_run(kinds, grads, b0, has_b1, b1, kappa0=1.0, want_state=True):
+    """B identity Ell spaces, K cuts each (loop over orc_ell_update).  Arrays [K][B] / [K][B][n]."""
+    grads = np.ascontiguousarray(grads, dtype=np.float64)
+    K, B, n = grads.shape
+    kinds = np.ascontiguousarray(kinds, dtype=np.int32)
+    b0 = np.ascontiguousarray(b0, dtype=np.float64)
+    has_b1 = np.ascontiguousarray(has_b1, dtype=np.int32)
+    b1 = np.ascontiguousarray(b1, dtype=np.float64)
+    status = np.empty((K, B), dtype=np.int32)
+    mq = np.empty((B, n, n)) if want_state else None
+    xc = np.empty((B, n)) if want_state else None
+    kap = np.empty(B) if want_state else None
+    ok = lib().orc_ell_batch_run(B, n, K, _ptr(kinds), _ptr(grads), _ptr(b0), _ptr(has_b1), _ptr(b1), float(kappa0),
+                                 _ptr(status), _ptr(mq), _ptr(xc), _ptr(kap))
+    return int(ok), status, mq, xc, kap

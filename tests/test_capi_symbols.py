@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def declared_functions():
     names = set()
-    for header in ("ellhip.h", "ellhip_lowpass.h"):
+    for header in ("ellhip.h", "ellhip_lowpass.h", "ellhip_batch.h"):
         src = open(os.path.join(ROOT, "include", header)).read()
         src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
         names.update(re.findall(r"\b(ellhip_[a-z0-9_]+)\s*\(", src))
@@ -55,6 +55,9 @@ def test_no_device_means_loud_failure_not_fallback():
     assert lib.ellhip_lowpass_create(C.byref(o), 8, 0.12, 0.2, 0.9, 1.1, 0.01, None, -1) == pkg.capi.E_NODEVICE
     with pytest.raises(pkg.capi.EllHipError):
         pkg.create_lowpass_case(8)
+    assert lib.ellhip_batch_create(C.byref(o), 4, 8, None, None, None, None, -1) == pkg.capi.E_NODEVICE
+    with pytest.raises(pkg.capi.EllHipError):
+        pkg.EllBatch.new_with_scalar(np.ones(4), np.zeros((4, 8)))
 
 
 def test_product_package_never_imports_the_oracle():

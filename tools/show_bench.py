@@ -10,7 +10,10 @@ for path in sys.argv[1:]:
         print(path, "unreadable:", e)
         continue
     r = d["roofline"]
-    pk = {k: (round(v["avg_ms"], 4), round(v.get("GBps", 0))) for k, v in r["per_kernel"].items()}
+    pk = {k: (round(v["avg_ms"], 4), round(v.get("GBps", 0))) for k, v in r.get("per_kernel", {}).items()}
+    if "per_kernel" not in r:
+        r["whole_update"] = {"frac": r.get("frac", 0)}
+        pk = {"kernel_ms": round(r.get("avg_launch_ms", 0), 4), "GBps": round(r.get("achieved", 0))}
     print(f'{d["config"]["workload"]:18s} {d["config"].get("schedule","")[:9]:9s} d{d["config"].get("defer_depth",1)} gpus={d["n_gpus"]} upd/s={d["value"]:9.1f} '
           f'ms={d["ms_per_step"]:.4f} dom={r.get("kernel")} frac={r.get("frac", 0):.3f} whole={(r.get("whole_update") or r.get("whole_iteration"))["frac"]:.3f} {pk}')
     for o in d.get("other_schedules", []):
