@@ -482,8 +482,11 @@ def main() -> None:
     ms_per_step = elapsed / K * 1e3
     value = K / elapsed
     # algorithmic bytes per launch of each kernel class (per GPU)
-    alg = {"gemv": 8.0 * n2w, "rank1": 16.0 * n2w, "fused": 16.0 * n2w, "apply": 16.0 * n2w, "apply_gemv": 16.0 * n2w,
-           "symv": 4.0 * n2w,
+    symv_mode = (not sharded) and n % 2 == 0 and n >= int(os.environ.get("ELLHIP_SYMV_MIN_N", "10240")) \
+        and os.environ.get("ELLHIP_SYMV", "1") != "0"
+    lower_apply = symv_mode and os.environ.get("ELLHIP_APPLY_LOWER", "1") != "0"
+    alg = {"gemv": 8.0 * n2w, "rank1": 16.0 * n2w, "fused": 16.0 * n2w, "apply": (8.0 if lower_apply else 16.0) * n2w,
+           "apply_gemv": 16.0 * n2w, "symv": 4.0 * n2w,
            "stable_fwd": 8.0 * n * n, "stable_bwd": 4.0 * n * n, "stable_factor": 12.0 * n * n}
 
     def byte_model(sched, dep):
@@ -492,7 +495,11 @@ def main() -> None:
             if sched == "pipelined":
                 return 16.0 * n2w, "16*n^2 B/update (rank-1 pass of cut k fused with the GEMV of cut k+1)"
             return 24.0 * n2w, "24*n^2 B/update (GEMV pass 8 + rank-1 pass 16; SURVEY 8d)"
-        if not sharded and n % 2 == 0 and n >= 10240:
+        if symv_mode and lower_apply:
+            return 5.0 * n2w, ("5*n^2 B/update (deferred shrink, depth 8, unsharded: eight lower-triangle GEMV passes of "
+                               "4*n^2 + one lower-triangle apply pass of 8*n^2 per 8 updates; the upper triangle is "
+                               "mirrored back only when Q itself is read)")
+        if symv_mode:
             return 6.0 * n2w, ("6*n^2 B/update (deferred shrink, depth 8, unsharded: eight lower-triangle GEMV passes of "
                                "4*n^2 + one apply pass of 16*n^2 per 8 updates)")
         if sched == "pipelined":

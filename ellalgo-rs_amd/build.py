@@ -39,7 +39,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
     """Compile the HIP engine for gfx950 into ellalgo-rs_amd/libellhip.so."""
     if not force and not needs_build():
         return LIB_PATH
-    cmd = [_hipcc()] + HIPCC_FLAGS + ["-I", os.path.join(REPO_ROOT, "include"), "-o", LIB_PATH] + \
+    extra = os.environ.get("ELLHIP_EXTRA_HIPCC_FLAGS", "").split()  # tuning builds only
+    cmd = [_hipcc()] + HIPCC_FLAGS + extra + ["-I", os.path.join(REPO_ROOT, "include"), "-o", LIB_PATH] + \
           [os.path.join(CSRC, f) for f in SOURCES]
     if verbose:
         print(" ".join(cmd))

@@ -287,8 +287,14 @@ __global__ __launch_bounds__(256) void k_sweep(const double* Q, double* Qout, lo
 //     rowpart[J][r]  = sum over the segment's columns c <= r of Q[r][c] g[c]
 //     colpart[I][c]  = sum over the strip's rows r > c of Q[r][c] g[r]
 // and k_symv_reduce forms y[i] = sum_J rowpart[J][i] + sum_{I >= i/H} colpart[I][i] in a fixed order.
-constexpr int SYMV_H = 64;
-constexpr int SYMV_SEG = 2048;
+#ifndef ELLHIP_SYMV_H
+#define ELLHIP_SYMV_H 64
+#endif
+#ifndef ELLHIP_SYMV_SEG
+#define ELLHIP_SYMV_SEG 2048
+#endif
+constexpr int SYMV_H = ELLHIP_SYMV_H;      // (macros: tuning builds only, see profiles/r01/tune_symv.txt)
+constexpr int SYMV_SEG = ELLHIP_SYMV_SEG;
 constexpr int SYMV_NCH = SYMV_SEG / 512;  // 16-byte column chunks per thread
 
 template <int RW, bool NT, int ABL = 0>  // ABL: timing-only ablations for tools/tune_ell.hip (0 = the real kernel)
@@ -413,7 +419,11 @@ __global__ __launch_bounds__(256) void k_symv_reduce(long long n, const double* 
 // Deferred mode: apply the MAXPEND pending rank-1 updates to the local rows in one pass (and, when GV,
 // accumulate the GEMV of the next gradient on the freshly written values).  pend: MAXPEND vectors of
 // length n (stride n); cpend: their coefficients.  Same mapping and summation shape as k_sweep.
-template <int RW, int UNR, int VEC, bool NT, bool GV>
+// LOWER: only columns up to the tile's last row are touched (8 n^2 bytes for the whole pass instead of
+// 16 n^2).  Legal while every GEMV in between reads the lower triangle only (k_symv): the strict upper
+// triangle is then stale and is rebuilt from the lower one (k_mirror_lower_now) before anything reads it
+// -- which is exactly what the reference's mirror store `Q[j][i] = Q[i][j]` (src/ell.rs:124-126) makes of it.
+template <int RW, int UNR, int VEC, bool NT, bool GV, bool LOWER = false>
 __global__ __launch_bounds__(256) void k_sweep_apply(const double* Q, double* Qout, long long ld, long long n,
                                                      long long nrows, long long row0,
                                                      const double* __restrict__ pend,
@@ -456,11 +466,16 @@ __global__ __launch_bounds__(256) void k_sweep_apply(const double* Q, double* Qo
     const long long grow_min = row0 + row_base;           // rows of this tile: grow_min .. grow_max
     const long long grow_max = grow[RW - 1];
     constexpr long long STEP = 256 * VEC;
-    for (long long c = (long long)threadIdx.x * VEC; c < n; c += STEP * UNR) {
+    long long cend = n;
+    if (LOWER) {
+        cend = (grow_max / VEC + 1) * VEC;  // first column past the tile's diagonal, rounded up to the access width
+        if (cend > n) cend = n;
+    }
+    for (long long c = (long long)threadIdx.x * VEC; c < cend; c += STEP * UNR) {
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {
             const long long cc = c + u * STEP;
-            if (cc >= n) break;
+            if (cc >= cend) break;
             V vj[MAXPEND];
 #pragma unroll
             for (int j = 0; j < MAXPEND; ++j) vj[j] = *reinterpret_cast<const V*>(pend + (long long)j * n + cc);
@@ -890,6 +905,23 @@ __global__ __launch_bounds__(256) void k_mirror_lower(double* __restrict__ Q, lo
     __syncthreads();
     for (int k = ty; k < 32; k += 8) {
         const long long r = bx * 32 + k, c = by * 32 + tx;  // transposed position
+        if (r < n && c < n && c > r) Q[r * ld + c] = tile[tx][k];
+    }
+}
+
+// Unconditional form: rebuild the strict upper triangle after lower-triangle-only apply passes.
+__global__ __launch_bounds__(256) void k_mirror_lower_now(double* __restrict__ Q, long long ld, long long n) {
+    __shared__ double tile[32][33];
+    const long long bx = blockIdx.x, by = blockIdx.y;
+    if (by < bx) return;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int k = ty; k < 32; k += 8) {
+        const long long r = by * 32 + k, c = bx * 32 + tx;
+        tile[k][tx] = (r < n && c < n) ? Q[r * ld + c] : 0.0;
+    }
+    __syncthreads();
+    for (int k = ty; k < 32; k += 8) {
+        const long long r = bx * 32 + k, c = by * 32 + tx;
         if (r < n && c < n && c > r) Q[r * ld + c] = tile[tx][k];
     }
 }

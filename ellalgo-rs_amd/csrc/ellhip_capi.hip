@@ -87,6 +87,8 @@ struct ellhip_space {
     int symv = 1;                    // allow the lower-triangle GEMV in deferred mode (ELLHIP_SYMV=0 disables)
     int symv_rw = 2;
     long long symv_min_n = 10240;    // below this the full-row pass is faster (few, small triangle tiles)
+    int apply_lower = 1;             // with symv: apply passes touch the lower triangle only (ELLHIP_APPLY_LOWER)
+    bool upper_stale = false;        // strict upper triangle of Q is out of date (see flush_pending)
     int defer = 1;                   // 1 = shrink Q at every cut; MAXPEND = record and apply in batches
     int npend = 0;                   // updates recorded since the last flush (host view, optimistic in queue mode)
     int* d_flags = nullptr;          // EllStable persistent solves: block-ready flags (forward | backward)
@@ -216,6 +218,7 @@ void pick_shape(ellhip_space* s) {
     s->symv = env_int("ELLHIP_SYMV", 1);
     s->symv_rw = env_int("ELLHIP_SYMV_RW", 2);
     s->symv_min_n = env_int("ELLHIP_SYMV_MIN_N", 10240);
+    s->apply_lower = env_int("ELLHIP_APPLY_LOWER", 1);
     s->sh_apply = {4, 1, s->sh_fused.nt};  // 8 pending vectors per column step: more rows per workgroup amortise them
     s->sh_apply.rw = env_int("ELLHIP_APPLY_RW", s->sh_apply.rw);
     s->sh_apply.unr = env_int("ELLHIP_APPLY_UNR", s->sh_apply.unr);
@@ -278,17 +281,18 @@ bool deferring(const ellhip_space* s) {
     return s->variant == ELLHIP_SPACE_ELL && s->defer > 1 && !s->no_defer_trick && !s->needs_mirror;
 }
 
-template <int VEC, bool NT, bool GV>
+template <int VEC, bool NT, bool GV, bool LOWER = false>
 int launch_apply_t(ellhip_space* s, const double* gvec, double* gv_out) {
     const Shape& sh = s->sh_apply;
     const long long nr = s->nrows;
     const unsigned grid = (unsigned)((nr + sh.rw - 1) / sh.rw);
     double* out = gv_out ? gv_out + s->row0 : nullptr;
+    const int dir = LOWER ? 1 : s->dir;  // lower-only: last (longest) rows first, so the short ones fill the tail
 #define APPLY_CASE(RW, UNR)                                                                                   \
     if (sh.rw == RW && sh.unr == UNR) {                                                                       \
-        hipLaunchKernelGGL((k_sweep_apply<RW, UNR, VEC, NT, GV>), dim3(grid), dim3(256), 0, s->stream,        \
+        hipLaunchKernelGGL((k_sweep_apply<RW, UNR, VEC, NT, GV, LOWER>), dim3(grid), dim3(256), 0, s->stream, \
                            (const double*)s->d_Q, s->d_Q, s->ld, s->n, nr, s->row0, (const double*)s->d_pend, \
-                           (const double*)s->d_cpend, gvec, out, s->d_st, s->dir);                            \
+                           (const double*)s->d_cpend, gvec, out, s->d_st, dir);                               \
         return 0;                                                                                             \
     }
     APPLY_CASE(1, 2) APPLY_CASE(1, 4) APPLY_CASE(2, 1) APPLY_CASE(2, 2) APPLY_CASE(2, 4) APPLY_CASE(4, 1) APPLY_CASE(4, 2)
@@ -296,14 +300,22 @@ int launch_apply_t(ellhip_space* s, const double* gvec, double* gv_out) {
     return fail(ELLHIP_E_INVALID, "unsupported ELLHIP_APPLY_RW/UNR shape (supported: 1x2 1x4 2x1 2x2 2x4 4x1 4x2)");
 }
 
+bool symv_ok(const ellhip_space* s);
+
 // Apply every pending update to Q (one pass), optionally fused with the GEMV of `gvec`; then clear the slots.
+// While the GEMVs of this handle read the lower triangle only (symv_ok), so does the apply pass: half the
+// traffic; the strict upper triangle goes stale until make_q_current() mirrors it back.
 int flush_pending(ellhip_space* s, const double* gvec, double* gv_out) {
     {
         ProfScope ps(s, gvec ? CLS_APPLY_GEMV : CLS_APPLY);
         const bool even = (s->n % 2) == 0;
         const bool nt = even && s->sh_apply.nt;
         int rc;
-        if (gvec)
+        if (!gvec && s->apply_lower && symv_ok(s)) {
+            rc = nt ? launch_apply_t<2, true, false, true>(s, nullptr, nullptr)
+                    : launch_apply_t<2, false, false, true>(s, nullptr, nullptr);
+            s->upper_stale = true;
+        } else if (gvec)
             rc = !even ? launch_apply_t<1, false, true>(s, gvec, gv_out)
                        : (nt ? launch_apply_t<2, true, true>(s, gvec, gv_out) : launch_apply_t<2, false, true>(s, gvec, gv_out));
         else
@@ -561,7 +573,16 @@ int ensure_committed(ellhip_space* s) {
 int make_q_current(ellhip_space* s) {
     int rc = ensure_committed(s);
     if (rc) return rc;
-    if (s->npend > 0) return flush_pending(s, nullptr, nullptr);
+    if (s->npend > 0) {
+        rc = flush_pending(s, nullptr, nullptr);
+        if (rc) return rc;
+    }
+    if (s->upper_stale) {  // lower-triangle-only apply passes ran: rebuild the mirrored half
+        const unsigned t = (unsigned)((s->n + 31) / 32);
+        hipLaunchKernelGGL(k_mirror_lower_now, dim3(t, t), dim3(256), 0, s->stream, s->d_Q, s->ld, s->n);
+        HIPCHK(hipGetLastError());
+        s->upper_stale = false;
+    }
     return 0;
 }
 
@@ -864,6 +885,7 @@ int ellhip_clone(const ellhip_space* src_c, ellhip_space** out) {
     s->symv = src->symv;
     s->symv_rw = src->symv_rw;
     s->symv_min_n = src->symv_min_n;
+    s->apply_lower = src->apply_lower;
     rc = alloc_common(s);
     if (rc) {
         ellhip_destroy(s);
