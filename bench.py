@@ -22,6 +22,7 @@ from __future__ import annotations
 
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -147,6 +148,87 @@ def batch_bench(args, real_stdout) -> None:
         out["cpu_baseline"] = {"value": done / t_used, "unit": "updates/s", "cores": 1, "kind": "port",
                                "sample": f"{done} updates: {Bs} of the ellipsoids x {K} cuts, repeated, oracle/ell_oracle.c "
                                          f"orc_ell_batch_run, 1 thread, {t_used:.1f} s", "host_cpus": os.cpu_count()}
+    print(json.dumps(out), file=real_stdout, flush=True)
+
+
+# LMIOracle / LDLTMgr on the device.
+LMI_WORKLOADS = {"lmi-m2048-n64": (64, 2048), "lmi-m1024-n128": (128, 1024), "lmi-m4096-n16": (16, 4096)}
+
+
+def lmi_bench(args, real_stdout) -> None:
+    """LMIOracle::assess_feas calls/s for an m x m pencil with n variables (include/ellhip_lmi.h): a feasible point
+    (full LDL^T: the worst case) and an infeasible one (factorisation stops at the failing pivot, cut produced).
+    value = feasible-point calls/s.  The F_k stream is priced against HBM; the factorisation is O(m^3/3) of
+    two-rounding multiply-adds in the reference's summation order (not an MFMA shape: every element owns an
+    ordered accumulator)."""
+    import torch
+    if args.gpus != 1 or int(os.environ.get("WORLD_SIZE", "1")) != 1:
+        raise SystemExit("one oracle per GPU: replicas only (run with --gpus 1)")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device: the engine has no CPU path")
+    import ellalgo_rs_amd as pkg
+    n, m = LMI_WORKLOADS[args.workload]
+    S, W = args.steps, args.warmup
+    rng = np.random.default_rng(0x5EED)
+    a = rng.standard_normal((m, 64))
+    B = a @ a.T / 64.0 + 1.0 * np.eye(m)
+    F = rng.standard_normal((n, m, m))
+    F = (F + F.transpose(0, 2, 1)) / 2.0
+    x_feas = np.zeros(n)
+    x_dir = rng.standard_normal(n) / math.sqrt(n * m)
+    t0 = time.perf_counter()
+    dev = pkg.LMIOracle(F, B)
+    log(f"[lmi] {n} matrices {m} x {m} ({n * m * m * 8 / 2**30:.2f} GiB) uploaded in {time.perf_counter() - t0:.1f}s")
+    assert dev.assess_feas(x_feas) is None
+    scale = 0.25  # walk out along x_dir until F(x) stops being positive definite
+    while dev.assess_feas(scale * x_dir) is None:
+        scale *= 1.5
+        assert scale < 1e6
+    x_cut = scale * x_dir
+    cut = dev.assess_feas(x_cut)
+    p_cut = dev.pos[1]
+
+    def timed(x, count):
+        for _ in range(W):
+            dev.assess_feas(x)
+        t1 = time.perf_counter()
+        for _ in range(count):
+            dev.assess_feas(x)
+        return (time.perf_counter() - t1) / count
+
+    t_feas = timed(x_feas, S)
+    t_cut = timed(x_cut, S)
+    form_bytes = n * m * (m + 1) / 2 * 8.0
+    flops = m ** 3 / 3.0 * 2.0
+    out = {
+        "metric": "LMIOracle assess_feas calls/sec, %d x %d pencil with %d variables (feasible point, full LDL^T)" % (m, m, n),
+        "value": 1.0 / t_feas, "unit": "calls/s", "n_gpus": 1, "steps": S, "warmup": W, "ms_per_step": t_feas * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": args.workload, "n": n, "m": m, "pencil_bytes": 8.0 * n * m * m,
+                   "cut_case": {"ms_per_call": t_cut * 1e3, "failing_row": p_cut,
+                                "note": "factorisation stops at the failing pivot; witness + n quadratic forms follow"}},
+        "roofline": {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "kernel": "whole call", "traffic": None,
+                     "achieved": form_bytes / t_feas / 1e9, "frac": form_bytes / t_feas / 1e9 / HBM_PEAK_GBS,
+                     "byte_model": "lower triangle of the n matrices read once to form F(x): n*m*(m+1)/2*8 B; the call is "
+                                   "dominated by the ordered LDL^T, see factor_gflops",
+                     "factor_gflops": flops / t_feas / 1e9,
+                     "whole_update": {"frac": form_bytes / t_feas / 1e9 / HBM_PEAK_GBS}},
+    }
+    if not args.no_cpu_baseline:
+        from oracle import oracle as O
+        log("[lmi] timing the CPU oracle (bounded sample) ...")
+        cpu = O.OracleLMI(F, B)
+        t1 = time.perf_counter()
+        assert cpu.assess_feas(x_feas) is None
+        t_cpu = time.perf_counter() - t1
+        t1 = time.perf_counter()
+        rc = cpu.assess_feas(x_cut)
+        t_cpu_cut = time.perf_counter() - t1
+        assert rc is not None and cpu.ldlt.pos[1] == p_cut and rc[1] == cut[1].beta
+        out["cpu_baseline"] = {"value": 1.0 / t_cpu, "unit": "calls/s", "cores": 1, "kind": "port",
+                               "sample": f"1 feasible-point call ({t_cpu:.2f} s) and 1 cut call ({t_cpu_cut:.2f} s, same failing "
+                                         f"row {p_cut} and bit-identical ep) of oracle/lmi_oracle.c, 1 thread",
+                               "host_cpus": os.cpu_count(), "cut_case_calls_per_s": 1.0 / t_cpu_cut}
     print(json.dumps(out), file=real_stdout, flush=True)
 
 
@@ -315,7 +397,7 @@ def main() -> None:
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default=os.environ.get("ELLHIP_BENCH_WORKLOAD", "n16384-parallel"),
-                    choices=sorted(WORKLOADS) + sorted(LOWPASS_WORKLOADS) + sorted(BATCH_WORKLOADS))
+                    choices=sorted(WORKLOADS) + sorted(LOWPASS_WORKLOADS) + sorted(BATCH_WORKLOADS) + sorted(LMI_WORKLOADS))
     ap.add_argument("--profile-steps", type=int, default=40, help="extra steps with per-kernel HIP events")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
@@ -338,6 +420,8 @@ def main() -> None:
         return lowpass_bench(args, real_stdout)
     if args.workload in BATCH_WORKLOADS:
         return batch_bench(args, real_stdout)
+    if args.workload in LMI_WORKLOADS:
+        return lmi_bench(args, real_stdout)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -482,7 +566,7 @@ def main() -> None:
     ms_per_step = elapsed / K * 1e3
     value = K / elapsed
     # algorithmic bytes per launch of each kernel class (per GPU)
-    symv_mode = (not sharded) and n % 2 == 0 and n >= int(os.environ.get("ELLHIP_SYMV_MIN_N", "10240")) \
+    symv_mode = (not sharded) and n % 2 == 0 and n >= int(os.environ.get("ELLHIP_SYMV_MIN_N", "8192")) \
         and os.environ.get("ELLHIP_SYMV", "1") != "0"
     lower_apply = symv_mode and os.environ.get("ELLHIP_APPLY_LOWER", "1") != "0"
     alg = {"gemv": 8.0 * n2w, "rank1": 16.0 * n2w, "fused": 16.0 * n2w, "apply": (8.0 if lower_apply else 16.0) * n2w,

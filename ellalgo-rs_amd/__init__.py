@@ -7,7 +7,8 @@ sources (csrc/), the build recipe, the C++ host mirror of the reference's traits
 from . import build, capi, synth  # noqa: F401
 from .ell import (CutStatus, Ell, EllStable, ParallelCut, SingleCut, calc)  # noqa: F401
 from .batch import EllBatch  # noqa: F401
+from .lmi import LDLTMgr, LMI0Oracle, LMIOracle  # noqa: F401
 from .lowpass import LowpassOracle, create_lowpass_case, lowpass_case_constants  # noqa: F401
 
 __all__ = ["build", "capi", "synth", "CutStatus", "Ell", "EllStable", "ParallelCut", "SingleCut", "calc",
-           "EllBatch", "LowpassOracle", "create_lowpass_case", "lowpass_case_constants"]
+           "EllBatch", "LDLTMgr", "LMIOracle", "LMI0Oracle", "LowpassOracle", "create_lowpass_case", "lowpass_case_constants"]

@@ -12,7 +12,8 @@ REPO_ROOT = os.path.dirname(PKG_DIR)
 
 SOURCES = ["ellhip_capi.hip"]
 HEADERS = ["ell_kernels.hpp", "ellstable_kernels.hpp", "ellcalc_device.hpp", "lowpass_kernels.hpp",
-           "lowpass_capi.inc.hpp", "batch_kernels.hpp", "batch_capi.inc.hpp"]
+           "lowpass_capi.inc.hpp", "batch_kernels.hpp", "batch_capi.inc.hpp", "lmi_kernels.hpp",
+           "lmi_capi.inc.hpp"]
 
 # -ffp-contract=off: the reference never fuses a*b+c (two roundings per multiply-add); keeping
 # that makes the rank-1 pass bit-identical to the CPU arithmetic for the same gt.
@@ -31,7 +32,7 @@ def needs_build() -> bool:
     if not os.path.exists(LIB_PATH):
         return True
     t = os.path.getmtime(LIB_PATH)
-    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS] + [os.path.join(REPO_ROOT, "include", f) for f in ("ellhip.h", "ellhip_lowpass.h", "ellhip_batch.h")]
+    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS] + [os.path.join(REPO_ROOT, "include", f) for f in ("ellhip.h", "ellhip_lowpass.h", "ellhip_batch.h", "ellhip_lmi.h")]
     return any(os.path.getmtime(d) > t for d in deps)
 
 

@@ -35,6 +35,9 @@ EXPORTS = [
     "ellhip_batch_update_dev", "ellhip_batch_synchronize", "ellhip_batch_stream", "ellhip_batch_get_xc",
     "ellhip_batch_set_xc", "ellhip_batch_get_mq", "ellhip_batch_get_kappa", "ellhip_batch_get_tsq",
     "ellhip_batch_size", "ellhip_batch_ndim", "ellhip_batch_set_no_defer_trick", "ellhip_batch_set_use_parallel_cut",
+    # include/ellhip_lmi.h
+    "ellhip_lmi_create", "ellhip_lmi_destroy", "ellhip_lmi_assess_feas", "ellhip_lmi_pos", "ellhip_lmi_get_witness",
+    "ellhip_lmi_get_storage", "ellhip_lmi_sqrt",
 ]
 
 
@@ -126,6 +129,13 @@ def load():
         "ellhip_batch_ndim": (i64, [vp]),
         "ellhip_batch_set_no_defer_trick": (i32, [vp, i32]),
         "ellhip_batch_set_use_parallel_cut": (i32, [vp, i32]),
+        "ellhip_lmi_create": (i32, [C.POINTER(vp), i64, i64, vp, vp, i32]),
+        "ellhip_lmi_destroy": (None, [vp]),
+        "ellhip_lmi_assess_feas": (i32, [vp, vp, vp, C.POINTER(dbl)]),
+        "ellhip_lmi_pos": (i32, [vp, vp]),
+        "ellhip_lmi_get_witness": (i32, [vp, vp]),
+        "ellhip_lmi_get_storage": (i32, [vp, vp]),
+        "ellhip_lmi_sqrt": (i32, [vp, vp]),
     }
     for name in EXPORTS:
         fn = getattr(L, name)  # AttributeError if the library does not export it

@@ -86,7 +86,7 @@ struct ellhip_space {
     double* d_colpart = nullptr;     // symmetric GEMV: per-strip column partial sums [n/SYMV_H][n]
     int symv = 1;                    // allow the lower-triangle GEMV in deferred mode (ELLHIP_SYMV=0 disables)
     int symv_rw = 2;
-    long long symv_min_n = 10240;    // below this the full-row pass is faster (few, small triangle tiles)
+    long long symv_min_n = 8192;     // below this the full-row pass is faster (few, small triangle tiles)
     int apply_lower = 1;             // with symv: apply passes touch the lower triangle only (ELLHIP_APPLY_LOWER)
     bool upper_stale = false;        // strict upper triangle of Q is out of date (see flush_pending)
     int defer = 1;                   // 1 = shrink Q at every cut; MAXPEND = record and apply in batches
@@ -217,7 +217,7 @@ void pick_shape(ellhip_space* s) {
     }
     s->symv = env_int("ELLHIP_SYMV", 1);
     s->symv_rw = env_int("ELLHIP_SYMV_RW", 2);
-    s->symv_min_n = env_int("ELLHIP_SYMV_MIN_N", 10240);
+    s->symv_min_n = env_int("ELLHIP_SYMV_MIN_N", 8192);
     s->apply_lower = env_int("ELLHIP_APPLY_LOWER", 1);
     s->sh_apply = {4, 1, s->sh_fused.nt};  // 8 pending vectors per column step: more rows per workgroup amortise them
     s->sh_apply.rw = env_int("ELLHIP_APPLY_RW", s->sh_apply.rw);
@@ -1282,3 +1282,4 @@ int ellhip_profile_read(ellhip_space* s, double* ms_out, int64_t* count_out) {
 
 #include "lowpass_capi.inc.hpp"
 #include "batch_capi.inc.hpp"
+#include "lmi_capi.inc.hpp"

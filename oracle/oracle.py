@@ -20,7 +20,8 @@ CUT_BIAS, CUT_CENTRAL, CUT_Q = 0, 1, 2
 
 def build(force: bool = False) -> str:
     """Compile the oracle with gcc (oracle/Makefile)."""
-    srcs = [os.path.join(_HERE, f) for f in ("ell_oracle.c", "ell_oracle.h", "lowpass_oracle.c", "lowpass_oracle.h")]
+    srcs = [os.path.join(_HERE, f) for f in ("ell_oracle.c", "ell_oracle.h", "lowpass_oracle.c", "lowpass_oracle.h", "lmi_oracle.c",
+                                              "lmi_oracle.h")]
     stale = (not os.path.exists(_LIB_PATH)) or os.path.getmtime(_LIB_PATH) < max(os.path.getmtime(f) for f in srcs)
     if force or stale:
         subprocess.check_call(["make", "-C", _HERE, "-B", "libell_oracle.so"],
@@ -41,6 +42,18 @@ class _Lowpass(C.Structure):
                 ("idx2", C.c_int), ("idx3", C.c_int), ("fmax", C.c_double), ("kmax", C.c_int),
                 ("rows_visited", C.c_int64)]
 
+
+class _Ldlt(C.Structure):
+    _fields_ = [("pos0", C.c_int64), ("pos1", C.c_int64), ("wit", C.POINTER(C.c_double)), ("ndim", C.c_int64),
+                ("storage", C.POINTER(C.c_double))]
+
+
+class _Lmi(C.Structure):
+    _fields_ = [("mode", C.c_int), ("n", C.c_int64), ("m", C.c_int64), ("mat_f", C.POINTER(C.c_double)),
+                ("mat_b", C.POINTER(C.c_double)), ("ldlt", C.POINTER(_Ldlt))]
+
+
+_ELEM_FN = C.CFUNCTYPE(C.c_double, C.c_void_p, C.c_int64, C.c_int64)
 
 _lib = None
 _dp = C.POINTER(C.c_double)
@@ -94,6 +107,27 @@ def lib():
         L.orc_rows_gemv.restype = None
         L.orc_ell_batch_run.argtypes = [C.c_int64, C.c_int64, C.c_int64] + [C.c_void_p] * 5 + [C.c_double] + [C.c_void_p] * 4
         L.orc_ell_batch_run.restype = C.c_int64
+        L.orc_ldlt_new.argtypes = [C.c_int64]
+        L.orc_ldlt_new.restype = C.POINTER(_Ldlt)
+        L.orc_ldlt_free.argtypes = [C.POINTER(_Ldlt)]
+        L.orc_ldlt_free.restype = None
+        for nm in ("orc_ldlt_factor", "orc_ldlt_factor_semidefinite"):
+            getattr(L, nm).argtypes = [C.POINTER(_Ldlt), _ELEM_FN, C.c_void_p]
+            getattr(L, nm).restype = C.c_int
+        L.orc_ldlt_factorize.argtypes = [C.POINTER(_Ldlt), C.c_void_p]
+        L.orc_ldlt_factorize.restype = C.c_int
+        L.orc_ldlt_witness.argtypes = [C.POINTER(_Ldlt)]
+        L.orc_ldlt_witness.restype = C.c_double
+        L.orc_ldlt_sym_quad.argtypes = [C.POINTER(_Ldlt), C.c_void_p]
+        L.orc_ldlt_sym_quad.restype = C.c_double
+        L.orc_ldlt_sqrt.argtypes = [C.POINTER(_Ldlt), C.c_void_p]
+        L.orc_ldlt_sqrt.restype = None
+        L.orc_lmi_new.argtypes = [C.c_int, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]
+        L.orc_lmi_new.restype = C.POINTER(_Lmi)
+        L.orc_lmi_free.argtypes = [C.POINTER(_Lmi)]
+        L.orc_lmi_free.restype = None
+        L.orc_lmi_assess_feas.argtypes = [C.POINTER(_Lmi), C.c_void_p, C.c_void_p, C.POINTER(C.c_double)]
+        L.orc_lmi_assess_feas.restype = C.c_int
         L.orc_lowpass_new.argtypes = [C.c_int64] + [C.c_double] * 5
         L.orc_lowpass_new.restype = C.POINTER(_Lowpass)
         L.orc_lowpass_free.argtypes = [C.POINTER(_Lowpass)]
@@ -349,3 +383,85 @@ def ell_batch_run(kinds, grads, b0, has_b1, b1, kappa0=1.0, want_state=True):
     ok = lib().orc_ell_batch_run(B, n, K, _ptr(kinds), _ptr(grads), _ptr(b0), _ptr(has_b1), _ptr(b1), float(kappa0),
                                  _ptr(status), _ptr(mq), _ptr(xc), _ptr(kap))
     return int(ok), status, mq, xc, kap
+
+
+class OracleLDLT:
+    """LDLTMgr (src/oracles/ldlt_mgr.rs) as restated by the oracle."""
+
+    def __init__(self, ndim, _ptr_=None):
+        self.n = int(ndim)
+        self._own = _ptr_ is None
+        self.p = lib().orc_ldlt_new(self.n) if _ptr_ is None else _ptr_
+
+    def __del__(self):
+        p, self.p = getattr(self, "p", None), None
+        if p and self._own and _lib is not None:
+            _lib.orc_ldlt_free(p)
+
+    @property
+    def pos(self):
+        return (int(self.p.contents.pos0), int(self.p.contents.pos1))
+
+    @property
+    def wit(self):
+        return np.ctypeslib.as_array(self.p.contents.wit, shape=(self.n,))
+
+    @property
+    def storage(self):
+        return np.ctypeslib.as_array(self.p.contents.storage, shape=(self.n, self.n))
+
+    def factorize(self, mat):
+        mat = _arr(mat, self.n * self.n)
+        return bool(lib().orc_ldlt_factorize(self.p, _ptr(mat)))
+
+    def factor(self, get_elem, allow_semidefinite=False):
+        cb = _ELEM_FN(lambda ctx, i, j: float(get_elem(i, j)))
+        fn = lib().orc_ldlt_factor_semidefinite if allow_semidefinite else lib().orc_ldlt_factor
+        return bool(fn(self.p, cb, None))
+
+    def is_spd(self):
+        return self.pos[1] == 0
+
+    def witness(self):
+        assert not self.is_spd()
+        return lib().orc_ldlt_witness(self.p)
+
+    def sym_quad(self, mat):
+        mat = _arr(mat, self.n * self.n)
+        return lib().orc_ldlt_sym_quad(self.p, _ptr(mat))
+
+    def sqrt(self):
+        assert self.is_spd()
+        r = np.empty((self.n, self.n))
+        lib().orc_ldlt_sqrt(self.p, _ptr(r))
+        return r
+
+
+class OracleLMI:
+    """LMIOracle (mode 0, src/oracles/lmi_oracle.rs) / LMI0Oracle (mode 1, src/oracles/lmi0_oracle.rs)."""
+
+    def __init__(self, mat_f, mat_b=None):
+        mat_f = np.ascontiguousarray(mat_f, dtype=np.float64)
+        self.n, self.m = int(mat_f.shape[0]), int(mat_f.shape[1])
+        assert mat_f.shape == (self.n, self.m, self.m)
+        mode = 0 if mat_b is not None else 1
+        mb = None if mat_b is None else _arr(mat_b, self.m * self.m)
+        self.p = lib().orc_lmi_new(mode, self.n, self.m, _ptr(mat_f), _ptr(mb))
+
+    def __del__(self):
+        p, self.p = getattr(self, "p", None), None
+        if p and _lib is not None:
+            _lib.orc_lmi_free(p)
+
+    @property
+    def ldlt(self):
+        return OracleLDLT(self.m, _ptr_=self.p.contents.ldlt)
+
+    def assess_feas(self, x):
+        """None, or (g, ep)"""
+        x = _arr(x, self.n)
+        g = np.empty(self.n)
+        ep = C.c_double()
+        if not lib().orc_lmi_assess_feas(self.p, _ptr(x), _ptr(g), C.byref(ep)):
+            return None
+        return g, ep.value

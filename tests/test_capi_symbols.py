@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def declared_functions():
     names = set()
-    for header in ("ellhip.h", "ellhip_lowpass.h", "ellhip_batch.h"):
+    for header in ("ellhip.h", "ellhip_lowpass.h", "ellhip_batch.h", "ellhip_lmi.h"):
         src = open(os.path.join(ROOT, "include", header)).read()
         src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
         names.update(re.findall(r"\b(ellhip_[a-z0-9_]+)\s*\(", src))
@@ -58,6 +58,9 @@ def test_no_device_means_loud_failure_not_fallback():
     assert lib.ellhip_batch_create(C.byref(o), 4, 8, None, None, None, None, -1) == pkg.capi.E_NODEVICE
     with pytest.raises(pkg.capi.EllHipError):
         pkg.EllBatch.new_with_scalar(np.ones(4), np.zeros((4, 8)))
+    assert lib.ellhip_lmi_create(C.byref(o), 0, 2, None, (C.c_double * 4)(1, 0, 0, 1), -1) == pkg.capi.E_NODEVICE
+    with pytest.raises(pkg.capi.EllHipError):
+        pkg.LDLTMgr(3).factorize(np.eye(3))
 
 
 def test_product_package_never_imports_the_oracle():

@@ -25,7 +25,7 @@ def test_deferred_mixed_sequence_matches_oracle(gpu, orc, n):
 
 @pytest.mark.parametrize("n", [512, 1000, 2112, 4096])
 def test_deferred_symv_mixed_sequence_matches_oracle(gpu, orc, n, monkeypatch):
-    """Depth 8 with the lower-triangle GEMV forced on at small sizes (default threshold n >= 10240)."""
+    """Depth 8 with the lower-triangle GEMV forced on at small sizes (default threshold n >= 8192)."""
     monkeypatch.setenv("ELLHIP_SYMV_MIN_N", "512")
     xc0 = np.linspace(-1.0, 1.0, n)
     g = gpu.Ell.new_with_scalar(2.0, xc0)
@@ -196,7 +196,7 @@ def test_symv_equals_full_gemv_to_rounding(gpu, monkeypatch):
     from ellalgo_rs_amd import synth
     n, k = 2048 + 64, 20          # not a multiple of the segment width: exercises the ragged diagonal segment
     kinds, grads, b0, b1 = synth.parallel_cuts(n, k)
-    monkeypatch.setenv("ELLHIP_SYMV_MIN_N", "512")   # the default threshold (10240) would skip it at this size
+    monkeypatch.setenv("ELLHIP_SYMV_MIN_N", "512")   # the default threshold (8192) would skip it at this size
     a = gpu.Ell.new_with_scalar(1.0, np.zeros(n))
     a.defer_depth = 8
     monkeypatch.setenv("ELLHIP_SYMV", "0")
