@@ -454,6 +454,13 @@ def main() -> None:
     fused = args.schedule == "pipelined" and variant == "ell"
     depth = args.defer if variant == "ell" else 1
     C2 = args.compare_steps if variant == "ell" else 0
+    # N > 1, depth 8: symmetric row shards (equal lower-trapezoid areas, partial symmetric GEMVs added by one
+    # all-reduce, lower-trapezoid apply passes): 5*n^2/P bytes per GPU and update.  That schedule only, so the
+    # other schedules are not timed alongside.
+    shard_sym = (sharded and variant == "ell" and depth == 8 and n % 64 == 0 and n // 64 >= world
+                 and os.environ.get("ELLHIP_SHARD_SYMMETRIC", "1") != "0")
+    if shard_sym:
+        C2 = 0
     # alternatives measured after the main run, on the same handle: (schedule, depth)
     alts = []
     if C2 > 0:
@@ -463,7 +470,7 @@ def main() -> None:
     total = W + K + P + 2 * C2 * len(alts) + H
     if sharded and variant != "ell":
         raise SystemExit("EllStable does not shard: replicas only (see DESIGN.md)")
-    if n % world:
+    if n % world and not shard_sym:
         raise SystemExit(f"n={n} is not divisible by {world} ranks")
 
     t_gen = time.perf_counter()
@@ -477,9 +484,9 @@ def main() -> None:
         space = (pkg.Ell if variant == "ell" else pkg.EllStable).new_with_scalar(1.0, np.zeros(n), device=local_rank)
     else:
         from ellalgo_rs_amd.sharded import ShardedEll
-        space = ShardedEll.new_with_scalar(1.0, np.zeros(n), device=local_rank)
+        space = ShardedEll.new_with_scalar(1.0, np.zeros(n), device=local_rank, symmetric=shard_sym)
     nq = W + K + P + 2 * C2 * len(alts)
-    if variant == "ell" and depth != 1:
+    if variant == "ell" and depth != 1 and not shard_sym:
         space.set_defer_depth(depth) if sharded else setattr(space, "defer_depth", depth)
     space.queue_upload(kinds[:nq], grads[:nq], b0[:nq], b1[:nq])
 
@@ -566,8 +573,8 @@ def main() -> None:
     ms_per_step = elapsed / K * 1e3
     value = K / elapsed
     # algorithmic bytes per launch of each kernel class (per GPU)
-    symv_mode = (not sharded) and n % 2 == 0 and n >= int(os.environ.get("ELLHIP_SYMV_MIN_N", "8192")) \
-        and os.environ.get("ELLHIP_SYMV", "1") != "0"
+    symv_mode = ((not sharded) and n % 2 == 0 and n >= int(os.environ.get("ELLHIP_SYMV_MIN_N", "8192"))
+                 and os.environ.get("ELLHIP_SYMV", "1") != "0") or shard_sym
     lower_apply = symv_mode and os.environ.get("ELLHIP_APPLY_LOWER", "1") != "0"
     alg = {"gemv": 8.0 * n2w, "rank1": 16.0 * n2w, "fused": 16.0 * n2w, "apply": (8.0 if lower_apply else 16.0) * n2w,
            "apply_gemv": 16.0 * n2w, "symv": 4.0 * n2w,
@@ -580,9 +587,11 @@ def main() -> None:
                 return 16.0 * n2w, "16*n^2 B/update (rank-1 pass of cut k fused with the GEMV of cut k+1)"
             return 24.0 * n2w, "24*n^2 B/update (GEMV pass 8 + rank-1 pass 16; SURVEY 8d)"
         if symv_mode and lower_apply:
-            return 5.0 * n2w, ("5*n^2 B/update (deferred shrink, depth 8, unsharded: eight lower-triangle GEMV passes of "
-                               "4*n^2 + one lower-triangle apply pass of 8*n^2 per 8 updates; the upper triangle is "
-                               "mirrored back only when Q itself is read)")
+            return 5.0 * n2w, ("5*n^2 B/update (deferred shrink, depth 8: eight lower-triangle GEMV passes of 4*n^2 + one "
+                               "lower-triangle apply pass of 8*n^2 per 8 updates; the upper triangle is mirrored back "
+                               "only when Q itself is read" +
+                               ("; per GPU 1/P of that: symmetric row shards of equal trapezoid area, one all-reduce "
+                                "of the n-vector per update)" if sharded else ")"))
         if symv_mode:
             return 6.0 * n2w, ("6*n^2 B/update (deferred shrink, depth 8, unsharded: eight lower-triangle GEMV passes of "
                                "4*n^2 + one apply pass of 16*n^2 per 8 updates)")
@@ -662,7 +671,9 @@ def main() -> None:
         "config": {"workload": args.workload, "n": n, "space": variant, "cuts": cutgen,
                    "schedule": ("pipelined" if fused else "two-pass") if variant == "ell" else "ellstable",
                    "defer_depth": depth,
-                   "description": desc, "partition": f"row-block x{world}" if world > 1 else "none",
+                   "description": desc,
+                   "partition": (f"symmetric row shards x{world} (boundaries at n*sqrt(r/P), all-reduce)" if shard_sym
+                                 else f"row-block x{world} (all-gather)") if sharded else "none",
                    "q_bytes_per_gpu": 8.0 * n * n / world},
         "roofline": roofline,
     }

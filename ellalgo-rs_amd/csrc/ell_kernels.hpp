@@ -299,6 +299,7 @@ constexpr int SYMV_NCH = SYMV_SEG / 512;  // 16-byte column chunks per thread
 
 template <int RW, bool NT, int ABL = 0>  // ABL: timing-only ablations for tools/tune_ell.hip (0 = the real kernel)
 __global__ __launch_bounds__(256) void k_symv(const double* __restrict__ Q, long long ld, long long n,
+                                              long long row0, long long nrows,
                                               const double* __restrict__ g, double* __restrict__ rowpart,
                                               double* __restrict__ colpart, const DevState* __restrict__ st) {
     __shared__ double red[4][SYMV_H];
@@ -307,12 +308,16 @@ __global__ __launch_bounds__(256) void k_symv(const double* __restrict__ Q, long
     const int wave = threadIdx.x >> 6;
     // grid = (strips, segments), strips in descending order (the widest first).  Measured alternative: making
     // the segment index the fast one (row-major traversal) is 19 % slower (profiles/r01/tune_symv.txt).
+    // Row shard (symmetric multi-GPU mode): Q holds the rows [row0, row0 + nrows) only; I counts local strips,
+    // every row / column index below is global.  Unsharded: row0 = 0, nrows = n.
     const long long I = (long long)gridDim.x - 1 - blockIdx.x;
     const long long J = blockIdx.y;
-    const long long r0 = I * SYMV_H;
+    const long long r0 = row0 + I * SYMV_H;
     const long long c0 = J * SYMV_SEG;
-    if (r0 >= n || c0 > r0 + SYMV_H - 1) return;  // nothing at or left of the diagonal in this segment
-    const long long rlast = (r0 + SYMV_H - 1 < n - 1) ? r0 + SYMV_H - 1 : n - 1;
+    const long long rend = row0 + nrows;  // one past the last local row
+    if (r0 >= rend || c0 > r0 + SYMV_H - 1) return;  // nothing at or left of the diagonal in this segment
+    const long long rlast = (r0 + SYMV_H - 1 < rend - 1) ? r0 + SYMV_H - 1 : rend - 1;
+    Q -= row0 * ld;  // so that Q + r * ld addresses global row r
     const bool full = c0 + SYMV_SEG - 1 < r0;  // every column of the segment is strictly left of every row
 
     long long ck[SYMV_NCH];
@@ -332,10 +337,10 @@ __global__ __launch_bounds__(256) void k_symv(const double* __restrict__ Q, long
 #pragma unroll
         for (int r = 0; r < RW; ++r) {
             rr[r] = r0 + rg * RW + r;
-            const bool rv = rr[r] < n;
+            const bool rv = rr[r] < rend;
             gr[r] = rv ? g[rr[r]] : 0.0;
             accr[r] = 0.0;
-            const double* row = Q + (rv ? rr[r] : n - 1) * ld;
+            const double* row = Q + (rv ? rr[r] : rend - 1) * ld;
 #pragma unroll
             for (int k = 0; k < SYMV_NCH; ++k) {
                 // load the pair when its first column is at or left of the diagonal of this row
@@ -370,7 +375,7 @@ __global__ __launch_bounds__(256) void k_symv(const double* __restrict__ Q, long
         }
     }
     __syncthreads();
-    if (threadIdx.x < SYMV_H && r0 + threadIdx.x < n) {
+    if (threadIdx.x < SYMV_H && r0 + threadIdx.x < rend) {
         const int r = threadIdx.x;
         rowpart[J * n + r0 + r] = ((red[0][r] + red[1][r]) + red[2][r]) + red[3][r];
     }
@@ -382,7 +387,8 @@ __global__ __launch_bounds__(256) void k_symv(const double* __restrict__ Q, long
 // y[i] = sum_{J <= i/SEG} rowpart[J][i] + sum_{I >= i/H} colpart[I][i]   (fixed order)
 // One workgroup per 128 columns: lane = column pair (16-byte loads, 1 KiB per wave-instruction), wave w
 // takes the strips I0 + w, I0 + w + 4, ...; the four wave sums are combined as ((w0+w1)+w2)+w3.
-__global__ __launch_bounds__(256) void k_symv_reduce(long long n, const double* __restrict__ rowpart,
+__global__ __launch_bounds__(256) void k_symv_reduce(long long n, long long row0, long long nrows,
+                                                     const double* __restrict__ rowpart,
                                                      const double* __restrict__ colpart,
                                                      double* __restrict__ y, const DevState* __restrict__ st) {
     __shared__ double2_t part[4][64];
@@ -390,10 +396,12 @@ __global__ __launch_bounds__(256) void k_symv_reduce(long long n, const double* 
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const long long i = (long long)blockIdx.x * 128 + 2 * lane;  // columns i, i+1 (n is even)
-    const long long nstrips = (n + SYMV_H - 1) / SYMV_H;
+    const long long nstrips = (nrows + SYMV_H - 1) / SYMV_H;     // local strips
+    // A row shard yields its PARTIAL sums for every column (zeros right of its last row); the ranks' partial
+    // vectors are added by the caller's all-reduce.  (row0 is a multiple of SYMV_H, so pairs never straddle.)
     double2_t s = {0.0, 0.0};
     if (i < n) {
-        for (long long I = i / SYMV_H + wave; I < nstrips; I += 4) {
+        for (long long I = (i < row0 ? 0 : (i - row0) / SYMV_H) + wave; I < nstrips; I += 4) {
             const double2_t v = *reinterpret_cast<const double2_t*>(colpart + I * n + i);
             s.x += v.x;
             s.y += v.y;
@@ -403,7 +411,8 @@ __global__ __launch_bounds__(256) void k_symv_reduce(long long n, const double* 
     __syncthreads();
     if (wave == 0 && i < n) {
         double2_t r = {0.0, 0.0};
-        for (long long J = 0; J <= i / SYMV_SEG; ++J) {
+        const bool local = i >= row0 && i < row0 + nrows;
+        for (long long J = 0; local && J <= i / SYMV_SEG; ++J) {
             const double2_t v = *reinterpret_cast<const double2_t*>(rowpart + J * n + i);
             r.x += v.x;
             r.y += v.y;

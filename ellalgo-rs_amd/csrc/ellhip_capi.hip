@@ -87,6 +87,7 @@ struct ellhip_space {
     int symv = 1;                    // allow the lower-triangle GEMV in deferred mode (ELLHIP_SYMV=0 disables)
     int symv_rw = 2;
     long long symv_min_n = 8192;     // below this the full-row pass is faster (few, small triangle tiles)
+    bool shard_symmetric = false;    // row shard whose GEMVs are partial symmetric sums (ellhip_set_shard_symmetric)
     int apply_lower = 1;             // with symv: apply passes touch the lower triangle only (ELLHIP_APPLY_LOWER)
     bool upper_stale = false;        // strict upper triangle of Q is out of date (see flush_pending)
     int defer = 1;                   // 1 = shrink Q at every cut; MAXPEND = record and apply in batches
@@ -423,25 +424,41 @@ int ellstable_issue(ellhip_space* s, const double* g_dev, const CutParams* cp_de
 
 // ---- the three primitives --------------------------------------------------------------------
 
-// Lower-triangle GEMV: deferred mode (Q_base is bit-symmetric and only read), whole matrix on this GPU.
+// Lower-triangle GEMV: deferred mode (Q_base is bit-symmetric and only read).  Unsharded handles from
+// symv_min_n up; a row shard only in its symmetric mode (ellhip_set_shard_symmetric), where the GEMV yields this
+// shard's PARTIAL sums over its lower trapezoid and the caller adds the shards' vectors (all-reduce).
 bool symv_ok(const ellhip_space* s) {
-    return deferring(s) && s->symv && !s->sharded && (s->n % 2) == 0 && s->n >= s->symv_min_n && s->d_rowpart;
+    if (!(deferring(s) && s->symv && (s->n % 2) == 0 && s->d_rowpart)) return false;
+    return s->sharded ? s->shard_symmetric : s->n >= s->symv_min_n;
+}
+
+int symv_alloc(ellhip_space* s) {
+    if (s->d_rowpart || (s->n % 2) != 0 || s->n < 512 || (s->sharded && !s->shard_symmetric)) return 0;
+    const size_t nsegs = (size_t)((s->n + SYMV_SEG - 1) / SYMV_SEG), nstrips = (size_t)((s->nrows + SYMV_H - 1) / SYMV_H);
+    HIPCHK(hipMalloc(&s->d_rowpart, nsegs * (size_t)s->n * sizeof(double)));
+    HIPCHK(hipMalloc(&s->d_colpart, nstrips * (size_t)s->n * sizeof(double)));
+    // rows of rowpart outside this shard are never written but are read by nobody either; zero them anyway
+    HIPCHK(hipMemsetAsync(s->d_rowpart, 0, nsegs * (size_t)s->n * sizeof(double), s->stream));
+    HIPCHK(hipMemsetAsync(s->d_colpart, 0, nstrips * (size_t)s->n * sizeof(double), s->stream));
+    return 0;
 }
 
 int launch_symv(ellhip_space* s, const double* g_dev, double* y_out) {
   {
     ProfScope ps(s, CLS_SYMV);
-    const unsigned nstrips = (unsigned)((s->n + SYMV_H - 1) / SYMV_H);
+    const unsigned nstrips = (unsigned)((s->nrows + SYMV_H - 1) / SYMV_H);  // local strips
     const unsigned nsegs = (unsigned)((s->n + SYMV_SEG - 1) / SYMV_SEG);
     const bool nt = s->sh_gemv.nt != 0;
 #define SYMV_CASE(RW)                                                                                         \
     if (s->symv_rw == RW) {                                                                                   \
         if (nt)                                                                                               \
             hipLaunchKernelGGL((k_symv<RW, true>), dim3(nstrips, nsegs), dim3(256), 0, s->stream,             \
-                               (const double*)s->d_Q, s->ld, s->n, g_dev, s->d_rowpart, s->d_colpart, s->d_st); \
+                               (const double*)s->d_Q, s->ld, s->n, s->row0, s->nrows, g_dev, s->d_rowpart,   \
+                               s->d_colpart, s->d_st);                                                        \
         else                                                                                                  \
             hipLaunchKernelGGL((k_symv<RW, false>), dim3(nstrips, nsegs), dim3(256), 0, s->stream,            \
-                               (const double*)s->d_Q, s->ld, s->n, g_dev, s->d_rowpart, s->d_colpart, s->d_st); \
+                               (const double*)s->d_Q, s->ld, s->n, s->row0, s->nrows, g_dev, s->d_rowpart,   \
+                               s->d_colpart, s->d_st);                                                        \
     }
     SYMV_CASE(1) SYMV_CASE(2) SYMV_CASE(4) SYMV_CASE(8)
 #undef SYMV_CASE
@@ -450,8 +467,8 @@ int launch_symv(ellhip_space* s, const double* g_dev, double* y_out) {
     HIPCHK(hipGetLastError());
   }
     ProfScope ps(s, CLS_SYMV_REDUCE);
-    hipLaunchKernelGGL(k_symv_reduce, dim3((unsigned)((s->n + 127) / 128)), dim3(256), 0, s->stream, s->n,
-                       (const double*)s->d_rowpart, (const double*)s->d_colpart, y_out, s->d_st);
+    hipLaunchKernelGGL(k_symv_reduce, dim3((unsigned)((s->n + 127) / 128)), dim3(256), 0, s->stream, s->n, s->row0,
+                       s->nrows, (const double*)s->d_rowpart, (const double*)s->d_colpart, y_out, s->d_st);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -460,6 +477,8 @@ int launch_symv(ellhip_space* s, const double* g_dev, double* y_out) {
 int do_prime(ellhip_space* s, const double* g_dev, int slot) {
     if (s->variant != ELLHIP_SPACE_ELL) return 0;
     if (symv_ok(s)) return launch_symv(s, g_dev, s->d_gt[slot]);
+    if (s->shard_symmetric)
+        return fail(ELLHIP_E_STATE, "symmetric row shard: only the deferred (depth 8) schedule is available");
     ProfScope ps(s, CLS_GEMV);
     return launch_sweep<false, true>(s, s->sh_gemv, nullptr, g_dev, s->d_gt[slot]);
 }
@@ -577,7 +596,9 @@ int make_q_current(ellhip_space* s) {
         rc = flush_pending(s, nullptr, nullptr);
         if (rc) return rc;
     }
-    if (s->upper_stale) {  // lower-triangle-only apply passes ran: rebuild the mirrored half
+    if (s->upper_stale && !s->sharded) {  // lower-triangle-only apply passes ran: rebuild the mirrored half
+        // (a symmetric row shard cannot: the mirrored elements live on other ranks; its rows stay valid up to
+        // their diagonal only, see ellhip_set_shard_symmetric)
         const unsigned t = (unsigned)((s->n + 31) / 32);
         hipLaunchKernelGGL(k_mirror_lower_now, dim3(t, t), dim3(256), 0, s->stream, s->d_Q, s->ld, s->n);
         HIPCHK(hipGetLastError());
@@ -886,6 +907,8 @@ int ellhip_clone(const ellhip_space* src_c, ellhip_space** out) {
     s->symv_rw = src->symv_rw;
     s->symv_min_n = src->symv_min_n;
     s->apply_lower = src->apply_lower;
+    s->shard_symmetric = src->shard_symmetric;
+    s->upper_stale = src->upper_stale;
     rc = alloc_common(s);
     if (rc) {
         ellhip_destroy(s);
@@ -1061,6 +1084,7 @@ int ellhip_get_mq(const ellhip_space* s_c, double* mq_out) {
 int ellhip_set_no_defer_trick(ellhip_space* s, int flag) {
     if (!s) return fail(ELLHIP_E_INVALID, "NULL handle");
     if (s->variant != ELLHIP_SPACE_ELL) return fail(ELLHIP_E_INVALID, "no_defer_trick exists on Ell only");
+    if (s->shard_symmetric && flag) return fail(ELLHIP_E_STATE, "symmetric row shard: no_defer_trick is not available");
     DeviceGuard guard(s->device);
     int rc = make_q_current(s);  // recorded updates belong to the old mode
     if (rc) return rc;
@@ -1072,19 +1096,36 @@ int ellhip_set_defer_depth(ellhip_space* s, int depth) {
     if (!s) return fail(ELLHIP_E_INVALID, "NULL handle");
     if (s->variant != ELLHIP_SPACE_ELL) return fail(ELLHIP_E_INVALID, "deferred shrink exists on Ell only");
     if (depth != 1 && depth != MAXPEND) return fail(ELLHIP_E_INVALID, "defer depth must be 1 or 8");
+    if (s->shard_symmetric && depth == 1 && s->upper_stale)
+        return fail(ELLHIP_E_STATE, "symmetric row shard: the rows are current up to their diagonal only");
     DeviceGuard guard(s->device);
     int rc = make_q_current(s);
     if (rc) return rc;
-    if (depth > 1 && !s->sharded && !s->d_rowpart && (s->n % 2) == 0 && s->n >= 512) {
-        const size_t nsegs = (size_t)((s->n + SYMV_SEG - 1) / SYMV_SEG), nstrips = (size_t)((s->n + SYMV_H - 1) / SYMV_H);
-        HIPCHK(hipMalloc(&s->d_rowpart, nsegs * (size_t)s->n * sizeof(double)));
-        HIPCHK(hipMalloc(&s->d_colpart, nstrips * (size_t)s->n * sizeof(double)));
+    if (depth > 1) {
+        rc = symv_alloc(s);
+        if (rc) return rc;
     }
     s->defer = depth;
     return 0;
 }
 
 int ellhip_defer_depth(const ellhip_space* s) { return s ? s->defer : 0; }
+
+int ellhip_set_shard_symmetric(ellhip_space* s, int flag) {
+    if (!s) return fail(ELLHIP_E_INVALID, "NULL handle");
+    if (!s->sharded || s->variant != ELLHIP_SPACE_ELL) return fail(ELLHIP_E_INVALID, "symmetric mode is for row shards of Ell");
+    if ((s->n % 2) != 0 || (s->row0 % SYMV_H) != 0 || ((s->row0 + s->nrows) % SYMV_H != 0 && s->row0 + s->nrows != s->n))
+        return fail(ELLHIP_E_INVALID, "symmetric row shard: n must be even and the shard boundaries multiples of 64");
+    if (s->in_two_phase || s->primed || s->shrink_pending || s->npend > 0 || s->upper_stale)
+        return fail(ELLHIP_E_STATE, "symmetric row shard: set the mode before the first update");
+    DeviceGuard guard(s->device);
+    s->shard_symmetric = flag != 0;
+    if (s->shard_symmetric && s->defer > 1) {
+        int rc = symv_alloc(s);
+        if (rc) return rc;
+    }
+    return 0;
+}
 
 int ellhip_set_use_parallel_cut(ellhip_space* s, int flag) {
     if (!s) return fail(ELLHIP_E_INVALID, "NULL handle");

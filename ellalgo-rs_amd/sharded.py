@@ -35,6 +35,30 @@ def partition(n: int, world: int, rank: int):
     return rank * nrows, nrows
 
 
+def partition_symmetric(n: int, world: int, rank: int, align: int = 64):
+    """Row blocks with equal LOWER-TRAPEZOID area: boundaries at n*sqrt(r/world), rounded to `align` rows (the
+    strip height of the lower-triangle GEMV).  Rank r then reads (b[r+1]^2 - b[r]^2)/2 ~ n^2/(2 world)
+    elements per GEMV, whatever r."""
+    if world < 1 or not (0 <= rank < world):
+        raise ValueError(f"bad rank {rank} of {world}")
+    if n % align or n // align < world:
+        raise ValueError(f"n={n} must be a multiple of {align} with at least one strip per rank")
+    nstrips = n // align
+    bounds = [0]
+    for r in range(1, world):
+        b = int(round(nstrips * (r / world) ** 0.5))
+        b = min(max(b, bounds[-1] + 1), nstrips - (world - r))  # strictly increasing, room for the others
+        bounds.append(b)
+    bounds.append(nstrips)
+    return bounds[rank] * align, (bounds[rank + 1] - bounds[rank]) * align
+
+
+def allreduce_in_place(gt, row0: int, nrows: int) -> None:
+    """Symmetric schedule: every rank holds partial sums for all n entries; one ncclAllReduce(sum) adds them."""
+    import torch.distributed as dist
+    dist.all_reduce(gt)
+
+
 def allgather_in_place(gt, row0: int, nrows: int) -> None:
     """Assemble the full gt on every rank: rank r contributes gt[row0:row0+nrows] (its own rows).
     With the nccl backend this is one ncclAllGather over xGMI, in place (send = recv + rank*count)."""
@@ -81,6 +105,9 @@ class HipShardEngine:
 
     def set_defer_depth(self, depth):
         capi.check(self._lib.ellhip_set_defer_depth(self.h, int(depth)), "ellhip_set_defer_depth")
+
+    def set_symmetric(self, flag=True):
+        capi.check(self._lib.ellhip_set_shard_symmetric(self.h, int(flag)), "ellhip_set_shard_symmetric")
 
     def queue_upload(self, k, kinds, grads, b0, has1, b1):
         capi.check(self._lib.ellhip_queue_upload(self.h, k, _p(kinds), _p(grads), _p(b0), _p(has1), _p(b1)),
@@ -155,19 +182,26 @@ class ShardedEll:
     Same SearchSpace surface as ellalgo_rs_amd.Ell; every rank must make the same calls."""
 
     def __init__(self, kappa, mq_rows, xc, *, diag=None, device=-1, rank=None, world=None,
-                 engine_factory=None, exchange=None):
+                 engine_factory=None, exchange=None, symmetric=False):
+        """symmetric=True: the deferred (depth 8) schedule with lower-triangle GEMVs and apply passes on row
+        blocks of equal trapezoid area (partition_symmetric), partial sums added by ONE all-reduce per update:
+        5 n^2 / P bytes per GPU and update instead of 9 n^2 / P.  Only that schedule is available then."""
         if rank is None or world is None:
             import torch.distributed as dist
             rank, world = dist.get_rank(), dist.get_world_size()
         self.rank, self.world = rank, world
         xc = _f64(xc)
         self.n = int(xc.size)
-        self.row0, self.nrows = partition(self.n, world, rank)
+        self.symmetric = bool(symmetric)
+        self.row0, self.nrows = (partition_symmetric if symmetric else partition)(self.n, world, rank)
         mq_rows = None if mq_rows is None else _f64(mq_rows, self.nrows * self.n)
         diag = None if diag is None else _f64(diag, self.n)
         factory = engine_factory or (lambda *a: HipShardEngine(*a, device=device))
         self.engine = factory(self.n, self.row0, self.nrows, float(kappa), mq_rows, diag, xc)
-        self._exchange = exchange or allgather_in_place
+        self._exchange = exchange or (allreduce_in_place if symmetric else allgather_in_place)
+        if symmetric:
+            self.engine.set_symmetric(True)
+            self.engine.set_defer_depth(8)
         self._qk = 0
         self._primed_index = -1
 
@@ -221,7 +255,7 @@ class ShardedEll:
 
     @property
     def mq_rows(self) -> np.ndarray:
-        """This rank's row block of Q."""
+        """This rank's row block of Q (symmetric mode: current up to each row's diagonal only)."""
         return self.engine.mq_rows()
 
     def set_defer_depth(self, depth: int) -> None:

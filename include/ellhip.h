@@ -170,6 +170,16 @@ int ellhip_commit(ellhip_space *s, const double *next_grad);
  * depth 8 (both stay within the parity tolerance; shards agree with each other bit for bit). */
 int ellhip_set_defer_depth(ellhip_space *s, int depth);
 int ellhip_defer_depth(const ellhip_space *s);
+/* Symmetric row shard (multi-GPU, deferred schedule only).  Call once after ellhip_create_shard, together with
+ * ellhip_set_defer_depth(h, 8), on every rank; shard boundaries must be multiples of 64 and n even.  The GEMV
+ * of each cut then reads only this shard's LOWER trapezoid (columns up to each row's diagonal) and leaves in the
+ * gt buffer this shard's PARTIAL sums for all n entries (row sums for its rows, column sums for the columns left
+ * of them, zeros to the right): the caller adds the shards' vectors with ONE all-reduce (sum) instead of the
+ * all-gather of the row-block schedule.  Choosing the boundaries at n*sqrt(r/P) balances the trapezoids, so each
+ * GPU moves 5 n^2 / P bytes per update instead of 9 n^2 / P.  The apply passes touch the lower trapezoid only
+ * too: ellhip_get_mq on such a shard returns rows that are current up to their diagonal (the mirrored elements
+ * live on other ranks).  Depth-1 schedules and no_defer_trick are refused (ELLHIP_E_STATE). */
+int ellhip_set_shard_symmetric(ellhip_space *s, int flag);
 
 /* ---- device-resident cut queue (benchmarks, replay of recorded cut sequences) ---------------
  * Uploads k cuts once; run/begin/end then execute them without touching host memory, stopping

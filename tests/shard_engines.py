@@ -27,9 +27,28 @@ class OracleShardEngine:
         self.halted = False
         self.pending = None
 
+    symmetric = False
+
+    def set_symmetric(self, flag=True):
+        """ellhip_set_shard_symmetric: the GEMV yields this shard's partial sums over its lower trapezoid (the
+        double keeps its full rows current; only the GEMV's data flow is what the orchestration test is about)."""
+        self.symmetric = bool(flag)
+
+    def set_defer_depth(self, depth):
+        pass
+
     # ---- the three primitives (mirror of prime / cut / commit in csrc/ellhip_capi.hip)
     def _gemv(self, g):
-        oracle.rows_gemv(self.n, self.row0, self.nrows, self.Q, g, self.gt_np)
+        if not self.symmetric:
+            oracle.rows_gemv(self.n, self.row0, self.nrows, self.Q, g, self.gt_np)
+            return
+        y = np.zeros(self.n)
+        for r in range(self.nrows):
+            i = self.row0 + r
+            row = self.Q[r, :i + 1]
+            y[i] += float(row @ g[:i + 1])          # row sums, columns up to the diagonal
+            y[:i] += row[:i] * g[i]                  # column sums, strictly below the diagonal
+        self.gt_np[:] = y                            # partial: the all-reduce adds the shards' vectors
 
     def _scalar(self) -> int:
         kind, g, b0, b1 = self.cut

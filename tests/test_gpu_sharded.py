@@ -27,7 +27,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, backend, n, k, fused, defer, errq):
+def _worker(rank, world, port, backend, n, k, fused, defer, errq, symmetric=False):
     try:
         for p in (ROOT, HERE):
             if p not in sys.path:
@@ -52,12 +52,23 @@ def _worker(rank, world, port, backend, n, k, fused, defer, errq):
             dist.all_gather(parts, mine)
             gt.copy_(torch.cat(parts).to(gt.device))
 
+        def bounce_sum(gt, row0, nrows):  # symmetric schedule: all-reduce of the partial vectors, via gloo
+            torch.cuda.current_stream().synchronize()
+            t = gt.cpu()
+            dist.all_reduce(t)
+            gt.copy_(t.to(gt.device))
+
         kinds, grads, b0, b1 = synth.parallel_cuts(n, k)
         ref = pkg.Ell.new_with_scalar(1.0, np.zeros(n), device=0)
-        sh = ShardedEll.new_with_scalar(1.0, np.zeros(n), device=0, exchange=None if backend == "nccl" else bounce)
+        ex = None if backend == "nccl" else (bounce_sum if symmetric else bounce)
+        sh = ShardedEll.new_with_scalar(1.0, np.zeros(n), device=0, exchange=ex, symmetric=symmetric)
+        if symmetric:
+            from ellalgo_rs_amd.sharded import partition_symmetric
+            assert (sh.row0, sh.nrows) == partition_symmetric(n, world, rank)
         if defer != 1:
             ref.defer_depth = defer
-            sh.set_defer_depth(defer)
+            if not symmetric:   # (the symmetric constructor has selected depth 8 already)
+                sh.set_defer_depth(defer)
         half = k // 2
         # depth 8: the unsharded reference takes the lower-triangle GEMV, a shard the full-row one: same
         # vector to rounding.  depth 1: identical kernels, identical bits.
@@ -79,7 +90,11 @@ def _worker(rank, world, port, backend, n, k, fused, defer, errq):
         st_s, ts_s = sh.queue_results()
         st_r, ts_r = ref.queue_results()
         assert np.array_equal(st_s, st_r) and same(ts_s, ts_r) and np.all(st_r == 0)
-        assert same(sh.mq_rows, ref.mq[sh.row0:sh.row0 + sh.nrows]), "Q rows differ from unsharded engine"
+        mine, want = sh.mq_rows, ref.mq[sh.row0:sh.row0 + sh.nrows]
+        if symmetric:   # rows are current up to their diagonal only; the mirrored half lives on other ranks
+            keep = np.arange(n)[None, :] <= (sh.row0 + np.arange(sh.nrows))[:, None]
+            mine, want = np.where(keep, mine, 0.0), np.where(keep, want, 0.0)
+        assert same(mine, want), "Q rows differ from unsharded engine"
         assert same(sh.xc(), ref.xc()) and same([sh.kappa], [ref.kappa])
         dist.barrier()
         dist.destroy_process_group()
@@ -88,11 +103,12 @@ def _worker(rank, world, port, backend, n, k, fused, defer, errq):
         raise
 
 
-def _run(world, backend, n, k, fused=False, defer=1):
+def _run(world, backend, n, k, fused=False, defer=1, symmetric=False):
     ctx = mp.get_context("spawn")
     errq = ctx.SimpleQueue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, backend, n, k, fused, defer, errq)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, backend, n, k, fused, defer, errq, symmetric))
+             for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
@@ -130,3 +146,33 @@ def test_one_rank_rccl_in_place_allgather(gpu):
 
 def test_one_rank_rccl_pipelined_schedule(gpu):
     _run(1, "nccl", 1024, 12, fused=True)
+
+
+@pytest.mark.parametrize("world,n,fused", [(2, 512, True), (2, 1024, False), (3, 1536, True)])
+def test_symmetric_shards_share_one_gpu(gpu, world, n, fused):
+    """ellhip_set_shard_symmetric: sqrt row partition, partial lower-trapezoid GEMVs added by an all-reduce (gloo
+    transport between the ranks sharing the card), lower-trapezoid apply passes; against the unsharded engine."""
+    _run(world, "gloo", n, 40, fused=fused, defer=8, symmetric=True)
+
+
+def test_symmetric_shard_one_rank_rccl_all_reduce(gpu):
+    _run(1, "nccl", 1024, 40, fused=True, defer=8, symmetric=True)
+
+
+def test_symmetric_shard_refuses_other_schedules(gpu):
+    import ctypes as C
+    lib = gpu.capi.load()
+    n = 256
+    h = C.c_void_p()
+    gpu.capi.check(lib.ellhip_create_shard(C.byref(h), n, 64, 128, 1.0, None, None, None, -1))
+    gpu.capi.check(lib.ellhip_set_shard_symmetric(h, 1))
+    g = np.ones(n)
+    # depth 1: refused loudly (the all-reduce data flow needs the partial symmetric GEMV)
+    assert lib.ellhip_update_begin(h, 0, g.ctypes.data_as(C.c_void_p), 0.01, 0, 0.0) == gpu.capi.E_STATE
+    assert lib.ellhip_set_no_defer_trick(h, 1) == gpu.capi.E_STATE
+    lib.ellhip_destroy(h)
+    gpu.capi.check(lib.ellhip_create_shard(C.byref(h), n, 32, 128, 1.0, None, None, None, -1))
+    assert lib.ellhip_set_shard_symmetric(h, 1) == gpu.capi.E_INVALID   # boundaries must be multiples of 64
+    lib.ellhip_destroy(h)
+    e = gpu.Ell.new_with_scalar(1.0, np.zeros(n))
+    assert lib.ellhip_set_shard_symmetric(e._h, 1) == gpu.capi.E_INVALID  # not a shard

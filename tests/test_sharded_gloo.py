@@ -42,8 +42,14 @@ def _worker(rank, world, port, n, k, mode, errq):
         rng = np.random.default_rng(42)  # same stream on every rank
         xc0 = np.linspace(-1.0, 1.0, n)
         ref = oracle.OracleEll.new_with_scalar(2.0, xc0)
-        sh = ShardedEll.new_with_scalar(2.0, xc0, engine_factory=OracleShardEngine)
-        row0, nrows = partition(n, world, rank)
+        symmetric = mode.startswith("sym_")
+        mode = mode[4:] if symmetric else mode
+        sh = ShardedEll.new_with_scalar(2.0, xc0, engine_factory=OracleShardEngine, symmetric=symmetric)
+        if symmetric:
+            from ellalgo_rs_amd.sharded import partition_symmetric
+            row0, nrows = partition_symmetric(n, world, rank)
+        else:
+            row0, nrows = partition(n, world, rank)
         assert (sh.row0, sh.nrows) == (row0, nrows)
         cuts = []
         for i in range(k):
@@ -56,7 +62,10 @@ def _worker(rank, world, port, n, k, mode, errq):
             if mode == "direct":
                 ss = sh._update(kind, (g, (b0, b1)))
                 assert int(ss) == so, (i, int(ss), so)
-                assert sh.tsq() == ref.tsq
+                if symmetric:   # partial sums added across ranks: same value, another association
+                    assert abs(sh.tsq() - ref.tsq) <= 1e-12 * abs(ref.tsq)
+                else:
+                    assert sh.tsq() == ref.tsq
         if mode in ("queue", "queue_fused"):
             # the queue halts at the first failure, so replay only the successful prefix rule: build a
             # fresh reference that stops like the drivers do
@@ -78,12 +87,17 @@ def _worker(rank, world, port, n, k, mode, errq):
                     assert st[i] == 3
                     continue
                 so = ref.update(kind, g, b0, b1)
-                assert st[i] == so and ts[i] == ref.tsq
+                assert st[i] == so
+                assert ts[i] == ref.tsq or (symmetric and abs(ts[i] - ref.tsq) <= 1e-12 * abs(ref.tsq))
                 halted = so != 0
-        # every rank: its rows of Q, the full xc and kappa, bit for bit
-        assert np.array_equal(sh.mq_rows, ref.mq[row0:row0 + nrows]), "Q rows differ"
-        assert np.array_equal(sh.xc(), ref.xc), "xc differs"
-        assert sh.kappa == ref.kappa
+        if symmetric:
+            assert np.allclose(sh.mq_rows, ref.mq[row0:row0 + nrows], rtol=1e-11, atol=1e-14), "Q rows differ"
+            assert np.allclose(sh.xc(), ref.xc, rtol=1e-11, atol=1e-14), "xc differs"
+            assert abs(sh.kappa - ref.kappa) <= 1e-12 * ref.kappa
+        else:   # every rank: its rows of Q, the full xc and kappa, bit for bit
+            assert np.array_equal(sh.mq_rows, ref.mq[row0:row0 + nrows]), "Q rows differ"
+            assert np.array_equal(sh.xc(), ref.xc), "xc differs"
+            assert sh.kappa == ref.kappa
         # and the ranks agree with each other
         xs = [torch.zeros(n, dtype=torch.float64) for _ in range(world)]
         dist.all_gather(xs, torch.from_numpy(sh.xc()))
@@ -126,6 +140,28 @@ def test_sharded_queue_bit_identical_and_halts():
 
 def test_sharded_pipelined_queue_bit_identical_and_halts():
     _run(2, 48, 16, "queue_fused")
+
+
+@pytest.mark.parametrize("world,n,mode", [(2, 128, "sym_direct"), (3, 320, "sym_direct"), (2, 192, "sym_queue_fused"),
+                                          (4, 512, "sym_queue")])
+def test_symmetric_sharding_all_reduce_schedule(world, n, mode):
+    """Row blocks of equal trapezoid area, partial symmetric GEMVs, ONE all-reduce per update (gloo)."""
+    _run(world, n, 16, mode)
+
+
+def test_symmetric_partition_rules():
+    sys.path.insert(0, ROOT)
+    from ellalgo_rs_amd.sharded import partition_symmetric
+    for n, world in ((16384, 2), (16384, 8), (32768, 8), (512, 3), (128, 2)):
+        parts = [partition_symmetric(n, world, r) for r in range(world)]
+        assert parts[0][0] == 0 and sum(p[1] for p in parts) == n
+        assert all(p[0] % 64 == 0 and p[1] % 64 == 0 and p[1] > 0 for p in parts)
+        assert all(parts[r + 1][0] == parts[r][0] + parts[r][1] for r in range(world - 1))
+        if n >= 16384:
+            areas = [((r0 + nr) ** 2 - r0 ** 2) / 2 for r0, nr in parts]
+            assert max(areas) <= 1.05 * n * n / 2 / world
+    with pytest.raises(ValueError):
+        partition_symmetric(100, 2, 0)
 
 
 def test_partition_rules():

@@ -88,11 +88,11 @@ int main(int argc, char** argv) {
 #define SYMVV(RW, NT, ABL)                                                                                   \
     vs.push_back({std::string("symv  RW" #RW) + (NT ? " nt" : "   ") + " abl" #ABL, 4.0 * n2, [=](hipStream_t q, int) { \
                       dim3 grid((unsigned)((n + SYMV_H - 1) / SYMV_H), (unsigned)((n + SYMV_SEG - 1) / SYMV_SEG));       \
-                      hipLaunchKernelGGL((k_symv<RW, NT, ABL>), grid, dim3(256), 0, q, Q, ld, n, g, rowpart, colpart, st); \
+                      hipLaunchKernelGGL((k_symv<RW, NT, ABL>), grid, dim3(256), 0, q, Q, ld, n, 0LL, n, g, rowpart, colpart, st); \
                   }, {}});
     SYMVV(2, true, 0) SYMVV(2, true, 1) SYMVV(2, true, 2) SYMVV(4, true, 0) SYMVV(4, true, 1) SYMVV(2, false, 0)
     vs.push_back({"symv reduce", 0.0, [=](hipStream_t q, int) {
-                      hipLaunchKernelGGL(k_symv_reduce, dim3((unsigned)((n + 127) / 128)), dim3(256), 0, q, n, rowpart, colpart, gt2, st);
+                      hipLaunchKernelGGL(k_symv_reduce, dim3((unsigned)((n + 127) / 128)), dim3(256), 0, q, n, 0LL, n, rowpart, colpart, gt2, st);
                   }, {}});
     hipEvent_t a, b;
     CK(hipEventCreate(&a));
