@@ -457,8 +457,12 @@ def main() -> None:
     # N > 1, depth 8: symmetric row shards (equal lower-trapezoid areas, partial symmetric GEMVs added by one
     # all-reduce, lower-trapezoid apply passes): 5*n^2/P bytes per GPU and update.  That schedule only, so the
     # other schedules are not timed alongside.
+    # (taken when a rank's trapezoid still fills the GPU with 64 x 2048 tiles: n = 16384 up to P = 4, n = 32768 up to
+    # P = 8; below that the lower-triangle GEMV is latency bound and equal row blocks with full-row GEMVs are faster:
+    # measured per rank with tools/shard_timing.py)
+    sym_default = "1" if (float(n) * n / 2 / world) / (64 * 2048) >= 200 else "0"
     shard_sym = (sharded and variant == "ell" and depth == 8 and n % 64 == 0 and n // 64 >= world
-                 and os.environ.get("ELLHIP_SHARD_SYMMETRIC", "1") != "0")
+                 and os.environ.get("ELLHIP_SHARD_SYMMETRIC", sym_default) != "0")
     if shard_sym:
         C2 = 0
     # alternatives measured after the main run, on the same handle: (schedule, depth)

@@ -294,14 +294,17 @@ __global__ __launch_bounds__(256) void k_sweep(const double* Q, double* Qout, lo
 #define ELLHIP_SYMV_SEG 2048
 #endif
 constexpr int SYMV_H = ELLHIP_SYMV_H;      // (macros: tuning builds only, see profiles/r01/tune_symv.txt)
-constexpr int SYMV_SEG = ELLHIP_SYMV_SEG;
-constexpr int SYMV_NCH = SYMV_SEG / 512;  // 16-byte column chunks per thread
+constexpr int SYMV_SEG = ELLHIP_SYMV_SEG;  // default segment width; row shards with few tiles use SYMV_SEG_SMALL
+constexpr int SYMV_SEG_SMALL = 512;
 
-template <int RW, bool NT, int ABL = 0>  // ABL: timing-only ablations for tools/tune_ell.hip (0 = the real kernel)
+// SEG: segment width (2048 by default; 512 where a shard's trapezoid would give fewer tiles than the GPU has
+// room for -- at P = 8 a rank has ~130 tiles of 64 x 2048 but ~520 of 64 x 512).
+template <int RW, bool NT, int ABL = 0, int SEG = SYMV_SEG>  // ABL: timing-only ablations for tools/tune_ell.hip
 __global__ __launch_bounds__(256) void k_symv(const double* __restrict__ Q, long long ld, long long n,
                                               long long row0, long long nrows,
                                               const double* __restrict__ g, double* __restrict__ rowpart,
                                               double* __restrict__ colpart, const DevState* __restrict__ st) {
+    constexpr int SYMV_NCH = SEG / 512;  // 16-byte column chunks per thread
     __shared__ double red[4][SYMV_H];
     if (st->halted) return;
     const int lane = threadIdx.x & 63;
@@ -313,12 +316,12 @@ __global__ __launch_bounds__(256) void k_symv(const double* __restrict__ Q, long
     const long long I = (long long)gridDim.x - 1 - blockIdx.x;
     const long long J = blockIdx.y;
     const long long r0 = row0 + I * SYMV_H;
-    const long long c0 = J * SYMV_SEG;
+    const long long c0 = J * SEG;
     const long long rend = row0 + nrows;  // one past the last local row
     if (r0 >= rend || c0 > r0 + SYMV_H - 1) return;  // nothing at or left of the diagonal in this segment
     const long long rlast = (r0 + SYMV_H - 1 < rend - 1) ? r0 + SYMV_H - 1 : rend - 1;
     Q -= row0 * ld;  // so that Q + r * ld addresses global row r
-    const bool full = c0 + SYMV_SEG - 1 < r0;  // every column of the segment is strictly left of every row
+    const bool full = c0 + SEG - 1 < r0;  // every column of the segment is strictly left of every row
 
     long long ck[SYMV_NCH];
     double2_t gc[SYMV_NCH], accc[SYMV_NCH];
@@ -387,7 +390,7 @@ __global__ __launch_bounds__(256) void k_symv(const double* __restrict__ Q, long
 // y[i] = sum_{J <= i/SEG} rowpart[J][i] + sum_{I >= i/H} colpart[I][i]   (fixed order)
 // One workgroup per 128 columns: lane = column pair (16-byte loads, 1 KiB per wave-instruction), wave w
 // takes the strips I0 + w, I0 + w + 4, ...; the four wave sums are combined as ((w0+w1)+w2)+w3.
-__global__ __launch_bounds__(256) void k_symv_reduce(long long n, long long row0, long long nrows,
+__global__ __launch_bounds__(256) void k_symv_reduce(long long n, long long row0, long long nrows, long long seg,
                                                      const double* __restrict__ rowpart,
                                                      const double* __restrict__ colpart,
                                                      double* __restrict__ y, const DevState* __restrict__ st) {
@@ -412,7 +415,7 @@ __global__ __launch_bounds__(256) void k_symv_reduce(long long n, long long row0
     if (wave == 0 && i < n) {
         double2_t r = {0.0, 0.0};
         const bool local = i >= row0 && i < row0 + nrows;
-        for (long long J = 0; local && J <= i / SYMV_SEG; ++J) {
+        for (long long J = 0; local && J <= i / seg; ++J) {
             const double2_t v = *reinterpret_cast<const double2_t*>(rowpart + J * n + i);
             r.x += v.x;
             r.y += v.y;

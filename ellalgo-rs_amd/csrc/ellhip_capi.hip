@@ -88,6 +88,7 @@ struct ellhip_space {
     int symv_rw = 2;
     long long symv_min_n = 8192;     // below this the full-row pass is faster (few, small triangle tiles)
     bool shard_symmetric = false;    // row shard whose GEMVs are partial symmetric sums (ellhip_set_shard_symmetric)
+    int symv_seg = SYMV_SEG;         // segment width of the lower-triangle GEMV's tiles (see symv_alloc)
     int apply_lower = 1;             // with symv: apply passes touch the lower triangle only (ELLHIP_APPLY_LOWER)
     bool upper_stale = false;        // strict upper triangle of Q is out of date (see flush_pending)
     int defer = 1;                   // 1 = shrink Q at every cut; MAXPEND = record and apply in batches
@@ -434,7 +435,14 @@ bool symv_ok(const ellhip_space* s) {
 
 int symv_alloc(ellhip_space* s) {
     if (s->d_rowpart || (s->n % 2) != 0 || s->n < 512 || (s->sharded && !s->shard_symmetric)) return 0;
-    const size_t nsegs = (size_t)((s->n + SYMV_SEG - 1) / SYMV_SEG), nstrips = (size_t)((s->nrows + SYMV_H - 1) / SYMV_H);
+    // tiles of 64 x 2048 in this handle's lower trapezoid; with fewer than ~200 (less than one per CU) the narrow
+    // segments win (measured per rank at n = 16384: P = 8, 128 tiles: 0.049 vs 0.061 ms; P = 4, 256 tiles: 0.078 vs
+    // 0.067; P = 2: 0.109 vs 0.104; unsharded n = 8192, 256 tiles: 0.076 vs 0.066)
+    const double area = ((double)(s->row0 + s->nrows) * (double)(s->row0 + s->nrows) - (double)s->row0 * (double)s->row0) / 2.0;
+    s->symv_seg = (area / (64.0 * SYMV_SEG) < 200.0) ? SYMV_SEG_SMALL : SYMV_SEG;
+    s->symv_seg = env_int("ELLHIP_SYMV_SEG", s->symv_seg);
+    if (s->symv_seg != SYMV_SEG && s->symv_seg != SYMV_SEG_SMALL) return fail(ELLHIP_E_INVALID, "ELLHIP_SYMV_SEG must be 512 or 2048");
+    const size_t nsegs = (size_t)((s->n + s->symv_seg - 1) / s->symv_seg), nstrips = (size_t)((s->nrows + SYMV_H - 1) / SYMV_H);
     HIPCHK(hipMalloc(&s->d_rowpart, nsegs * (size_t)s->n * sizeof(double)));
     HIPCHK(hipMalloc(&s->d_colpart, nstrips * (size_t)s->n * sizeof(double)));
     // rows of rowpart outside this shard are never written but are read by nobody either; zero them anyway
@@ -444,31 +452,36 @@ int symv_alloc(ellhip_space* s) {
 }
 
 int launch_symv(ellhip_space* s, const double* g_dev, double* y_out) {
+    const int seg = s->symv_seg;
   {
     ProfScope ps(s, CLS_SYMV);
     const unsigned nstrips = (unsigned)((s->nrows + SYMV_H - 1) / SYMV_H);  // local strips
-    const unsigned nsegs = (unsigned)((s->n + SYMV_SEG - 1) / SYMV_SEG);
+    const unsigned nsegs = (unsigned)((s->n + seg - 1) / seg);
     const bool nt = s->sh_gemv.nt != 0;
-#define SYMV_CASE(RW)                                                                                         \
-    if (s->symv_rw == RW) {                                                                                   \
-        if (nt)                                                                                               \
-            hipLaunchKernelGGL((k_symv<RW, true>), dim3(nstrips, nsegs), dim3(256), 0, s->stream,             \
-                               (const double*)s->d_Q, s->ld, s->n, s->row0, s->nrows, g_dev, s->d_rowpart,   \
-                               s->d_colpart, s->d_st);                                                        \
-        else                                                                                                  \
-            hipLaunchKernelGGL((k_symv<RW, false>), dim3(nstrips, nsegs), dim3(256), 0, s->stream,            \
-                               (const double*)s->d_Q, s->ld, s->n, s->row0, s->nrows, g_dev, s->d_rowpart,   \
-                               s->d_colpart, s->d_st);                                                        \
+    const int rw = (seg == SYMV_SEG) ? s->symv_rw : 8;  // narrow segments: 8 rows x 1 chunk in flight per thread
+    bool done = false;
+#define SYMV_GO(RW, NTV, SEGV)                                                                               \
+    hipLaunchKernelGGL((k_symv<RW, NTV, 0, SEGV>), dim3(nstrips, nsegs), dim3(256), 0, s->stream,            \
+                       (const double*)s->d_Q, s->ld, s->n, s->row0, s->nrows, g_dev, s->d_rowpart, s->d_colpart, \
+                       s->d_st);                                                                            \
+    done = true
+#define SYMV_CASE(RW)                                                   \
+    if (!done && seg == SYMV_SEG && rw == RW) {                         \
+        if (nt) { SYMV_GO(RW, true, SYMV_SEG); } else { SYMV_GO(RW, false, SYMV_SEG); } \
     }
     SYMV_CASE(1) SYMV_CASE(2) SYMV_CASE(4) SYMV_CASE(8)
 #undef SYMV_CASE
-    if (s->symv_rw != 1 && s->symv_rw != 2 && s->symv_rw != 4 && s->symv_rw != 8)
-        return fail(ELLHIP_E_INVALID, "unsupported ELLHIP_SYMV_RW (1, 2, 4, 8)");
+    if (!done && seg == SYMV_SEG_SMALL) {
+        if (nt) { SYMV_GO(8, true, SYMV_SEG_SMALL); } else { SYMV_GO(8, false, SYMV_SEG_SMALL); }
+    }
+#undef SYMV_GO
+    if (!done) return fail(ELLHIP_E_INVALID, "unsupported ELLHIP_SYMV_RW (1, 2, 4, 8) / ELLHIP_SYMV_SEG (512, 2048)");
     HIPCHK(hipGetLastError());
   }
     ProfScope ps(s, CLS_SYMV_REDUCE);
     hipLaunchKernelGGL(k_symv_reduce, dim3((unsigned)((s->n + 127) / 128)), dim3(256), 0, s->stream, s->n, s->row0,
-                       s->nrows, (const double*)s->d_rowpart, (const double*)s->d_colpart, y_out, s->d_st);
+                       s->nrows, (long long)seg, (const double*)s->d_rowpart, (const double*)s->d_colpart, y_out,
+                       s->d_st);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -909,6 +922,7 @@ int ellhip_clone(const ellhip_space* src_c, ellhip_space** out) {
     s->apply_lower = src->apply_lower;
     s->shard_symmetric = src->shard_symmetric;
     s->upper_stale = src->upper_stale;
+    s->symv_seg = src->symv_seg;
     rc = alloc_common(s);
     if (rc) {
         ellhip_destroy(s);
