@@ -404,7 +404,19 @@ __global__ __launch_bounds__(256) void k_symv_reduce(long long n, long long row0
     // vectors are added by the caller's all-reduce.  (row0 is a multiple of SYMV_H, so pairs never straddle.)
     double2_t s = {0.0, 0.0};
     if (i < n) {
-        for (long long I = (i < row0 ? 0 : (i - row0) / SYMV_H) + wave; I < nstrips; I += 4) {
+        // loads are independent of the running sums: keep 8 of them in flight, add in strip order
+        long long I = (i < row0 ? 0 : (i - row0) / SYMV_H) + wave;
+        for (; I + 28 < nstrips; I += 32) {
+            double2_t v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const double2_t*>(colpart + (I + 4 * u) * n + i);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                s.x += v[u].x;
+                s.y += v[u].y;
+            }
+        }
+        for (; I < nstrips; I += 4) {
             const double2_t v = *reinterpret_cast<const double2_t*>(colpart + I * n + i);
             s.x += v.x;
             s.y += v.y;
@@ -587,7 +599,7 @@ __global__ __launch_bounds__(256) void k_pend_reset(double* __restrict__ pend, d
 // butterfly, ((w0+w1)+w2)+w3, then the partials in index order), so omega has the same bits on every
 // rank of a row-partitioned run and in every schedule.
 __host__ __device__ inline int scalar_groups(long long n) {
-    long long g = n / 1024;  // >= 1024 elements per workgroup
+    long long g = n / 1024;  // >= 1024 elements per workgroup (64 groups of 256 measured slower: 22.7 vs 17.8 us)
     if (g < 1) g = 1;
     if (g > 64) g = 64;
     return (int)g;
@@ -749,14 +761,18 @@ __global__ __launch_bounds__(256) void k_scalar_apply_def(long long n, const dou
         }
         return;
     }
-    if (tid == 0) {
+    __shared__ double dsum[MAXPEND + 1];
+    if (tid <= MAXPEND) {  // one thread per partial-sum column, workgroups in index order
         const int G = scalar_groups(n);
+        double a = 0.0;
+        for (int b = 0; b < G; ++b) a += partial[(long long)b * (MAXPEND + 1) + tid];
+        dsum[tid] = a;
+    }
+    __syncthreads();
+    if (tid == 0) {
         double d[MAXPEND + 1];
 #pragma unroll
-        for (int k = 0; k <= MAXPEND; ++k) d[k] = 0.0;
-        for (int b = 0; b < G; ++b)
-#pragma unroll
-            for (int k = 0; k <= MAXPEND; ++k) d[k] += partial[(long long)b * (MAXPEND + 1) + k];
+        for (int k = 0; k <= MAXPEND; ++k) d[k] = dsum[k];
         double omega = d[0];  // g.(Q_base g)
 #pragma unroll
         for (int j = 0; j < MAXPEND; ++j) {
