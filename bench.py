@@ -406,7 +406,7 @@ def main() -> None:
     ap.add_argument("--schedule", choices=["pipelined", "two-pass"], default="pipelined",
                     help="pipelined: one pass over Q per update (shrink of cut k fused with the GEMV of cut k+1, "
                          "16*n^2 B); two-pass: GEMV pass + rank-1 pass per update (24*n^2 B). Same results.")
-    ap.add_argument("--defer", type=int, choices=[1, 8], default=8,
+    ap.add_argument("--defer", type=int, choices=[1, 8, 16], default=8,
                     help="8: record cuts and apply them to Q in batches of 8 (GEMV passes are read-only, "
                          "8*n^2*(1+1/8) B per update); 1: rewrite Q at every cut like the reference. Same results "
                          "to the 1e-10 parity tolerance.")
@@ -461,14 +461,16 @@ def main() -> None:
     # P = 8; below that the lower-triangle GEMV is latency bound and equal row blocks with full-row GEMVs are faster:
     # measured per rank with tools/shard_timing.py)
     sym_default = "1" if (float(n) * n / 2 / world) / (64 * 2048) >= 200 else "0"
-    shard_sym = (sharded and variant == "ell" and depth == 8 and n % 64 == 0 and n // 64 >= world
+    shard_sym = (sharded and variant == "ell" and depth in (8, 16) and n % 64 == 0 and n // 64 >= world
                  and os.environ.get("ELLHIP_SHARD_SYMMETRIC", sym_default) != "0")
     if shard_sym:
         C2 = 0
     # alternatives measured after the main run, on the same handle: (schedule, depth)
     alts = []
     if C2 > 0:
-        for alt in (("pipelined", 8), ("pipelined", 1), ("two-pass", 8), ("two-pass", 1)):
+        for alt in (("pipelined", 16), ("pipelined", 8), ("pipelined", 1), ("two-pass", 8), ("two-pass", 1)):
+            if alt[1] == 16 and (sharded or n % 2 or n < int(os.environ.get("ELLHIP_SYMV_MIN_N", "8192"))):
+                continue  # depth 16 exists on the lower-triangle schedule only
             if alt != (args.schedule, depth):
                 alts.append(alt)
     total = W + K + P + 2 * C2 * len(alts) + H
@@ -488,7 +490,8 @@ def main() -> None:
         space = (pkg.Ell if variant == "ell" else pkg.EllStable).new_with_scalar(1.0, np.zeros(n), device=local_rank)
     else:
         from ellalgo_rs_amd.sharded import ShardedEll
-        space = ShardedEll.new_with_scalar(1.0, np.zeros(n), device=local_rank, symmetric=shard_sym)
+        space = ShardedEll.new_with_scalar(1.0, np.zeros(n), device=local_rank, symmetric=shard_sym,
+                                          defer_depth=depth if shard_sym else 8)
     nq = W + K + P + 2 * C2 * len(alts)
     if variant == "ell" and depth != 1 and not shard_sym:
         space.set_defer_depth(depth) if sharded else setattr(space, "defer_depth", depth)
@@ -591,9 +594,9 @@ def main() -> None:
                 return 16.0 * n2w, "16*n^2 B/update (rank-1 pass of cut k fused with the GEMV of cut k+1)"
             return 24.0 * n2w, "24*n^2 B/update (GEMV pass 8 + rank-1 pass 16; SURVEY 8d)"
         if symv_mode and lower_apply:
-            return 5.0 * n2w, ("5*n^2 B/update (deferred shrink, depth 8: eight lower-triangle GEMV passes of 4*n^2 + one "
-                               "lower-triangle apply pass of 8*n^2 per 8 updates; the upper triangle is mirrored back "
-                               "only when Q itself is read" +
+            return (4.0 + 8.0 / dep) * n2w, (f"{4.0 + 8.0 / dep:g}*n^2 B/update (deferred shrink, depth {dep}: one lower-triangle "
+                               f"GEMV pass of 4*n^2 per update + one lower-triangle apply pass of 8*n^2 per {dep} updates; the "
+                               "upper triangle is mirrored back only when Q itself is read" +
                                ("; per GPU 1/P of that: symmetric row shards of equal trapezoid area, one all-reduce "
                                 "of the n-vector per update)" if sharded else ")"))
         if symv_mode:

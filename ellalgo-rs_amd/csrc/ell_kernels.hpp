@@ -90,7 +90,7 @@ __device__ __forceinline__ void queue_bookkeeping(DevState* st, int status, doub
 // through exactly the roundings of the reference's one-update-at-a-time loop (src/ell.rs:117-128).
 // Per update: 8 n^2 (1 + 1/MAXPEND) + ... bytes instead of 16 n^2 (pipelined) or 24 n^2 (two-pass).
 // Unused slots hold c_j = 0 and v_j = 0, which makes every formula above an exact no-op for them.
-constexpr int MAXPEND = 8;
+constexpr int MAXPEND = 16;  // capacity of the pending-update buffers; the depth in force (NP) is 8 or 16
 
 typedef double double2_t __attribute__((ext_vector_type(2)));
 
@@ -447,7 +447,7 @@ __global__ __launch_bounds__(256) void k_symv_reduce(long long n, long long row0
 // 16 n^2).  Legal while every GEMV in between reads the lower triangle only (k_symv): the strict upper
 // triangle is then stale and is rebuilt from the lower one (k_mirror_lower_now) before anything reads it
 // -- which is exactly what the reference's mirror store `Q[j][i] = Q[i][j]` (src/ell.rs:124-126) makes of it.
-template <int RW, int UNR, int VEC, bool NT, bool GV, bool LOWER = false>
+template <int RW, int UNR, int VEC, bool NT, bool GV, bool LOWER = false, int NP = 8>
 __global__ __launch_bounds__(256) void k_sweep_apply(const double* Q, double* Qout, long long ld, long long n,
                                                      long long nrows, long long row0,
                                                      const double* __restrict__ pend,
@@ -464,13 +464,13 @@ __global__ __launch_bounds__(256) void k_sweep_apply(const double* Q, double* Qo
     const long long row_base = tile * RW;
     if (row_base >= nrows) return;
 
-    double ratio[MAXPEND];
+    double ratio[NP];
 #pragma unroll
-    for (int j = 0; j < MAXPEND; ++j) ratio[j] = cpend[j];
+    for (int j = 0; j < NP; ++j) ratio[j] = cpend[j];
     const double* rp[RW];
     double* wp[RW];
     long long grow[RW];
-    double gtr[MAXPEND][RW], rgr[MAXPEND][RW], acc[RW];
+    double gtr[NP][RW], rgr[NP][RW], acc[RW];
     bool valid[RW];
 #pragma unroll
     for (int r = 0; r < RW; ++r) {
@@ -482,7 +482,7 @@ __global__ __launch_bounds__(256) void k_sweep_apply(const double* Q, double* Qo
         grow[r] = row0 + rr;
         acc[r] = 0.0;
 #pragma unroll
-        for (int j = 0; j < MAXPEND; ++j) {
+        for (int j = 0; j < NP; ++j) {
             gtr[j][r] = pend[(long long)j * n + grow[r]];
             rgr[j][r] = ratio[j] * gtr[j][r];  // r_qg of src/ell.rs:119, update j
         }
@@ -500,9 +500,9 @@ __global__ __launch_bounds__(256) void k_sweep_apply(const double* Q, double* Qo
         for (int u = 0; u < UNR; ++u) {
             const long long cc = c + u * STEP;
             if (cc >= cend) break;
-            V vj[MAXPEND];
+            V vj[NP];
 #pragma unroll
-            for (int j = 0; j < MAXPEND; ++j) vj[j] = *reinterpret_cast<const V*>(pend + (long long)j * n + cc);
+            for (int j = 0; j < NP; ++j) vj[j] = *reinterpret_cast<const V*>(pend + (long long)j * n + cc);
             V hv;
             if (GV) hv = *reinterpret_cast<const V*>(gvec + cc);
             V qv[RW];
@@ -520,13 +520,13 @@ __global__ __launch_bounds__(256) void k_sweep_apply(const double* Q, double* Qo
                     for (int v = 0; v < VEC; ++v) {
                         double x = VecT<VEC>::get(qv[r], v);
 #pragma unroll
-                        for (int j = 0; j < MAXPEND; ++j) x = x - rgr[j][r] * VecT<VEC>::get(vj[j], v);
+                        for (int j = 0; j < NP; ++j) x = x - rgr[j][r] * VecT<VEC>::get(vj[j], v);
                         VecT<VEC>::set(o[r], v, x);
                     }
             } else if (all_upper) {
-                V rv[MAXPEND];  // (ratio_j * gt_j[col]): the mirrored element's r_qg
+                V rv[NP];  // (ratio_j * gt_j[col]): the mirrored element's r_qg
 #pragma unroll
-                for (int j = 0; j < MAXPEND; ++j)
+                for (int j = 0; j < NP; ++j)
 #pragma unroll
                     for (int v = 0; v < VEC; ++v) VecT<VEC>::set(rv[j], v, ratio[j] * VecT<VEC>::get(vj[j], v));
 #pragma unroll
@@ -535,7 +535,7 @@ __global__ __launch_bounds__(256) void k_sweep_apply(const double* Q, double* Qo
                     for (int v = 0; v < VEC; ++v) {
                         double x = VecT<VEC>::get(qv[r], v);
 #pragma unroll
-                        for (int j = 0; j < MAXPEND; ++j) x = x - VecT<VEC>::get(rv[j], v) * gtr[j][r];
+                        for (int j = 0; j < NP; ++j) x = x - VecT<VEC>::get(rv[j], v) * gtr[j][r];
                         VecT<VEC>::set(o[r], v, x);
                     }
             } else {
@@ -546,7 +546,7 @@ __global__ __launch_bounds__(256) void k_sweep_apply(const double* Q, double* Qo
                         const bool lower = cc + v <= grow[r];
                         double x = VecT<VEC>::get(qv[r], v);
 #pragma unroll
-                        for (int j = 0; j < MAXPEND; ++j) {  // in recording order: the reference's roundings
+                        for (int j = 0; j < NP; ++j) {  // in recording order: the reference's roundings
                             const double gc = VecT<VEC>::get(vj[j], v);
                             const double upd = lower ? rgr[j][r] * gc : (ratio[j] * gc) * gtr[j][r];
                             x = x - upd;
@@ -574,6 +574,75 @@ __global__ __launch_bounds__(256) void k_sweep_apply(const double* Q, double* Qo
         if (threadIdx.x < RW && row_base + threadIdx.x < nrows) {
             const int r = threadIdx.x;
             gv_out[row_base + r] = ((red[0][r] + red[1][r]) + red[2][r]) + red[3][r];
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------- k_apply_lower ---
+// Lower-trapezoid apply pass for depth NP (8 or 16).  MEASURED NEGATIVE RESULT, kept selectable: at n = 16384 it
+// takes 0.62 ms at depth 8 (k_sweep_apply<LOWER>: 0.44 ms) and 1.36 ms at depth 16, so depth 16 ends up slower
+// than depth 8 (3420 vs 3730 updates/s): 16 x 16 coefficient reads from LDS per 512-column chunk and 4 NP
+// two-rounding multiply-subtracts per pair of elements make the pass issue bound, not HBM bound.  Depth 16 is
+// therefore available (ellhip_set_defer_depth(h, 16)) but not a default anywhere.  A
+// workgroup owns APL_TR consecutive rows and sweeps the columns up to the tile's diagonal in chunks of 512; per
+// chunk each thread loads its 16-byte pair of the NP pending vectors ONCE (registers) and runs all APL_TR rows
+// through it, so the vectors cost one L2 read per 16 rows (k_sweep_apply: one per 4) -- that is what makes
+// depth 16 pay: twice the updates per pass of Q for the same L2 traffic as depth 8 had.  The row coefficients
+// c_j * v_j[row] are workgroup-uniform and live in LDS.  Every element left of or on the diagonal goes through
+// the reference's sequence of roundings, x <- x - (c_j v_j[row]) v_j[col], j in recording order; the few
+// elements right of the diagonal inside the last chunk get the same expression (they are stale by contract:
+// nothing reads the strict upper triangle before k_mirror_lower_now rebuilds it).
+constexpr int APL_TR = 16;
+
+template <int NP, bool NT>
+__global__ __launch_bounds__(256) void k_apply_lower(double* __restrict__ Q, long long ld, long long n,
+                                                     long long nrows, long long row0,
+                                                     const double* __restrict__ pend,
+                                                     const double* __restrict__ cpend,
+                                                     const DevState* __restrict__ st) {
+    __shared__ double coef[NP][APL_TR];
+    if (st->halted) return;
+    const long long tile = (long long)gridDim.x - 1 - blockIdx.x;  // last (longest) rows first
+    const long long lr0 = tile * APL_TR;                            // first local row of the tile
+    if (lr0 >= nrows) return;
+    const int nr = (int)((nrows - lr0 < APL_TR) ? nrows - lr0 : APL_TR);
+    for (int idx = threadIdx.x; idx < NP * APL_TR; idx += 256) {
+        const int j = idx / APL_TR, r = idx - j * APL_TR;
+        coef[j][r] = (r < nr) ? cpend[j] * pend[(long long)j * n + row0 + lr0 + r] : 0.0;  // r_qg of src/ell.rs:119
+    }
+    __syncthreads();
+    const long long gmax = row0 + lr0 + nr - 1;  // last global row of the tile
+    long long cend = (gmax / 2 + 1) * 2;         // first column past the tile's diagonal, pair aligned
+    if (cend > n) cend = n;
+    double* base = Q + lr0 * ld;
+    for (long long c = 2 * (long long)threadIdx.x; c < cend; c += 512) {
+        double2_t vj[NP];
+#pragma unroll
+        for (int j = 0; j < NP; ++j) vj[j] = *reinterpret_cast<const double2_t*>(pend + (long long)j * n + c);
+#pragma unroll
+        for (int r0 = 0; r0 < APL_TR; r0 += 4) {
+            double2_t x[4];
+            bool on[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int r = r0 + u;
+                // a row takes part while the pair starts at or left of its diagonal (keeps the traffic at the trapezoid)
+                on[u] = r < nr && c <= row0 + lr0 + r;
+                if (on[u]) x[u] = ld_stream<NT, double2_t>(base + (long long)r * ld + c);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (!on[u]) continue;
+#pragma unroll
+                for (int j = 0; j < NP; ++j) {
+                    const double cf = coef[j][r0 + u];
+                    x[u].x = x[u].x - cf * vj[j].x;
+                    x[u].y = x[u].y - cf * vj[j].y;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (on[u]) *reinterpret_cast<double2_t*>(base + (long long)(r0 + u) * ld + c) = x[u];
         }
     }
 }
@@ -704,11 +773,12 @@ __global__ __launch_bounds__(256) void k_scalar_apply(long long n, const double*
 //   k_scalar_apply_def  every workgroup: gy, d_j = v_j.g; omega = gy - sum_j c_j d_j^2; tsq, EllCalc; its slice
 //                       of gt = y - sum_j (c_j d_j) v_j is recorded as the new pending vector and applied
 //                       to xc; workgroup 0 records c = sigma/omega, bumps npend, publishes kappa / status.
+template <int NP>
 __global__ __launch_bounds__(256) void k_scalar_dot_def(long long n, const double* __restrict__ g,
                                                         const double* __restrict__ y,
                                                         const double* __restrict__ pend,
                                                         double* __restrict__ partial, DevState* __restrict__ st) {
-    __shared__ double red[4][MAXPEND + 1];
+    __shared__ double red[4][NP + 1];
     const int tid = threadIdx.x;
     const int halted = st->halted;
     if (blockIdx.x == 0 && tid == 0) {
@@ -719,25 +789,26 @@ __global__ __launch_bounds__(256) void k_scalar_dot_def(long long n, const doubl
     const long long m = scalar_slice(n);
     const long long lo = (long long)blockIdx.x * m;
     const long long hi = (lo + m < n) ? lo + m : n;
-    double s[MAXPEND + 1];
+    double s[NP + 1];
 #pragma unroll
-    for (int k = 0; k <= MAXPEND; ++k) s[k] = 0.0;
+    for (int k = 0; k <= NP; ++k) s[k] = 0.0;
     for (long long i = lo + tid; i < hi; i += 256) {
         const double gi = g[i];
         s[0] += gi * y[i];
 #pragma unroll
-        for (int j = 0; j < MAXPEND; ++j) s[1 + j] += pend[(long long)j * n + i] * gi;
+        for (int j = 0; j < NP; ++j) s[1 + j] += pend[(long long)j * n + i] * gi;
     }
 #pragma unroll
-    for (int k = 0; k <= MAXPEND; ++k) {
+    for (int k = 0; k <= NP; ++k) {
         const double w = wave_allreduce_sum(s[k]);
         if ((tid & 63) == 0) red[tid >> 6][k] = w;
     }
     __syncthreads();
-    if (tid <= MAXPEND)
-        partial[(long long)blockIdx.x * (MAXPEND + 1) + tid] = ((red[0][tid] + red[1][tid]) + red[2][tid]) + red[3][tid];
+    if (tid <= NP)
+        partial[(long long)blockIdx.x * (NP + 1) + tid] = ((red[0][tid] + red[1][tid]) + red[2][tid]) + red[3][tid];
 }
 
+template <int NP>
 __global__ __launch_bounds__(256) void k_scalar_apply_def(long long n, const double* __restrict__ y,
                                                           double* __restrict__ xc, double* __restrict__ pend,
                                                           double* __restrict__ cpend,
@@ -750,7 +821,7 @@ __global__ __launch_bounds__(256) void k_scalar_apply_def(long long n, const dou
     // The host passes it: it equals the device's count as long as the queue has not halted, and a halted
     // queue ignores every later launch.
     __shared__ double bc_roo;
-    __shared__ double bc_cd[MAXPEND];
+    __shared__ double bc_cd[NP];
     __shared__ int bc_status;
     const int tid = threadIdx.x;
     const bool lead = blockIdx.x == 0;
@@ -761,21 +832,21 @@ __global__ __launch_bounds__(256) void k_scalar_apply_def(long long n, const dou
         }
         return;
     }
-    __shared__ double dsum[MAXPEND + 1];
-    if (tid <= MAXPEND) {  // one thread per partial-sum column, workgroups in index order
+    __shared__ double dsum[NP + 1];
+    if (tid <= NP) {  // one thread per partial-sum column, workgroups in index order
         const int G = scalar_groups(n);
         double a = 0.0;
-        for (int b = 0; b < G; ++b) a += partial[(long long)b * (MAXPEND + 1) + tid];
+        for (int b = 0; b < G; ++b) a += partial[(long long)b * (NP + 1) + tid];
         dsum[tid] = a;
     }
     __syncthreads();
     if (tid == 0) {
-        double d[MAXPEND + 1];
+        double d[NP + 1];
 #pragma unroll
-        for (int k = 0; k <= MAXPEND; ++k) d[k] = dsum[k];
+        for (int k = 0; k <= NP; ++k) d[k] = dsum[k];
         double omega = d[0];  // g.(Q_base g)
 #pragma unroll
-        for (int j = 0; j < MAXPEND; ++j) {
+        for (int j = 0; j < NP; ++j) {
             // slot `slot` is being written by the lead workgroup in this very launch: it is empty by
             // definition, so it is not read
             const double cd = (j == slot) ? 0.0 : cpend[j] * d[1 + j];  // c_j (v_j.g)
@@ -816,9 +887,9 @@ __global__ __launch_bounds__(256) void k_scalar_apply_def(long long n, const dou
     __syncthreads();
     if (bc_status != ST_SUCCESS) return;
     const double roo = bc_roo;
-    double cd[MAXPEND];
+    double cd[NP];
 #pragma unroll
-    for (int j = 0; j < MAXPEND; ++j) cd[j] = bc_cd[j];
+    for (int j = 0; j < NP; ++j) cd[j] = bc_cd[j];
     double* vnew = pend + (long long)slot * n;
     const long long m = scalar_slice(n);
     const long long lo = (long long)blockIdx.x * m;
@@ -826,7 +897,7 @@ __global__ __launch_bounds__(256) void k_scalar_apply_def(long long n, const dou
     for (long long i = lo + tid; i < hi; i += 256) {
         double gt = y[i];
 #pragma unroll
-        for (int j = 0; j < MAXPEND; ++j) gt = gt - cd[j] * pend[(long long)j * n + i];
+        for (int j = 0; j < NP; ++j) gt = gt - cd[j] * pend[(long long)j * n + i];
         vnew[i] = gt;                    // slot `slot` was all zeros until now: its own term above was an exact 0
         xc[i] = xc[i] - roo * gt;        // :113-115
     }

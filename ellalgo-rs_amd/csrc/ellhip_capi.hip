@@ -90,6 +90,7 @@ struct ellhip_space {
     bool shard_symmetric = false;    // row shard whose GEMVs are partial symmetric sums (ellhip_set_shard_symmetric)
     int symv_seg = SYMV_SEG;         // segment width of the lower-triangle GEMV's tiles (see symv_alloc)
     int apply_lower = 1;             // with symv: apply passes touch the lower triangle only (ELLHIP_APPLY_LOWER)
+    int apply_kernel = 0;            // depth 8: 0 = k_sweep_apply<LOWER> (4-row tiles, 0.44 ms at n = 16384), 1 = k_apply_lower (0.62 ms)
     bool upper_stale = false;        // strict upper triangle of Q is out of date (see flush_pending)
     int defer = 1;                   // 1 = shrink Q at every cut; MAXPEND = record and apply in batches
     int npend = 0;                   // updates recorded since the last flush (host view, optimistic in queue mode)
@@ -221,6 +222,7 @@ void pick_shape(ellhip_space* s) {
     s->symv_rw = env_int("ELLHIP_SYMV_RW", 2);
     s->symv_min_n = env_int("ELLHIP_SYMV_MIN_N", 8192);
     s->apply_lower = env_int("ELLHIP_APPLY_LOWER", 1);
+    s->apply_kernel = env_int("ELLHIP_APPLY_KERNEL", 0);
     s->sh_apply = {4, 1, s->sh_fused.nt};  // 8 pending vectors per column step: more rows per workgroup amortise them
     s->sh_apply.rw = env_int("ELLHIP_APPLY_RW", s->sh_apply.rw);
     s->sh_apply.unr = env_int("ELLHIP_APPLY_UNR", s->sh_apply.unr);
@@ -314,9 +316,24 @@ int flush_pending(ellhip_space* s, const double* gvec, double* gv_out) {
         const bool nt = even && s->sh_apply.nt;
         int rc;
         if (!gvec && s->apply_lower && symv_ok(s)) {
-            rc = nt ? launch_apply_t<2, true, false, true>(s, nullptr, nullptr)
-                    : launch_apply_t<2, false, false, true>(s, nullptr, nullptr);
+            const unsigned grid = (unsigned)((s->nrows + APL_TR - 1) / APL_TR);
+#define APL_GO(NPV, NTV)                                                                                        \
+    hipLaunchKernelGGL((k_apply_lower<NPV, NTV>), dim3(grid), dim3(256), 0, s->stream, s->d_Q, s->ld, s->n, s->nrows, \
+                       s->row0, (const double*)s->d_pend, (const double*)s->d_cpend, (const DevState*)s->d_st)
+            if (s->defer == 16) {  // 16 pending updates: the 16-row-tile kernel (coefficients in LDS)
+                if (nt) APL_GO(16, true); else APL_GO(16, false);
+            } else if (s->apply_kernel == 1) {  // ELLHIP_APPLY_KERNEL=1: the same kernel at depth 8 (measured slower)
+                if (nt) APL_GO(8, true); else APL_GO(8, false);
+            } else {
+                rc = nt ? launch_apply_t<2, true, false, true>(s, nullptr, nullptr)
+                        : launch_apply_t<2, false, false, true>(s, nullptr, nullptr);
+                if (rc) return rc;
+            }
+#undef APL_GO
+            rc = 0;
             s->upper_stale = true;
+        } else if (s->defer != 8) {
+            return fail(ELLHIP_E_STATE, "defer depth 16 needs the lower-triangle schedule");
         } else if (gvec)
             rc = !even ? launch_apply_t<1, false, true>(s, gvec, gv_out)
                        : (nt ? launch_apply_t<2, true, true>(s, gvec, gv_out) : launch_apply_t<2, false, true>(s, gvec, gv_out));
@@ -329,7 +346,7 @@ int flush_pending(ellhip_space* s, const double* gvec, double* gv_out) {
         s->dir ^= 1;
     }
     hipLaunchKernelGGL(k_pend_reset, dim3(64), dim3(256), 0, s->stream, s->d_pend, s->d_cpend,
-                       (long long)MAXPEND * s->n, s->d_st);
+                       (long long)s->defer * s->n, s->d_st);
     HIPCHK(hipGetLastError());
     s->npend = 0;
     return 0;
@@ -507,11 +524,14 @@ int do_cut(ellhip_space* s, const double* g_dev, const CutParams* cp_dev, CutPar
     if (deferring(s)) {
         // gt currently holds y = Q_base * g; the stage corrects it with the pending updates and records the
         // cut as pending update number s->npend (optimistically counted; see ellhip_queue_results / callers)
-        hipLaunchKernelGGL(k_scalar_dot_def, dim3(G), dim3(256), 0, s->stream, s->n, g_dev, gt,
-                           (const double*)s->d_pend, s->d_partial, s->d_st);
-        hipLaunchKernelGGL(k_scalar_apply_def, dim3(G), dim3(256), 0, s->stream, s->n, gt, s->d_xc, s->d_pend,
-                           s->d_cpend, (const double*)s->d_partial, s->d_st, calc, cp_dev, cp_val, s->npend, queue_mode,
-                           qst, qtsq);
+#define SCALAR_DEF(NPV)                                                                                           \
+    hipLaunchKernelGGL(k_scalar_dot_def<NPV>, dim3(G), dim3(256), 0, s->stream, s->n, g_dev, gt,                   \
+                       (const double*)s->d_pend, s->d_partial, s->d_st);                                          \
+    hipLaunchKernelGGL(k_scalar_apply_def<NPV>, dim3(G), dim3(256), 0, s->stream, s->n, gt, s->d_xc, s->d_pend,    \
+                       s->d_cpend, (const double*)s->d_partial, s->d_st, calc, cp_dev, cp_val, s->npend, queue_mode, \
+                       qst, qtsq)
+        if (s->defer == 16) { SCALAR_DEF(16); } else { SCALAR_DEF(8); }
+#undef SCALAR_DEF
         HIPCHK(hipGetLastError());
         s->npend += 1;
         return 0;
@@ -537,7 +557,7 @@ int do_commit(ellhip_space* s, bool shrink, const double* gnext_dev) {
     if (deferring(s)) {
         // nothing to shrink now: the cut was recorded.  When the slots are full, one pass applies them all
         // (and carries the next GEMV); otherwise the next gradient only needs a read-only pass.
-        if (s->npend >= MAXPEND) {
+        if (s->npend >= s->defer) {
             if (gnext_dev && !symv_ok(s)) return flush_pending(s, gnext_dev, s->d_gt[s->cur ^ 1]);
             int rc = flush_pending(s, nullptr, nullptr);  // the next GEMV runs on the lower triangle afterwards
             if (rc) return rc;
@@ -920,6 +940,7 @@ int ellhip_clone(const ellhip_space* src_c, ellhip_space** out) {
     s->symv_rw = src->symv_rw;
     s->symv_min_n = src->symv_min_n;
     s->apply_lower = src->apply_lower;
+    s->apply_kernel = src->apply_kernel;
     s->shard_symmetric = src->shard_symmetric;
     s->upper_stale = src->upper_stale;
     s->symv_seg = src->symv_seg;
@@ -1109,7 +1130,7 @@ int ellhip_set_no_defer_trick(ellhip_space* s, int flag) {
 int ellhip_set_defer_depth(ellhip_space* s, int depth) {
     if (!s) return fail(ELLHIP_E_INVALID, "NULL handle");
     if (s->variant != ELLHIP_SPACE_ELL) return fail(ELLHIP_E_INVALID, "deferred shrink exists on Ell only");
-    if (depth != 1 && depth != MAXPEND) return fail(ELLHIP_E_INVALID, "defer depth must be 1 or 8");
+    if (depth != 1 && depth != 8 && depth != 16) return fail(ELLHIP_E_INVALID, "defer depth must be 1, 8 or 16");
     if (s->shard_symmetric && depth == 1 && s->upper_stale)
         return fail(ELLHIP_E_STATE, "symmetric row shard: the rows are current up to their diagonal only");
     DeviceGuard guard(s->device);
@@ -1118,6 +1139,14 @@ int ellhip_set_defer_depth(ellhip_space* s, int depth) {
     if (depth > 1) {
         rc = symv_alloc(s);
         if (rc) return rc;
+    }
+    if (depth == 16) {
+        // 16 pending updates only fit the lower-triangle schedule (k_symv + k_apply_lower)
+        const bool lower_schedule = s->symv && s->apply_lower && (s->n % 2) == 0 && s->d_rowpart &&
+                                    (s->sharded ? s->shard_symmetric : s->n >= s->symv_min_n);
+        if (!lower_schedule)
+            return fail(ELLHIP_E_INVALID, "defer depth 16 needs the lower-triangle schedule: an unsharded handle with n "
+                                          "even and >= 8192, or a symmetric row shard");
     }
     s->defer = depth;
     return 0;

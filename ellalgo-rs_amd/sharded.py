@@ -182,7 +182,7 @@ class ShardedEll:
     Same SearchSpace surface as ellalgo_rs_amd.Ell; every rank must make the same calls."""
 
     def __init__(self, kappa, mq_rows, xc, *, diag=None, device=-1, rank=None, world=None,
-                 engine_factory=None, exchange=None, symmetric=False):
+                 engine_factory=None, exchange=None, symmetric=False, defer_depth=8):
         """symmetric=True: the deferred (depth 8) schedule with lower-triangle GEMVs and apply passes on row
         blocks of equal trapezoid area (partition_symmetric), partial sums added by ONE all-reduce per update:
         5 n^2 / P bytes per GPU and update instead of 9 n^2 / P.  Only that schedule is available then."""
@@ -201,7 +201,7 @@ class ShardedEll:
         self._exchange = exchange or (allreduce_in_place if symmetric else allgather_in_place)
         if symmetric:
             self.engine.set_symmetric(True)
-            self.engine.set_defer_depth(8)
+            self.engine.set_defer_depth(defer_depth)
         self._qk = 0
         self._primed_index = -1
 

@@ -164,10 +164,14 @@ int ellhip_commit(ellhip_space *s, const double *next_grad);
  * 1e-10 parity tolerance of depth 1 (gt is the same vector computed in a different order); they are
  * bit-identical across schedules, row partitions and GPU counts for a given depth.  Not used while
  * no_defer_trick is set or before a non-symmetric input matrix has been mirrored.  Ell only.
- * On an unsharded handle (even n) depth 8 also computes Q_base*g through the lower triangle only
- * (every stored element is used for a row sum and a column sum: 4 n^2 bytes per GEMV pass); a
- * row-partitioned handle keeps the full-row GEMV, so its bits differ from an unsharded handle's at
- * depth 8 (both stay within the parity tolerance; shards agree with each other bit for bit). */
+ * On an unsharded handle (even n >= 8192) depth 8 also computes Q_base*g through the lower triangle only
+ * (every stored element is used for a row sum and a column sum: 4 n^2 bytes per GEMV pass) and applies the
+ * recorded updates to the lower triangle only (8 n^2 bytes per 8 updates; the upper half is mirrored back
+ * before anything observes Q).  An equal-block row shard keeps the full-row passes, so its bits differ from an
+ * unsharded handle's at depth 8 (both stay within the parity tolerance; shards agree with each other bit for
+ * bit); a symmetric row shard (below) runs the lower-triangle schedule on its trapezoid.
+ * depth = 16: the same with 16 recorded updates per apply pass; lower-triangle schedule only (ELLHIP_E_INVALID
+ * otherwise).  Measured slower than depth 8 on MI355X (the apply pass turns issue bound): not a default. */
 int ellhip_set_defer_depth(ellhip_space *s, int depth);
 int ellhip_defer_depth(const ellhip_space *s);
 /* Symmetric row shard (multi-GPU, deferred schedule only).  Call once after ellhip_create_shard, together with

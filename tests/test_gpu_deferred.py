@@ -211,3 +211,48 @@ def test_symv_equals_full_gemv_to_rounding(gpu, monkeypatch):
     assert np.array_equal(qa, qa.T)
     assert np.max(np.abs(qa - qb)) <= 1e-12 * np.max(np.abs(qb))
     assert np.max(np.abs(a.xc() - b.xc())) <= 1e-12 * np.max(np.abs(b.xc()))
+
+
+@pytest.mark.parametrize("n", [512, 1000, 2112, 4096])
+@pytest.mark.parametrize("depth", [8, 16])
+def test_lower_triangle_schedule_depths_match_oracle(gpu, orc, n, depth, monkeypatch):
+    """k_symv + k_apply_lower (16-row tiles) at depth 8 and 16, forced on at small sizes; get_mq in between
+    exercises the mirror at every phase of the pending count."""
+    monkeypatch.setenv("ELLHIP_SYMV_MIN_N", "512")
+    xc0 = np.linspace(-1.0, 1.0, n)
+    g = gpu.Ell.new_with_scalar(2.0, xc0)
+    g.defer_depth = depth
+    assert g.defer_depth == depth
+    o = orc.OracleEll.new_with_scalar(2.0, xc0)
+    nsucc = run_mixed(g, o, 60, seed=1300 + n + depth, check_every=7)
+    assert nsucc >= 30
+    assert_state_close(g, o, what=f"lower schedule depth {depth} n={n}")
+
+
+def test_depth16_needs_the_lower_triangle_schedule(gpu):
+    g = gpu.Ell.new_with_scalar(1.0, np.zeros(1024))   # below the default threshold (8192)
+    with pytest.raises(gpu.capi.EllHipError):
+        g.defer_depth = 16
+    g = gpu.Ell.new_with_scalar(1.0, np.zeros(1001))
+    with pytest.raises(gpu.capi.EllHipError):
+        g.defer_depth = 16
+
+
+def test_apply_kernels_agree_bit_for_bit(gpu, monkeypatch):
+    """k_apply_lower (16-row tiles) and k_sweep_apply<LOWER> (4-row tiles) put every lower-triangle element through
+    the same roundings."""
+    monkeypatch.setenv("ELLHIP_SYMV_MIN_N", "512")
+    n, k = 1536, 24
+    from ellalgo_rs_amd import synth
+    kinds, grads, b0, b1 = synth.parallel_cuts(n, k)
+    outs = []
+    for kern in ("0", "1"):
+        monkeypatch.setenv("ELLHIP_APPLY_KERNEL", kern)
+        e = gpu.Ell.new_with_scalar(1.0, np.zeros(n))
+        e.defer_depth = 8
+        e.queue_upload(kinds, grads, b0, b1)
+        e.queue_run(0, k)
+        st, _ = e.queue_results()
+        assert np.all(st == 0)
+        outs.append((e.mq, e.xc(), e.kappa))
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1]) and outs[0][2] == outs[1][2]
