@@ -281,6 +281,46 @@ int orc_ell_update_rowwise(orc_ell *e, int kind, const double *grad, double b0, 
     return ell_update_impl(e, kind, grad, b0, has_b1, b1, 1);
 }
 
+/* NOT the reference's loop: the same arithmetic with the rows of the GEMV and of the row-wise rank-1 spread over
+ * OpenMP threads (each row's sum is still a left fold; omega is folded serially), for the "all cores" line of
+ * bench.py's cpu_baseline.  Bit-identical to orc_ell_update_rowwise.  Symmetric Q only. */
+int orc_ell_update_rowwise_mt(orc_ell *e, int kind, const double *grad, double b0, int has_b1, double b1) {
+    const int64_t n = e->n;
+    double *gt = e->gt;
+    double *mq = e->mq;
+    double coef[3];
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < n; ++i) {
+        const double *row = mq + i * n;
+        double acc = 0.0;
+        for (int64_t j = 0; j < n; ++j) acc += row[j] * grad[j];
+        gt[i] = acc;
+    }
+    double omega = dot_fold(n, grad, gt);
+    e->tsq = e->kappa * omega;
+    int status = orc_calc_dispatch(&e->helper, kind, b0, has_b1, b1, e->tsq, coef);
+    if (status != ORC_SUCCESS) return status;
+    const double rho_over_omega = coef[0] / omega;
+    for (int64_t i = 0; i < n; ++i) e->xc[i] -= rho_over_omega * gt[i];
+    const double ratio = coef[1] / omega;
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < n; ++i) {
+        double *row = mq + i * n;
+        const double gti = gt[i];
+        const double r_i = ratio * gti;
+        for (int64_t j = 0; j <= i; ++j) row[j] -= r_i * gt[j];
+        for (int64_t j = i + 1; j < n; ++j) row[j] -= (ratio * gt[j]) * gti;
+    }
+    e->kappa *= coef[2];
+    if (e->no_defer_trick) {
+        const double k = e->kappa;
+#pragma omp parallel for schedule(static)
+        for (int64_t t = 0; t < n * n; ++t) mq[t] *= k;
+        e->kappa = 1.0;
+    }
+    return status;
+}
+
 double orc_ell_kappa(const orc_ell *e) { return e->kappa; }
 double orc_ell_tsq(const orc_ell *e) { return e->tsq; }
 double *orc_ell_mq(orc_ell *e) { return e->mq; }

@@ -77,6 +77,9 @@ int orc_ell_update(orc_ell *e, int kind, const double *grad, double b0, int has_
  * matrix with the (ratio*gt[max])*gt[min] form (bit-identical for symmetric Q, no strided
  * mirror stores). Used to cross-check the identity the HIP kernel relies on. */
 int orc_ell_update_rowwise(orc_ell *e, int kind, const double *grad, double b0, int has_b1, double b1);
+/* NOT the reference's loop: orc_ell_update_rowwise with its rows spread over OpenMP threads (bit-identical to
+ * it); for the "all cores" line of bench.py's cpu_baseline only. */
+int orc_ell_update_rowwise_mt(orc_ell *e, int kind, const double *grad, double b0, int has_b1, double b1);
 double orc_ell_kappa(const orc_ell *e);
 double orc_ell_tsq(const orc_ell *e);
 double *orc_ell_mq(orc_ell *e);

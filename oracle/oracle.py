@@ -100,6 +100,8 @@ def lib():
             getattr(L, pre + "_xc").restype = _dp
         L.orc_ell_update_rowwise.argtypes = L.orc_ell_update.argtypes
         L.orc_ell_update_rowwise.restype = C.c_int
+        L.orc_ell_update_rowwise_mt.argtypes = L.orc_ell_update.argtypes
+        L.orc_ell_update_rowwise_mt.restype = C.c_int
         L.orc_ell_set_no_defer_trick.argtypes = [C.c_void_p, C.c_int]
         L.orc_ell_set_use_parallel_cut.argtypes = [C.c_void_p, C.c_int]
         L.orc_ellstable_set_corrected.argtypes = [C.c_void_p, C.c_int]
@@ -273,6 +275,12 @@ class OracleEll(_Space):
         g = _arr(grad, self.n)
         return lib().orc_ell_update_rowwise(self.h, kind, _ptr(g), float(b0), int(b1 is not None),
                                             0.0 if b1 is None else float(b1))
+
+    def update_rowwise_mt(self, kind, grad, b0, b1=None):
+        """NOT the reference's loop: the row-wise form on all OpenMP threads (bit-identical to update_rowwise)."""
+        g = _arr(grad, self.n)
+        return lib().orc_ell_update_rowwise_mt(self.h, kind, _ptr(g), float(b0), int(b1 is not None),
+                                               0.0 if b1 is None else float(b1))
 
     def set_no_defer_trick(self, flag): lib().orc_ell_set_no_defer_trick(self.h, int(flag))
     def set_use_parallel_cut(self, flag): lib().orc_ell_set_use_parallel_cut(self.h, int(flag))

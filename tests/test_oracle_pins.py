@@ -183,3 +183,17 @@ def test_row_block_gemv_equals_full(orc):
     orc.rows_gemv(n, 0, 16, q[:16], g, parts)
     orc.rows_gemv(n, 16, 32, q[16:], g, parts)
     assert np.array_equal(full, parts)
+
+
+def test_rowwise_openmp_variant_is_bit_identical_to_the_serial_row_wise_form():
+    """bench.py's "all cores" CPU line (not the reference's loop) must still be the reference's arithmetic."""
+    import numpy as np
+    from oracle import oracle as O
+    n = 257
+    rng = np.random.default_rng(3)
+    a, b = O.OracleEll.new_with_scalar(2.0, np.linspace(-1, 1, n)), O.OracleEll.new_with_scalar(2.0, np.linspace(-1, 1, n))
+    for i in range(12):
+        g = rng.standard_normal(n)
+        beta = 0.02 * (i % 3)
+        assert a.update_rowwise(0, g, beta) == b.update_rowwise_mt(0, g, beta)
+    assert np.array_equal(a.mq, b.mq) and np.array_equal(a.xc, b.xc) and a.kappa == b.kappa and a.tsq == b.tsq
