@@ -361,11 +361,38 @@ __global__ __launch_bounds__(256) void k_st_fwd_persist(double* __restrict__ M, 
     if (threadIdx.x < SPANEL) wstrip[threadIdx.x] = (c0 + threadIdx.x < n) ? g[c0 + threadIdx.x] : 0.0;
 
     double* t = lds + wv * (SPANEL * SLDS_PAD);
+    // The products S[col][row] = U[row][col] * w[row] of a row block are needed by nobody before the backward
+    // solve, so for the LAST row block (the one this workgroup's own solve is waiting for) they stay in registers
+    // and are written back only after the own block has been solved and published: the two LDS transposes, the
+    // global stores and their four barriers leave the critical path of the dependency chain.
+    double2_t u[2][16];
+    auto write_back = [&](long long J0) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const long long r0 = J0 + 32 * wv + 16 * h;
+            if (h) __syncthreads();  // the tile of the previous pass has been drained
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                t[(2 * lane) * SLDS_PAD + r] = u[h][r].x;
+                t[(2 * lane + 1) * SLDS_PAD + r] = u[h][r].y;
+            }
+            __syncthreads();
+            // S[col][r0 .. r0+16) for the 128 columns: 8 lanes x 16 B = one full 128-byte line per column
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const int col_local = 8 * k + (lane >> 3);
+                const long long col = c0 + col_local;
+                if (col < n) {
+                    const double2_t v = *reinterpret_cast<const double2_t*>(&t[col_local * SLDS_PAD + 2 * piece]);
+                    *reinterpret_cast<double2_t*>(M + col * ld + r0 + 2 * piece) = v;
+                }
+            }
+        }
+    };
     for (long long kb = 0; kb < sblk; ++kb) {
         const long long J0 = kb * SB;  // all 128 rows exist: J0 + 128 <= c0 < n
         // nothing below depends on the flag except w: request both passes' rows of U (and, in the last
         // iteration, the own diagonal block) before waiting, so their HBM latency is hidden behind the wait
-        double2_t u[2][16];
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const long long r0 = J0 + 32 * wv + 16 * h;
@@ -384,8 +411,6 @@ __global__ __launch_bounds__(256) void k_st_fwd_persist(double* __restrict__ M, 
         double p0 = 0.0, p1 = 0.0;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            const long long r0 = J0 + 32 * wv + 16 * h;
-            if (h) __syncthreads();  // the tile of the previous pass has been drained
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const double wj = wblk[32 * wv + 16 * h + r];
@@ -393,18 +418,8 @@ __global__ __launch_bounds__(256) void k_st_fwd_persist(double* __restrict__ M, 
                 const double v1 = u[h][r].y * wj;
                 p0 += v0;
                 p1 += v1;
-                t[(2 * lane) * SLDS_PAD + r] = v0;
-                t[(2 * lane + 1) * SLDS_PAD + r] = v1;
-            }
-            __syncthreads();
-#pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                const int col_local = 8 * k + (lane >> 3);
-                const long long col = c0 + col_local;
-                if (col < n) {
-                    const double2_t v = *reinterpret_cast<const double2_t*>(&t[col_local * SLDS_PAD + 2 * piece]);
-                    *reinterpret_cast<double2_t*>(M + col * ld + r0 + 2 * piece) = v;
-                }
+                u[h][r].x = v0;  // the product replaces the factor entry (src/ell_stable.rs:66)
+                u[h][r].y = v1;
             }
         }
         part[wv][2 * lane] = p0;
@@ -415,10 +430,17 @@ __global__ __launch_bounds__(256) void k_st_fwd_persist(double* __restrict__ M, 
                               part[3][threadIdx.x];
             wstrip[threadIdx.x] = wstrip[threadIdx.x] - s4;
         }
-        __syncthreads();  // tiles drained, wstrip / part reusable
+        if (kb + 1 < sblk) {
+            write_back(J0);
+            __syncthreads();  // tiles drained, part reusable
+        }
     }
     __syncthreads();
     st_fwd_diag_block<true>(M, ld, n, c0, blk, dreg, lds, dlds, wstrip, w, z, gg, flags + sblk, epoch);
+    if (sblk > 0) {
+        __syncthreads();  // the parked pieces have been written back: `lds` is free for the transposes
+        write_back((sblk - 1) * SB);
+    }
 }
 
 // ---------------------------------------------------------------------------------- mid -------
