@@ -371,6 +371,7 @@ int ellstable_issue(ellhip_space* s, const double* g_dev, const CutParams* cp_de
     double* q = gg + n;
     double* beta2 = q + n;
     double* dscale = beta2 + n;
+    double* qpub = dscale + n;  // publish buffer of the persistent backward solve (data-as-flag hand-off)
     hipStream_t st = s->stream;
     // One launch per solve when every 128-column strip can have its own resident workgroup; otherwise
     // (n > 128 * 256) one launch per block.
@@ -396,7 +397,8 @@ int ellstable_issue(ellhip_space* s, const double* g_dev, const CutParams* cp_de
         ProfScope ps(s, CLS_SCALAR);
         EllCalcDev calc = EllCalcDev::make(n, s->use_parallel_cut);
         hipLaunchKernelGGL(k_st_mid, dim3(1), dim3(1024), 0, st, s->d_Q, ld, n, z, gg, q, beta2, dscale, s->d_st,
-                           calc, cp_dev, cp_val, queue_mode, qst, qtsq);
+                           calc, cp_dev, cp_val, queue_mode, qst, qtsq, persist ? w : (double*)nullptr,
+                           persist ? qpub : (double*)nullptr);
         hipLaunchKernelGGL(k_st_diag, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, s->d_Q, ld, n,
                            (const double*)dscale, s->d_st);
         HIPCHK(hipGetLastError());
@@ -410,8 +412,8 @@ int ellstable_issue(ellhip_space* s, const double* g_dev, const CutParams* cp_de
     {
         ProfScope ps(s, CLS_ST_BWD);
         if (persist) {
-            hipLaunchKernelGGL(k_st_bwd_persist, dim3((unsigned)nb), dim3(256), 0, st, s->d_Q, ld, n, q,
-                               s->d_flags + 256, err, ++s->epoch, s->d_st);
+            hipLaunchKernelGGL(k_st_bwd_persist, dim3((unsigned)nb), dim3(256), 0, st, s->d_Q, ld, n, q, qpub, err,
+                               s->d_st);
         } else {
             hipLaunchKernelGGL(k_st_bwd_last, dim3(1), dim3(256), 0, st, s->d_Q, ld, n, nb - 1, q, s->d_st);
             for (long long kb = nb - 1; kb >= 1; --kb) {
@@ -677,7 +679,9 @@ int alloc_common(ellhip_space* s) {
         HIPCHK(hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&s->ev_join, hipEventDisableTiming));
     }
-    if (s->variant == ELLHIP_SPACE_ELL_STABLE) HIPCHK(hipMalloc(&s->d_work, vbytes * 7));
+    if (s->variant == ELLHIP_SPACE_ELL_STABLE) {
+        HIPCHK(hipMalloc(&s->d_work, vbytes * 7));
+    }
     HIPCHK(hipHostMalloc(&s->h_result, sizeof(DevState), hipHostMallocDefault));
     return 0;
 }
