@@ -1158,6 +1158,16 @@ int ellhip_set_defer_depth(ellhip_space* s, int depth) {
 
 int ellhip_defer_depth(const ellhip_space* s) { return s ? s->defer : 0; }
 
+int ellhip_flush(ellhip_space* s) {
+    if (!s) return fail(ELLHIP_E_INVALID, "NULL handle");
+    if (s->variant != ELLHIP_SPACE_ELL) return 0;
+    DeviceGuard guard(s->device);
+    int rc = ensure_committed(s);
+    if (rc) return rc;
+    if (s->npend > 0) return flush_pending(s, nullptr, nullptr);
+    return 0;
+}
+
 int ellhip_set_shard_symmetric(ellhip_space* s, int flag) {
     if (!s) return fail(ELLHIP_E_INVALID, "NULL handle");
     if (!s->sharded || s->variant != ELLHIP_SPACE_ELL) return fail(ELLHIP_E_INVALID, "symmetric mode is for row shards of Ell");

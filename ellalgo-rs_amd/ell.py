@@ -201,6 +201,10 @@ class _SpaceBase:
     def set_stream(self, stream_ptr: int) -> None:
         capi.check(self._lib.ellhip_set_stream(self._h, C.c_void_p(stream_ptr)))
 
+    def flush(self) -> None:
+        """ellhip_flush: apply the recorded (deferred) updates now"""
+        capi.check(self._lib.ellhip_flush(self._h), "ellhip_flush")
+
     def profile_enable(self, flag: bool) -> None:
         capi.check(self._lib.ellhip_profile_enable(self._h, int(flag)))
 

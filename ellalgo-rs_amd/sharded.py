@@ -106,6 +106,9 @@ class HipShardEngine:
     def set_defer_depth(self, depth):
         capi.check(self._lib.ellhip_set_defer_depth(self.h, int(depth)), "ellhip_set_defer_depth")
 
+    def flush(self):
+        capi.check(self._lib.ellhip_flush(self.h), "ellhip_flush")
+
     def set_symmetric(self, flag=True):
         capi.check(self._lib.ellhip_set_shard_symmetric(self.h, int(flag)), "ellhip_set_shard_symmetric")
 
@@ -305,6 +308,11 @@ class ShardedEll:
         if np.any(st[st >= 0] != 0):   # the queue halted: nothing stays primed
             self._primed_index = -1
         return st, ts
+
+    def flush(self):
+        """apply the recorded (deferred) updates now (local rows; no collective involved)"""
+        with self._issue():
+            self.engine.flush()
 
     def synchronize(self):
         self.engine.synchronize()

@@ -174,6 +174,10 @@ int ellhip_commit(ellhip_space *s, const double *next_grad);
  * otherwise).  Measured slower than depth 8 on MI355X (the apply pass turns issue bound): not a default. */
 int ellhip_set_defer_depth(ellhip_space *s, int depth);
 int ellhip_defer_depth(const ellhip_space *s);
+/* Apply whatever the deferred schedule has recorded so far (and a shrink a pipelined cut left pending) now,
+ * asynchronously on the handle's stream.  Never needed for correctness (every observer of Q does it itself);
+ * bench.py calls it at both ends of its timed region so that the region pays for ALL of its updates. */
+int ellhip_flush(ellhip_space *s);
 /* Symmetric row shard (multi-GPU, deferred schedule only).  Call once after ellhip_create_shard, together with
  * ellhip_set_defer_depth(h, 8), on every rank; shard boundaries must be multiples of 64 and n even.  The GEMV
  * of each cut then reads only this shard's LOWER trapezoid (columns up to each row's diagonal) and leaves in the

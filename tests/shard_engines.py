@@ -137,3 +137,4 @@ class OracleShardEngine:
     def kappa(self): return self.kap
     def tsq(self): return self.tsqv
     def synchronize(self): pass
+    def flush(self): pass
