@@ -21,7 +21,8 @@ for path in sys.argv[1:]:
         print(f'{"":18s} {o["schedule"][:9]:9s} d{o["defer_depth"]}        upd/s={o["updates_per_s"]:9.1f} ms={o["ms_per_step"]:.4f} '
               f'whole={o["whole_update"]["frac"]:.3f} {pk}')
     if "host_call_path" in d:
-        print(f'{"":18s} host-call path {d["host_call_path"]["updates_per_s"]:.1f} upd/s', end="")
+        hp = d["host_call_path"]
+        print(f'{"":18s} host-call path ' + " ".join(f"{k}={v:.1f}" for k, v in hp.items() if k.startswith("updates_per_s")), end="")
     if "cpu_baseline" in d:
         print(f'   cpu {d["cpu_baseline"]["value"]:.3f} /s', end="")
         if "gpu_same_sample_iterations_per_s" in d["cpu_baseline"]:
