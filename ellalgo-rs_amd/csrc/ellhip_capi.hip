@@ -470,33 +470,38 @@ int symv_alloc(ellhip_space* s) {
     return 0;
 }
 
+template <int RW, int SEG>
+void symv_go(ellhip_space* s, const double* g_dev, unsigned nstrips, unsigned nsegs, bool nt) {
+    if (nt)
+        hipLaunchKernelGGL((k_symv<RW, true, 0, SEG>), dim3(nstrips, nsegs), dim3(256), 0, s->stream, (const double*)s->d_Q,
+                           s->ld, s->n, s->row0, s->nrows, g_dev, s->d_rowpart, s->d_colpart, s->d_st);
+    else
+        hipLaunchKernelGGL((k_symv<RW, false, 0, SEG>), dim3(nstrips, nsegs), dim3(256), 0, s->stream, (const double*)s->d_Q,
+                           s->ld, s->n, s->row0, s->nrows, g_dev, s->d_rowpart, s->d_colpart, s->d_st);
+}
+
 int launch_symv(ellhip_space* s, const double* g_dev, double* y_out) {
     const int seg = s->symv_seg;
-  {
-    ProfScope ps(s, CLS_SYMV);
-    const unsigned nstrips = (unsigned)((s->nrows + SYMV_H - 1) / SYMV_H);  // local strips
-    const unsigned nsegs = (unsigned)((s->n + seg - 1) / seg);
-    const bool nt = s->sh_gemv.nt != 0;
-    const int rw = (seg == SYMV_SEG) ? s->symv_rw : 8;  // narrow segments: 8 rows x 1 chunk in flight per thread
-    bool done = false;
-#define SYMV_GO(RW, NTV, SEGV)                                                                               \
-    hipLaunchKernelGGL((k_symv<RW, NTV, 0, SEGV>), dim3(nstrips, nsegs), dim3(256), 0, s->stream,            \
-                       (const double*)s->d_Q, s->ld, s->n, s->row0, s->nrows, g_dev, s->d_rowpart, s->d_colpart, \
-                       s->d_st);                                                                            \
-    done = true
-#define SYMV_CASE(RW)                                                   \
-    if (!done && seg == SYMV_SEG && rw == RW) {                         \
-        if (nt) { SYMV_GO(RW, true, SYMV_SEG); } else { SYMV_GO(RW, false, SYMV_SEG); } \
+    {
+        ProfScope ps(s, CLS_SYMV);
+        const unsigned nstrips = (unsigned)((s->nrows + SYMV_H - 1) / SYMV_H);  // local strips
+        const unsigned nsegs = (unsigned)((s->n + seg - 1) / seg);
+        const bool nt = s->sh_gemv.nt != 0;
+        if (seg == SYMV_SEG_SMALL) {
+            symv_go<8, SYMV_SEG_SMALL>(s, g_dev, nstrips, nsegs, nt);  // narrow segments: 8 rows x 1 chunk in flight
+        } else if (seg == SYMV_SEG) {
+            switch (s->symv_rw) {
+                case 1: symv_go<1, SYMV_SEG>(s, g_dev, nstrips, nsegs, nt); break;
+                case 2: symv_go<2, SYMV_SEG>(s, g_dev, nstrips, nsegs, nt); break;
+                case 4: symv_go<4, SYMV_SEG>(s, g_dev, nstrips, nsegs, nt); break;
+                case 8: symv_go<8, SYMV_SEG>(s, g_dev, nstrips, nsegs, nt); break;
+                default: return fail(ELLHIP_E_INVALID, "unsupported ELLHIP_SYMV_RW (1, 2, 4, 8)");
+            }
+        } else {
+            return fail(ELLHIP_E_INVALID, "unsupported ELLHIP_SYMV_SEG (512, 2048)");
+        }
+        HIPCHK(hipGetLastError());
     }
-    SYMV_CASE(1) SYMV_CASE(2) SYMV_CASE(4) SYMV_CASE(8)
-#undef SYMV_CASE
-    if (!done && seg == SYMV_SEG_SMALL) {
-        if (nt) { SYMV_GO(8, true, SYMV_SEG_SMALL); } else { SYMV_GO(8, false, SYMV_SEG_SMALL); }
-    }
-#undef SYMV_GO
-    if (!done) return fail(ELLHIP_E_INVALID, "unsupported ELLHIP_SYMV_RW (1, 2, 4, 8) / ELLHIP_SYMV_SEG (512, 2048)");
-    HIPCHK(hipGetLastError());
-  }
     ProfScope ps(s, CLS_SYMV_REDUCE);
     hipLaunchKernelGGL(k_symv_reduce, dim3((unsigned)((s->n + 127) / 128)), dim3(256), 0, s->stream, s->n, s->row0,
                        s->nrows, (long long)seg, (const double*)s->d_rowpart, (const double*)s->d_colpart, y_out,
