@@ -2,7 +2,7 @@
 # Tuning builds of k_symv tile shapes (run on the GPU box): rebuilds libellhip.so with -D overrides and times
 # the default bench.  Restores nothing: the box is scratch.
 set -u
-for cfg in "2048 64 2" "1024 64 2" "1024 64 4" "1024 128 4" "2048 128 2" "512 128 8" "1024 128 2"; do
+for cfg in ${SYMV_TILE_CFGS:-"2048 64 2" "4096 32 2" "4096 32 1" "8192 16 1" "2048 32 2" "2048 32 4"}; do
   set -- $cfg
   ELLHIP_EXTRA_HIPCC_FLAGS="-DELLHIP_SYMV_SEG=$1 -DELLHIP_SYMV_H=$2" python -c "
 import importlib, sys
