@@ -1,0 +1,63 @@
+"""GPU: bench.py honours its output contract -- exactly ONE JSON line on stdout with the driver's fields, the
+`roofline` object of the dominant kernel and the `cpu_baseline` object -- for the headline workload and for the
+secondary workloads."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+COMMON = {"metric": str, "value": float, "unit": str, "n_gpus": int, "steps": int, "warmup": int, "ms_per_step": float,
+          "higher_is_better": bool, "scaling": str, "dtype": str, "data": str, "config": dict, "roofline": dict}
+
+
+def run_bench(*args, timeout=600):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], capture_output=True, text=True,
+                       timeout=timeout, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, f"stdout must hold exactly one line, got {len(lines)}"
+    return json.loads(lines[0])
+
+
+def check_common(d, steps, warmup):
+    for k, t in COMMON.items():
+        assert k in d and isinstance(d[k], t), (k, d.get(k))
+    assert d["vs_baseline"] is None and d["dtype"] == "f64" and d["data"] == "synthetic" and d["higher_is_better"] is True
+    assert d["n_gpus"] == 1 and d["steps"] == steps and d["warmup"] == warmup
+    assert d["value"] > 0 and d["ms_per_step"] > 0 and "workload" in d["config"]
+    r = d["roofline"]
+    assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s") and r["peak"] == 8000.0
+    assert r["achieved"] > 0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and "traffic" in r
+
+
+def test_headline_workload_contract():
+    d = run_bench("--steps", "16", "--warmup", "8", "--compare-steps", "0", "--profile-steps", "8", "--host-path-steps", "4",
+                  "--cpu-budget", "2")
+    check_common(d, 16, 8)
+    assert d["metric"].startswith("ellipsoid updates/sec at n=16384") and d["unit"] == "updates/s"
+    assert d["config"]["workload"] == "n16384-parallel" and d["scaling"] == "strong"
+    assert abs(d["value"] - 1e3 / d["ms_per_step"]) < 1e-6 * d["value"]
+    r = d["roofline"]
+    assert r["kernel"] == "k_symv" and r["traffic"] and 0.3 < r["frac"] < 1.0
+    assert abs(r["alg_bytes_per_launch"] - 4.0 * 16384 ** 2) < 1.0     # lower triangle: 4 n^2 bytes
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] == 1 and c["unit"] == "updates/s" and c["value"] > 0 and c["sample"]
+    assert c["all_cores"]["threads"] >= 1 and "NOT the reference" in c["all_cores"]["note"]
+    assert d["host_call_path"]["updates_per_s"] > 0
+
+
+@pytest.mark.parametrize("workload,args", [("n4096-deep", ("--steps", "40", "--warmup", "8", "--compare-steps", "0")),
+                                           ("n4096-ellstable", ("--steps", "20", "--warmup", "4")),
+                                           ("lowpass-n1024", ("--steps", "200", "--warmup", "50", "--profile-steps", "50")),
+                                           ("batch-n16", ("--steps", "10", "--warmup", "2")),
+                                           ("lmi-m1024-n128", ("--steps", "3", "--warmup", "1"))])
+def test_other_workloads_contract(workload, args):
+    d = run_bench("--workload", workload, "--cpu-budget", "1", "--host-path-steps", "0", *args)
+    check_common(d, int(args[1]), int(args[3]))
+    assert d["config"]["workload"] == workload
+    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["value"] > 0
