@@ -244,6 +244,7 @@ def lowpass_bench(args, real_stdout) -> None:
     import ellalgo_rs_amd as pkg
     n = LOWPASS_WORKLOADS[args.workload]
     K, W, P = args.steps, args.warmup, args.profile_steps
+    dep = args.defer if args.defer in (1, 8) else 8  # (n <= 4096 here: the full-row schedule, depth 8)
     c = pkg.lowpass_case_constants(corrected=True)
     kappa0 = 40.0
 
@@ -251,7 +252,7 @@ def lowpass_bench(args, real_stdout) -> None:
         t0 = time.perf_counter()
         o = pkg.LowpassOracle(n, *c)
         sp = pkg.Ell.new_with_scalar(kappa0, np.zeros(n))
-        sp.defer_depth = args.defer
+        sp.defer_depth = dep
         log(f"[lowpass] table {15 * n} x {n} ({15 * n * n * 8 / 2**30:.2f} GiB) + Q built in {time.perf_counter() - t0:.1f}s")
         return o, sp
 
@@ -306,18 +307,18 @@ def lowpass_bench(args, real_stdout) -> None:
             roofline["traffic_source"] = pmc.get("source")
     except OSError:
         pass
-    upd_bytes = {1: 16.0, 8: 9.0}[args.defer] * n2
+    upd_bytes = {1: 16.0, 8: 9.0}[dep] * n2
     whole = rows_timed / K * n * 8.0 + upd_bytes
     roofline["whole_iteration"] = {"alg_bytes": whole, "GBps": whole / (ms_per_step * 1e-3) / 1e9,
                                    "frac": whole / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                    "model": f"oracle rows {rows_timed / K:.0f} x n x 8 + ellipsoid update "
-                                            f"{upd_bytes / n2:.0f}*n^2 (defer depth {args.defer}, shrink fused with the next GEMV)"}
+                                            f"{upd_bytes / n2:.0f}*n^2 (defer depth {dep}, shrink fused with the next GEMV)"}
     out = {
         "metric": "cutting-plane iterations/sec, LowpassOracle + Ell device-resident loop at n=%d" % n,
         "value": K / elapsed, "unit": "iterations/s", "n_gpus": 1, "steps": K, "warmup": W,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
-        "config": {"workload": args.workload, "n": n, "space": "ell", "defer_depth": args.defer,
+        "config": {"workload": args.workload, "n": n, "space": "ell", "defer_depth": dep,
                    "oracle": "LowpassOracle, corrected create_lowpass_case constants (parity unpinned by the reference, "
                              "see oracle/lowpass_oracle.h)", "table_bytes": 15.0 * n2 * 8.0, "kappa0": kappa0,
                    "gamma_after": gamma},
@@ -424,8 +425,10 @@ def main() -> None:
     ap.add_argument("--schedule", choices=["pipelined", "two-pass"], default="pipelined",
                     help="pipelined: one pass over Q per update (shrink of cut k fused with the GEMV of cut k+1, "
                          "16*n^2 B); two-pass: GEMV pass + rank-1 pass per update (24*n^2 B). Same results.")
-    ap.add_argument("--defer", type=int, choices=[1, 8, 16], default=8,
-                    help="8: record cuts and apply them to Q in batches of 8 (GEMV passes are read-only, "
+    ap.add_argument("--defer", type=int, choices=[0, 1, 8, 16], default=0,
+                    help="0 (default): 16 where the lower-triangle schedule exists (unsharded n even >= 8192, symmetric "
+                         "shards), else 8.  "
+                         "8: record cuts and apply them to Q in batches of 8 (GEMV passes are read-only, "
                          "8*n^2*(1+1/8) B per update); 1: rewrite Q at every cut like the reference. Same results "
                          "to the 1e-10 parity tolerance.")
     ap.add_argument("--compare-steps", type=int, default=48,
@@ -471,6 +474,14 @@ def main() -> None:
     H = args.host_path_steps if not sharded else 0
     fused = args.schedule == "pipelined" and variant == "ell"
     depth = args.defer if variant == "ell" else 1
+    if depth == 0:  # auto: 16 pending updates per apply pass where the lower-triangle schedule runs, else 8
+        lower_ok = n % 2 == 0 and os.environ.get("ELLHIP_SYMV", "1") != "0" and os.environ.get("ELLHIP_APPLY_LOWER", "1") != "0"
+        if not sharded:
+            depth = 16 if (lower_ok and n >= int(os.environ.get("ELLHIP_SYMV_MIN_N", "8192"))) else 8
+        else:
+            sym = (n % 64 == 0 and n // 64 >= world and (float(n) * n / 2 / world) / (64 * 2048) >= 200
+                   and os.environ.get("ELLHIP_SHARD_SYMMETRIC", "1") != "0")
+            depth = 16 if (lower_ok and sym) else 8
     C2 = args.compare_steps if variant == "ell" else 0
     # N > 1, depth 8: symmetric row shards (equal lower-trapezoid areas, partial symmetric GEMVs added by one
     # all-reduce, lower-trapezoid apply passes): 5*n^2/P bytes per GPU and update.  That schedule only, so the

@@ -579,11 +579,7 @@ __global__ __launch_bounds__(256) void k_sweep_apply(const double* Q, double* Qo
 }
 
 // ----------------------------------------------------------------------------- k_apply_lower ---
-// Lower-trapezoid apply pass for depth NP (8 or 16).  MEASURED NEGATIVE RESULT, kept selectable: at n = 16384 it
-// takes 0.62 ms at depth 8 (k_sweep_apply<LOWER>: 0.44 ms) and 1.36 ms at depth 16, so depth 16 ends up slower
-// than depth 8 (3420 vs 3730 updates/s): 16 x 16 coefficient reads from LDS per 512-column chunk and 4 NP
-// two-rounding multiply-subtracts per pair of elements make the pass issue bound, not HBM bound.  Depth 16 is
-// therefore available (ellhip_set_defer_depth(h, 16)) but not a default anywhere.  A
+// Lower-trapezoid apply pass for depth NP (8 or 16), used while every GEMV of the handle is a k_symv.  A
 // workgroup owns APL_TR consecutive rows and sweeps the columns up to the tile's diagonal in chunks of 512; per
 // chunk each thread loads its 16-byte pair of the NP pending vectors ONCE (registers) and runs all APL_TR rows
 // through it, so the vectors cost one L2 read per 16 rows (k_sweep_apply: one per 4) -- that is what makes
@@ -592,9 +588,15 @@ __global__ __launch_bounds__(256) void k_sweep_apply(const double* Q, double* Qo
 // the reference's sequence of roundings, x <- x - (c_j v_j[row]) v_j[col], j in recording order; the few
 // elements right of the diagonal inside the last chunk get the same expression (they are stale by contract:
 // nothing reads the strict upper triangle before k_mirror_lower_now rebuilds it).
+// History: the first version (row groups fully unrolled, row-outer / j-inner) needed 255 VGPRs + 68 AGPRs
+// (occupancy 1) and took 0.62 ms at depth 8 and 1.36 ms at depth 16 -- slower than k_sweep_apply<LOWER>
+// (0.44 ms); with the row-group loop rolled and j outermost it takes 0.40 ms at depth 8 and 0.41 ms at depth 16,
+// which makes depth 16 the fastest schedule (4120 vs 3810 updates/s at n = 16384).
 constexpr int APL_TR = 16;
 
-template <int NP, bool NT>
+// APL_RG = rows in flight per thread (measured at n = 16384, ms per pass: depth 8: RG 4 0.426, 8 0.404, 16 0.397;
+// depth 16: RG 4 0.409, 8 0.471, 16 1.57 (spills)).
+template <int NP, bool NT, int APL_RG = (NP == 16 ? 4 : 8)>
 __global__ __launch_bounds__(256) void k_apply_lower(double* __restrict__ Q, long long ld, long long n,
                                                      long long nrows, long long row0,
                                                      const double* __restrict__ pend,
@@ -619,29 +621,28 @@ __global__ __launch_bounds__(256) void k_apply_lower(double* __restrict__ Q, lon
         double2_t vj[NP];
 #pragma unroll
         for (int j = 0; j < NP; ++j) vj[j] = *reinterpret_cast<const double2_t*>(pend + (long long)j * n + c);
+#pragma unroll 1  // (fully unrolled, the row groups kept 255 VGPRs + 68 AGPRs alive: occupancy 1)
+        for (int r0 = 0; r0 < APL_TR; r0 += APL_RG) {
+            double2_t x[APL_RG];
+            bool on[APL_RG];
 #pragma unroll
-        for (int r0 = 0; r0 < APL_TR; r0 += 4) {
-            double2_t x[4];
-            bool on[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < APL_RG; ++u) {
                 const int r = r0 + u;
                 // a row takes part while the pair starts at or left of its diagonal (keeps the traffic at the trapezoid)
                 on[u] = r < nr && c <= row0 + lr0 + r;
                 if (on[u]) x[u] = ld_stream<NT, double2_t>(base + (long long)r * ld + c);
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                if (!on[u]) continue;
+            for (int j = 0; j < NP; ++j) {
 #pragma unroll
-                for (int j = 0; j < NP; ++j) {
+                for (int u = 0; u < APL_RG; ++u) {  // per element still j ascending: the reference's order of roundings
                     const double cf = coef[j][r0 + u];
                     x[u].x = x[u].x - cf * vj[j].x;
                     x[u].y = x[u].y - cf * vj[j].y;
                 }
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
+            for (int u = 0; u < APL_RG; ++u)
                 if (on[u]) *reinterpret_cast<double2_t*>(base + (long long)(r0 + u) * ld + c) = x[u];
         }
     }

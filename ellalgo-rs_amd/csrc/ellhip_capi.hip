@@ -90,7 +90,7 @@ struct ellhip_space {
     bool shard_symmetric = false;    // row shard whose GEMVs are partial symmetric sums (ellhip_set_shard_symmetric)
     int symv_seg = SYMV_SEG;         // segment width of the lower-triangle GEMV's tiles (see symv_alloc)
     int apply_lower = 1;             // with symv: apply passes touch the lower triangle only (ELLHIP_APPLY_LOWER)
-    int apply_kernel = 0;            // depth 8: 0 = k_sweep_apply<LOWER> (4-row tiles, 0.44 ms at n = 16384), 1 = k_apply_lower (0.62 ms)
+    int apply_kernel = 1;            // depth 8: 1 = k_apply_lower (16-row tiles, 0.40 ms at n = 16384), 0 = k_sweep_apply<LOWER> (0.44 ms)
     bool upper_stale = false;        // strict upper triangle of Q is out of date (see flush_pending)
     int defer = 1;                   // 1 = shrink Q at every cut; MAXPEND = record and apply in batches
     int npend = 0;                   // updates recorded since the last flush (host view, optimistic in queue mode)
@@ -222,7 +222,7 @@ void pick_shape(ellhip_space* s) {
     s->symv_rw = env_int("ELLHIP_SYMV_RW", 2);
     s->symv_min_n = env_int("ELLHIP_SYMV_MIN_N", 8192);
     s->apply_lower = env_int("ELLHIP_APPLY_LOWER", 1);
-    s->apply_kernel = env_int("ELLHIP_APPLY_KERNEL", 0);
+    s->apply_kernel = env_int("ELLHIP_APPLY_KERNEL", 1);
     s->sh_apply = {4, 1, s->sh_fused.nt};  // 8 pending vectors per column step: more rows per workgroup amortise them
     s->sh_apply.rw = env_int("ELLHIP_APPLY_RW", s->sh_apply.rw);
     s->sh_apply.unr = env_int("ELLHIP_APPLY_UNR", s->sh_apply.unr);
@@ -322,7 +322,7 @@ int flush_pending(ellhip_space* s, const double* gvec, double* gv_out) {
                        s->row0, (const double*)s->d_pend, (const double*)s->d_cpend, (const DevState*)s->d_st)
             if (s->defer == 16) {  // 16 pending updates: the 16-row-tile kernel (coefficients in LDS)
                 if (nt) APL_GO(16, true); else APL_GO(16, false);
-            } else if (s->apply_kernel == 1) {  // ELLHIP_APPLY_KERNEL=1: the same kernel at depth 8 (measured slower)
+            } else if (s->apply_kernel == 1) {  // depth 8, same kernel (0.40 ms; ELLHIP_APPLY_KERNEL=0: k_sweep_apply, 0.44)
                 if (nt) APL_GO(8, true); else APL_GO(8, false);
             } else {
                 rc = nt ? launch_apply_t<2, true, false, true>(s, nullptr, nullptr)

@@ -170,8 +170,9 @@ int ellhip_commit(ellhip_space *s, const double *next_grad);
  * before anything observes Q).  An equal-block row shard keeps the full-row passes, so its bits differ from an
  * unsharded handle's at depth 8 (both stay within the parity tolerance; shards agree with each other bit for
  * bit); a symmetric row shard (below) runs the lower-triangle schedule on its trapezoid.
- * depth = 16: the same with 16 recorded updates per apply pass; lower-triangle schedule only (ELLHIP_E_INVALID
- * otherwise).  Measured slower than depth 8 on MI355X (the apply pass turns issue bound): not a default. */
+ * depth = 16: the same with 16 recorded updates per apply pass (4.5 n^2 bytes per update); lower-triangle schedule
+ * only (ELLHIP_E_INVALID otherwise).  The fastest schedule on MI355X where it exists (4100 vs 3800 updates/s at
+ * n = 16384) and bench.py's default there. */
 int ellhip_set_defer_depth(ellhip_space *s, int depth);
 int ellhip_defer_depth(const ellhip_space *s);
 /* Apply whatever the deferred schedule has recorded so far (and a shrink a pipelined cut left pending) now,

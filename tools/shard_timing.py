@@ -18,6 +18,7 @@ from ellalgo_rs_amd.sharded import HipShardEngine, partition, partition_symmetri
 n, P = int(sys.argv[1]), int(sys.argv[2])
 K = int(sys.argv[3]) if len(sys.argv) > 3 else 32
 symmetric = os.environ.get("SHARD_SYMMETRIC", "1") != "0"
+depth = int(os.environ.get("SHARD_DEPTH", "16" if symmetric else "8"))
 kinds, grads, b0, b1 = synth.deep_cuts(n, K)
 engines = []
 for r in range(P):
@@ -25,7 +26,7 @@ for r in range(P):
     e = HipShardEngine(n, row0, nrows, 1.0, None, None, np.zeros(n), device=0)
     if symmetric:
         e.set_symmetric(True)
-    e.set_defer_depth(8)
+    e.set_defer_depth(depth)
     engines.append(e)
 for e in engines:
     e.profile_enable(True)
@@ -50,7 +51,7 @@ for i in range(K):
     for e in engines:
         st.append(e.end())   # synchronous
     assert all(s == 0 for s in st), (i, st)
-print(f"n={n} P={P} symmetric={symmetric}: per-update kernel time per rank (ms), {K} updates")
+print(f"n={n} P={P} symmetric={symmetric} depth={depth}: per-update kernel time per rank (ms), {K} updates")
 worst = 0.0
 for r, e in enumerate(engines):
     pr = e.profile_read()
