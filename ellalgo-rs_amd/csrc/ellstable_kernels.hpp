@@ -380,11 +380,26 @@ __global__ __launch_bounds__(256) void k_st_fwd_persist(double* __restrict__ M, 
 
     double* t = lds + wv * (SPANEL * SLDS_PAD);
     // The products S[col][row] = U[row][col] * w[row] of a row block are needed by nobody before the backward
-    // solve, so for the LAST row block (the one this workgroup's own solve is waiting for) they stay in registers
-    // and are written back only after the own block has been solved and published: the two LDS transposes, the
-    // global stores and their four barriers leave the critical path of the dependency chain.
+    // solve, so for the LAST row block (the one this workgroup's own solve is waiting for) they are written back
+    // only after the own block has been solved and published: the two LDS transposes, the global stores and their
+    // four barriers leave the critical path of the dependency chain.  They are RECOMPUTED then (the 128 x 128
+    // factor entries are re-read, L2-resident; w of that block is still in LDS) rather than kept in registers
+    // across the diagonal-block solve: keeping them cost 128 VGPRs there and made the kernel spill (472 B/lane).
     double2_t u[2][16];
-    auto write_back = [&](long long J0) {
+    auto write_back = [&](long long J0, bool recompute) {
+        if (recompute) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const long long r0 = J0 + 32 * wv + 16 * h;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const double2_t f = *reinterpret_cast<const double2_t*>(M + (r0 + r) * ld + cl);
+                    const double wj = wblk[32 * wv + 16 * h + r];
+                    u[h][r].x = f.x * wj;
+                    u[h][r].y = f.y * wj;
+                }
+            }
+        }
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const long long r0 = J0 + 32 * wv + 16 * h;
@@ -451,7 +466,7 @@ __global__ __launch_bounds__(256) void k_st_fwd_persist(double* __restrict__ M, 
             wstrip[threadIdx.x] = wstrip[threadIdx.x] - s4;
         }
         if (kb + 1 < sblk) {
-            write_back(J0);
+            write_back(J0, false);
             __syncthreads();  // tiles drained, part reusable
         }
     }
@@ -459,7 +474,7 @@ __global__ __launch_bounds__(256) void k_st_fwd_persist(double* __restrict__ M, 
     st_fwd_diag_block<true>(M, ld, n, c0, blk, dreg, lds, dlds, wstrip, w, z, gg, flags + sblk, epoch);
     if (sblk > 0) {
         __syncthreads();  // the parked pieces have been written back: `lds` is free for the transposes
-        write_back((sblk - 1) * SB);
+        write_back((sblk - 1) * SB, true);
     }
 }
 
