@@ -181,7 +181,11 @@ struct ProfScope {
                 if (prof_flush(s) != 0) return;
             } else {
                 ProfEvent e;
-                if (hipEventCreate(&e.a) != hipSuccess || hipEventCreate(&e.b) != hipSuccess) return;
+                if (hipEventCreate(&e.a) != hipSuccess) return;
+                if (hipEventCreate(&e.b) != hipSuccess) {
+                    (void)hipEventDestroy(e.a);
+                    return;
+                }
                 e.cls = cls;
                 s->prof_events.push_back(e);
             }
@@ -705,10 +709,17 @@ int write_state(ellhip_space* s) {
     return 0;
 }
 
+// Bitwise symmetry test of the caller's matrix, in 64 x 64 tiles so that the transposed accesses stay in cache
+// (a plain double loop walks one operand with stride n: tens of seconds at n = 16384).
 bool host_is_symmetric(const double* mq, long long n) {
-    for (long long i = 0; i < n; ++i)
-        for (long long j = 0; j < i; ++j)
-            if (memcmp(&mq[i * n + j], &mq[j * n + i], sizeof(double)) != 0) return false;
+    constexpr long long T = 64;
+    for (long long i0 = 0; i0 < n; i0 += T)
+        for (long long j0 = 0; j0 <= i0; j0 += T) {
+            const long long i1 = std::min(i0 + T, n), j1 = std::min(j0 + T, n);
+            for (long long i = i0; i < i1; ++i)
+                for (long long j = j0; j < j1 && j < i; ++j)
+                    if (memcmp(&mq[i * n + j], &mq[j * n + i], sizeof(double)) != 0) return false;
+        }
     return true;
 }
 
@@ -743,7 +754,7 @@ int create_impl(ellhip_space** out, int variant, long long n, long long row0, lo
     // n = 16384: 5.8 -> 6.3 TB/s); blocks that live in the Infinity Cache are left dense.
     s->ld = n;
     if ((n % 512) == 0 && (double)nrows * (double)n * 8.0 > 200.0 * 1024 * 1024) s->ld = n + 16;
-    s->ld = n + env_int("ELLHIP_PAD", (int)(s->ld - n));
+    s->ld = n + std::max(0, env_int("ELLHIP_PAD", (int)(s->ld - n)));
     if ((n % 2) == 0 && (s->ld % 2) != 0) s->ld += 1;
     if (variant == ELLHIP_SPACE_ELL_STABLE) s->ld = n + (n & 1);  // 16-byte aligned rows for the 2-column lanes
     pick_shape(s);
@@ -891,6 +902,7 @@ void ellhip_destroy(ellhip_space* s) {
     if (!s) return;
     DeviceGuard guard(s->device);
     if (s->stream) (void)hipStreamSynchronize(s->stream);
+    if (s->aux_stream) (void)hipStreamSynchronize(s->aux_stream);  // nothing may be in flight when the buffers go
     for (auto& pe : s->prof_events) {
         (void)hipEventDestroy(pe.a);
         (void)hipEventDestroy(pe.b);
@@ -912,7 +924,6 @@ void ellhip_destroy(ellhip_space* s) {
     if (s->d_flags) (void)hipFree(s->d_flags);
     if (s->d_st) (void)hipFree(s->d_st);
     if (s->h_result) (void)hipHostFree(s->h_result);
-    if (s->aux_stream) (void)hipStreamSynchronize(s->aux_stream);
     if (s->ev_fork) (void)hipEventDestroy(s->ev_fork);
     if (s->ev_join) (void)hipEventDestroy(s->ev_join);
     if (s->aux_stream) (void)hipStreamDestroy(s->aux_stream);
@@ -1210,7 +1221,8 @@ int ellhip_calc(int64_t n, int use_parallel_cut, int kind, double beta0, int has
     cp.b1 = has_beta1 ? beta1 : 0.0;
     hipLaunchKernelGGL(k_calc_one, dim3(1), dim3(1), 0, 0, EllCalcDev::make(n, use_parallel_cut), cp, tsq, d_out);
     double h[4];
-    hipError_t e = hipMemcpy(h, d_out, sizeof h, hipMemcpyDeviceToHost);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpy(h, d_out, sizeof h, hipMemcpyDeviceToHost);
     (void)hipFree(d_out);
     if (e != hipSuccess) return fail(ELLHIP_E_HIP, "ellhip_calc", e);
     out3[0] = h[1];

@@ -111,3 +111,83 @@ def test_ellstable_first_update_closed_form(gpu, orc):
     np.testing.assert_allclose(np.diag(m), np.diag(o.mq), rtol=1e-12)
     np.testing.assert_allclose(e.xc(), o.xc, rtol=1e-12, atol=1e-300)
     assert abs(e.kappa - o.kappa) <= 1e-13 * abs(o.kappa)
+
+
+def _close_in_blocks(qg, qo, tol, what):
+    """max|qg - qo| <= tol * max|qo| without a third full-size temporary (row blocks)."""
+    scale = 0.0
+    err = 0.0
+    for r in range(0, qo.shape[0], 1024):
+        a, b = qg[r:r + 1024], qo[r:r + 1024]
+        scale = max(scale, float(np.max(np.abs(b))))
+        err = max(err, float(np.max(np.abs(a - b))))
+    assert err <= tol * scale, f"{what}: Q abs err {err} vs scale {scale}"
+
+
+def test_ell_default_schedule_matches_oracle_at_full_size(gpu, orc):
+    """The timed configuration itself (n = 16384, parallel cuts, depth 16, lower-triangle GEMV + lower-trapezoid
+    apply, pipelined queue) against the CPU oracle on the same 18 cuts -- one apply pass at cut 16, two cuts
+    still recorded when the state is read.  Whole state to the north-star tolerance."""
+    from ellalgo_rs_amd import synth
+    from util import TOL
+    k = 18
+    kinds, grads, b0, b1 = synth.parallel_cuts(N, k)
+    e = gpu.Ell.new_with_scalar(1.0, np.zeros(N))
+    e.defer_depth = 16
+    e.queue_upload(kinds, grads, b0, b1)
+    e.queue_run(0, k, fused=True)
+    st, ts = e.queue_results()
+    o = orc.OracleEll.new_with_scalar(1.0, np.zeros(N))
+    want_ts = np.empty(k)
+    for i in range(k):
+        assert o.update_rowwise_mt(int(kinds[i]), grads[i], b0[i], None if np.isnan(b1[i]) else b1[i]) == 0
+        want_ts[i] = o.tsq
+    assert np.all(st == 0)
+    assert np.max(np.abs(ts - want_ts) / np.abs(want_ts)) <= TOL
+    assert abs(e.kappa - o.kappa) <= TOL * abs(o.kappa)
+    xo = np.array(o.xc)
+    assert np.max(np.abs(e.xc() - xo)) <= TOL * np.max(np.abs(xo))
+    qg = e.mq                      # applies the two recorded updates and mirrors the lower triangle
+    _close_in_blocks(qg, o.mq, TOL, "n=16384 depth 16")
+    assert np.array_equal(qg[:2048, :2048], qg[:2048, :2048].T)
+
+
+def test_ellstable_matches_oracle_at_full_size(gpu, orc):
+    """BASELINE config 5 (n = 16384 EllStable, deep cuts): the persistent flag-chained solves over all 128
+    column strips against the CPU oracle -- diagonal, factor AND scratch triangle, xc, kappa, tsq."""
+    from ellalgo_rs_amd import synth
+    from util import TOL
+    k = 3
+    kinds, grads, b0, _ = synth.deep_cuts(N, k)
+    e = gpu.EllStable.new_with_scalar(1.0, np.zeros(N))
+    o = orc.OracleEllStable.new_with_scalar(1.0, np.zeros(N))
+    for i in range(k):
+        assert int(e.update_bias_cut((grads[i], float(b0[i])))) == o.update(0, grads[i], b0[i]) == 0
+        assert abs(e.tsq() - o.tsq) <= TOL * abs(o.tsq)
+    assert abs(e.kappa - o.kappa) <= TOL * abs(o.kappa)
+    xo = np.array(o.xc)
+    assert np.max(np.abs(e.xc() - xo)) <= TOL * np.max(np.abs(xo))
+    _close_in_blocks(e.mq, o.mq, TOL, "n=16384 EllStable")
+
+
+def test_ell_n32768_matches_oracle(gpu, orc):
+    """BASELINE config 4's size on ONE GPU (Q = 8 GiB): two deep cuts through the depth-16 schedule against the
+    oracle; the 8 GiB matrices are compared on a band of rows (first, middle, last 512) to bound host memory."""
+    from ellalgo_rs_amd import synth
+    from util import TOL
+    n, k = 32768, 2
+    kinds, grads, b0, _ = synth.deep_cuts(n, k)
+    e = gpu.Ell.new_with_scalar(1.0, np.zeros(n))
+    e.defer_depth = 16
+    o = orc.OracleEll.new_with_scalar(1.0, np.zeros(n))
+    for i in range(k):
+        assert int(e.update_bias_cut((grads[i], float(b0[i])))) == 0
+        assert o.update_rowwise_mt(0, grads[i], b0[i], None) == 0
+        assert abs(e.tsq() - o.tsq) <= TOL * abs(o.tsq)
+    assert abs(e.kappa - o.kappa) <= TOL * abs(o.kappa)
+    xo = np.array(o.xc)
+    assert np.max(np.abs(e.xc() - xo)) <= TOL * np.max(np.abs(xo))
+    qg, qo = e.mq, o.mq
+    scale = 1.0   # Q0 = I and two small rank-1 corrections: the largest element stays ~1
+    for r in (0, n // 2 - 256, n - 512):
+        assert np.max(np.abs(qg[r:r + 512] - qo[r:r + 512])) <= TOL * scale
