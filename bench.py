@@ -522,7 +522,7 @@ def main() -> None:
         space = ShardedEll.new_with_scalar(1.0, np.zeros(n), device=local_rank, symmetric=shard_sym,
                                           defer_depth=depth if shard_sym else 8)
     nq = W + K + P + 2 * C2 * len(alts)
-    if variant == "ell" and depth != 1 and not shard_sym:
+    if variant == "ell" and not shard_sym:   # always explicit: a new unsharded handle may start at depth 16 by itself
         space.set_defer_depth(depth) if sharded else setattr(space, "defer_depth", depth)
     space.queue_upload(kinds[:nq], grads[:nq], b0[:nq], b1[:nq])
 

@@ -809,6 +809,15 @@ int create_impl(ellhip_space** out, int variant, long long n, long long row0, lo
     if (hipStreamSynchronize(s->stream) != hipSuccess) return bail(fail(ELLHIP_E_HIP, "sync after upload"));
     rc = write_state(s);
     if (rc) return bail(rc);
+    // Default schedule of a new unsharded Ell handle: depth 16 wherever the lower-triangle schedule exists (even
+    // n >= 8192: 4.5 n^2 instead of 24 n^2 bytes per update, results within the parity tolerance of depth 1, Q made
+    // current for every observer), otherwise the reference's data flow (depth 1).  ELLHIP_AUTO_DEFER=0 keeps depth 1
+    // everywhere; ellhip_set_defer_depth overrides either way.  Row shards stay at 1 until their owner chooses.
+    if (variant == ELLHIP_SPACE_ELL && !sharded && env_int("ELLHIP_AUTO_DEFER", 1) && s->symv && s->apply_lower &&
+        (n % 2) == 0 && n >= s->symv_min_n) {
+        rc = ellhip_set_defer_depth(s, 16);
+        if (rc) return bail(rc);
+    }
     *out = s;
     return 0;
 }

@@ -256,3 +256,34 @@ def test_apply_kernels_agree_bit_for_bit(gpu, monkeypatch):
         assert np.all(st == 0)
         outs.append((e.mq, e.xc(), e.kappa))
     assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1]) and outs[0][2] == outs[1][2]
+
+
+def test_default_depth_of_new_handles(gpu, monkeypatch):
+    """ellhip_create: depth 16 wherever the lower-triangle schedule exists (unsharded Ell, even n >= 8192), else the
+    reference's data flow; ELLHIP_AUTO_DEFER=0 keeps depth 1 everywhere; clones inherit; the setter overrides."""
+    assert gpu.Ell.new_with_scalar(1.0, np.zeros(4096)).defer_depth == 1
+    assert gpu.Ell.new_with_scalar(1.0, np.zeros(8191)).defer_depth == 1      # odd n: no 16-byte pairs
+    e = gpu.Ell.new_with_scalar(1.0, np.zeros(8192))
+    assert e.defer_depth == 16 and e.clone().defer_depth == 16
+    e.defer_depth = 1
+    assert e.defer_depth == 1 and e.clone().defer_depth == 1
+    monkeypatch.setenv("ELLHIP_AUTO_DEFER", "0")
+    assert gpu.Ell.new_with_scalar(1.0, np.zeros(8192)).defer_depth == 1
+    monkeypatch.delenv("ELLHIP_AUTO_DEFER")
+    # a caller-supplied NON-symmetric matrix: the first successful update mirrors it as the reference does, then
+    # the recorded schedule takes over -- same state as depth 1 to rounding
+    n = 8192
+    rng = np.random.default_rng(11)
+    mq = np.eye(n)
+    mq[5, 3] = 0.25          # lower-triangle entry without its mirror image
+    from ellalgo_rs_amd import synth
+    kinds, grads, b0, _ = synth.deep_cuts(n, 3)
+    a = gpu.Ell.new_with_matrix(1.0, mq, np.zeros(n))
+    b = gpu.Ell.new_with_matrix(1.0, mq, np.zeros(n))
+    b.defer_depth = 1
+    assert a.defer_depth == 16
+    for i in range(3):
+        assert int(a.update_bias_cut((grads[i], float(b0[i])))) == int(b.update_bias_cut((grads[i], float(b0[i])))) == 0
+    qa, qb = a.mq, b.mq
+    assert qa[3, 5] == qa[5, 3] and np.max(np.abs(qa - qb)) <= 1e-12 * np.max(np.abs(qb))
+    assert np.max(np.abs(a.xc() - b.xc())) <= 1e-12 * np.max(np.abs(b.xc()))

@@ -81,6 +81,7 @@ def test_deferred_symv_equals_immediate_path_at_full_size(gpu, cuts):
     kinds, grads, b0, b1 = synth.parallel_cuts(N, k)
     a = gpu.Ell.new_with_scalar(1.0, np.zeros(N))
     b = gpu.Ell.new_with_scalar(1.0, np.zeros(N))
+    a.defer_depth = 1   # (a new handle of this size starts at depth 16)
     b.defer_depth = 8
     a.queue_upload(kinds, grads, b0, b1)
     b.queue_upload(kinds, grads, b0, b1)
@@ -133,7 +134,7 @@ def test_ell_default_schedule_matches_oracle_at_full_size(gpu, orc):
     k = 18
     kinds, grads, b0, b1 = synth.parallel_cuts(N, k)
     e = gpu.Ell.new_with_scalar(1.0, np.zeros(N))
-    e.defer_depth = 16
+    assert e.defer_depth == 16          # what a new handle of this size starts with
     e.queue_upload(kinds, grads, b0, b1)
     e.queue_run(0, k, fused=True)
     st, ts = e.queue_results()

@@ -195,6 +195,7 @@ def test_deep_cuts_large_matches_oracle(gpu, orc, n):
     from ellalgo_rs_amd import synth
     kinds, grads, b0, _ = synth.deep_cuts(n, 6)   # n = 8192 exercises the padded leading dimension + nt policy
     g = gpu.Ell.new_with_scalar(1.0, np.zeros(n))
+    g.defer_depth = 1                             # the reference's data flow (n = 8192 would start at depth 16)
     o = orc.OracleEll.new_with_scalar(1.0, np.zeros(n))
     for i in range(6):
         so = o.update(0, grads[i], b0[i])

@@ -12,8 +12,8 @@ def run_ell(gpu, variant, n, k, depth):
     from ellalgo_rs_amd import synth
     kinds, grads, b0, b1 = synth.parallel_cuts(n, k)
     e = (gpu.EllStable if variant == "stable" else gpu.Ell).new_with_scalar(1.0, np.zeros(n))
-    if variant == "ell" and depth != 1:
-        e.defer_depth = depth
+    if variant == "ell":
+        e.defer_depth = depth   # explicit: with the lowered threshold a new handle would start at depth 16
     e.queue_upload(kinds, grads, b0, b1)
     e.queue_run(0, k, fused=(variant == "ell"))
     st, ts = e.queue_results()
