@@ -21,7 +21,7 @@ KERNEL_CLASS_NAMES = ("gemv", "scalar", "rank1", "stable_fwd", "stable_bwd", "st
 EXPORTS = [
     "ellhip_create", "ellhip_create_shard", "ellhip_clone", "ellhip_destroy", "ellhip_update", "ellhip_tsq",
     "ellhip_get_xc", "ellhip_set_xc", "ellhip_kappa", "ellhip_ndim", "ellhip_get_mq",
-    "ellhip_set_no_defer_trick", "ellhip_set_use_parallel_cut", "ellhip_set_defer_depth", "ellhip_defer_depth", "ellhip_flush", "ellhip_set_shard_symmetric", "ellhip_calc", "ellhip_update_begin",
+    "ellhip_set_no_defer_trick", "ellhip_set_use_parallel_cut", "ellhip_set_defer_depth", "ellhip_defer_depth", "ellhip_flush", "ellhip_queue_primed", "ellhip_set_shard_symmetric", "ellhip_calc", "ellhip_update_begin",
     "ellhip_update_end", "ellhip_gt_dev", "ellhip_set_gt_dev", "ellhip_prime", "ellhip_cut", "ellhip_commit",
     "ellhip_queue_upload", "ellhip_queue_run", "ellhip_queue_run_fused", "ellhip_queue_begin", "ellhip_queue_end",
     "ellhip_queue_prime", "ellhip_queue_cut", "ellhip_queue_commit", "ellhip_queue_results", "ellhip_set_stream",
@@ -78,6 +78,7 @@ def load():
         "ellhip_set_no_defer_trick": (i32, [vp, i32]),
         "ellhip_set_use_parallel_cut": (i32, [vp, i32]),
         "ellhip_set_defer_depth": (i32, [vp, i32]),
+        "ellhip_queue_primed": (i64, [vp]),
         "ellhip_defer_depth": (i32, [vp]),
         "ellhip_flush": (i32, [vp]),
         "ellhip_set_shard_symmetric": (i32, [vp, i32]),

@@ -632,13 +632,36 @@ int ensure_committed(ellhip_space* s) {
     return 0;
 }
 
+void drop_prime(ellhip_space* s);
+
+// A gradient that is primed but not yet cut carries y = Q_base * g for the base the recorded updates belong to
+// (the scalar stage corrects it with them).  When something other than the cut sequence itself applies the
+// recorded updates -- ellhip_flush, or an observer of Q between commit(next) and cut(next) -- the base changes
+// under that y, so it is recomputed against the new base.  A row shard cannot (its GEMV needs the owner's
+// collective): its prime is dropped instead and the owner primes again (ellhip_queue_primed tells).
+bool prime_is_uncut(const ellhip_space* s) {
+    return s->variant == ELLHIP_SPACE_ELL && s->primed && !s->shrink_pending && s->g_cur != nullptr;
+}
+int refresh_prime(ellhip_space* s) {
+    if (s->sharded) {
+        drop_prime(s);
+        return 0;
+    }
+    return do_prime(s, s->g_cur, s->cur);
+}
+
 // For observers of Q itself (get_mq, clone, mode switches): also apply what deferred mode has recorded.
 int make_q_current(ellhip_space* s) {
+    const bool uncut = prime_is_uncut(s);
     int rc = ensure_committed(s);
     if (rc) return rc;
     if (s->npend > 0) {
         rc = flush_pending(s, nullptr, nullptr);
         if (rc) return rc;
+        if (uncut) {
+            rc = refresh_prime(s);
+            if (rc) return rc;
+        }
     }
     if (s->upper_stale && !s->sharded) {  // lower-triangle-only apply passes ran: rebuild the mirrored half
         // (a symmetric row shard cannot: the mirrored elements live on other ranks; its rows stay valid up to
@@ -1187,11 +1210,18 @@ int ellhip_flush(ellhip_space* s) {
     if (!s) return fail(ELLHIP_E_INVALID, "NULL handle");
     if (s->variant != ELLHIP_SPACE_ELL) return 0;
     DeviceGuard guard(s->device);
+    const bool uncut = prime_is_uncut(s);
     int rc = ensure_committed(s);
     if (rc) return rc;
-    if (s->npend > 0) return flush_pending(s, nullptr, nullptr);
+    if (s->npend > 0) {
+        rc = flush_pending(s, nullptr, nullptr);
+        if (rc) return rc;
+        if (uncut) return refresh_prime(s);  // the primed gradient's Q_base*g belongs to the old base
+    }
     return 0;
 }
+
+int64_t ellhip_queue_primed(const ellhip_space* s) { return (s && s->primed) ? (int64_t)s->primed_qindex : -1; }
 
 int ellhip_set_shard_symmetric(ellhip_space* s, int flag) {
     if (!s) return fail(ELLHIP_E_INVALID, "NULL handle");

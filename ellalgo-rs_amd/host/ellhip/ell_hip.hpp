@@ -104,6 +104,8 @@ class SpaceHip {
     // 1 = rewrite Q at every cut (reference data flow); 8 = record cuts, apply them to Q in batches of 8
     void set_defer_depth(int depth) { check(ellhip_set_defer_depth(h_, depth), "ellhip_set_defer_depth"); }
     int defer_depth() const { return ellhip_defer_depth(h_); }
+    void flush() { check(ellhip_flush(h_), "ellhip_flush"); }
+    long long queue_primed() const { return ellhip_queue_primed(h_); }
     std::size_t ndim() const { return n_; }
     ellhip_space* handle() { return h_; }
 

@@ -109,6 +109,9 @@ class HipShardEngine:
     def flush(self):
         capi.check(self._lib.ellhip_flush(self.h), "ellhip_flush")
 
+    def queue_primed(self) -> int:
+        return int(self._lib.ellhip_queue_primed(self.h))
+
     def set_symmetric(self, flag=True):
         capi.check(self._lib.ellhip_set_shard_symmetric(self.h, int(flag)), "ellhip_set_shard_symmetric")
 
@@ -256,14 +259,25 @@ class ShardedEll:
     def kappa(self):
         return self.engine.kappa()
 
+    def _sync_primed(self) -> None:
+        """A shard whose recorded updates were applied by an observer (flush, mq_rows, a depth change) has dropped
+        its primed GEMV -- it belonged to the old base: the next queue_run then primes, and exchanges, again."""
+        if hasattr(self.engine, "queue_primed"):
+            self._primed_index = self.engine.queue_primed()
+
     @property
     def mq_rows(self) -> np.ndarray:
         """This rank's row block of Q (symmetric mode: current up to each row's diagonal only)."""
-        return self.engine.mq_rows()
+        with self._issue():
+            out = self.engine.mq_rows()
+        self._sync_primed()
+        return out
 
     def set_defer_depth(self, depth: int) -> None:
-        """See ellhip_set_defer_depth: 1 = immediate shrink, 8 = recorded and applied in batches."""
-        self.engine.set_defer_depth(depth)
+        """See ellhip_set_defer_depth: 1 = immediate shrink, 8 / 16 = recorded and applied in batches."""
+        with self._issue():
+            self.engine.set_defer_depth(depth)
+        self._sync_primed()
 
     # ---- device-resident cut queue (every rank uploads the same cuts)
     def queue_upload(self, kinds, grads, beta0, beta1=None) -> int:
@@ -313,6 +327,9 @@ class ShardedEll:
         """apply the recorded (deferred) updates now (local rows; no collective involved)"""
         with self._issue():
             self.engine.flush()
+        # a shard whose recorded updates were applied has dropped its primed GEMV (it belonged to the old base):
+        # the next queue_run primes -- and exchanges -- again
+        self._sync_primed()
 
     def synchronize(self):
         self.engine.synchronize()

@@ -182,6 +182,11 @@ int ellhip_defer_depth(const ellhip_space *s);
  * asynchronously on the handle's stream.  Never needed for correctness (every observer of Q does it itself);
  * bench.py calls it at both ends of its timed region so that the region pays for ALL of its updates. */
 int ellhip_flush(ellhip_space *s);
+/* Queue index of the cut whose GEMV is in place (primed, not yet cut), or -1.  ellhip_flush and the observers of
+ * Q (get_mq, clone, mode switches) keep a primed gradient valid on an unsharded handle (its Q_base*g is recomputed
+ * when they apply recorded updates); on a row shard they DROP the prime instead, because the recomputation needs
+ * the owner's collective -- a multi-GPU driver asks here after such a call and primes again if need be. */
+int64_t ellhip_queue_primed(const ellhip_space *s);
 /* Symmetric row shard (multi-GPU, deferred schedule only).  Call once after ellhip_create_shard, together with
  * ellhip_set_defer_depth(h, 8), on every rank; shard boundaries must be multiples of 64 and n even.  The GEMV
  * of each cut then reads only this shard's LOWER trapezoid (columns up to each row's diagonal) and leaves in the

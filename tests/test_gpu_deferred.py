@@ -287,3 +287,61 @@ def test_default_depth_of_new_handles(gpu, monkeypatch):
     qa, qb = a.mq, b.mq
     assert qa[3, 5] == qa[5, 3] and np.max(np.abs(qa - qb)) <= 1e-12 * np.max(np.abs(qb))
     assert np.max(np.abs(a.xc() - b.xc())) <= 1e-12 * np.max(np.abs(b.xc()))
+
+
+@pytest.mark.parametrize("depth", [8, 16])
+def test_observers_between_prime_and_cut_keep_the_primed_gradient_valid(gpu, orc, depth, monkeypatch):
+    """A gradient that is primed but not yet cut carries y = Q_base*g for the base the recorded updates belong to.
+    ellhip_flush / get_mq / clone in that window apply the recorded updates (Q_base changes), so the library must
+    recompute y: the sequence has to come out the same as the undisturbed one."""
+    from ellalgo_rs_amd import synth
+    from util import TOL
+    monkeypatch.setenv("ELLHIP_SYMV_MIN_N", "512")
+    n, k = 1024, 30
+    kinds, grads, b0, b1 = synth.parallel_cuts(n, k)
+    a = gpu.Ell.new_with_scalar(1.0, np.zeros(n))
+    a.defer_depth = depth
+    a.queue_upload(kinds, grads, b0, b1)
+    a.queue_run(0, k, fused=True)
+    sa, ta = a.queue_results()
+    assert np.all(sa == 0)
+    # queue path: the fused run leaves the next cut primed; flush / get_mq / clone in between
+    b = gpu.Ell.new_with_scalar(1.0, np.zeros(n))
+    b.defer_depth = depth
+    b.queue_upload(kinds, grads, b0, b1)
+    b.queue_run(0, 5, fused=True)
+    b.flush()
+    b.queue_run(5, 6, fused=True)
+    q_mid = b.mq
+    b.queue_run(11, 7, fused=True)
+    c = b.clone()
+    b.queue_run(18, k - 18, fused=True)
+    sb, tb = b.queue_results()
+    assert np.all(sb == 0)
+    assert np.max(np.abs(ta - tb) / np.abs(ta)) <= 1e-12
+    assert np.max(np.abs(a.mq - b.mq)) <= 1e-12 * np.max(np.abs(a.mq))
+    assert np.max(np.abs(a.xc() - b.xc())) <= 1e-12 * np.max(np.abs(a.xc()))
+    # direct path: prime / cut / commit(next) with observers while `next` is primed
+    d = gpu.Ell.new_with_scalar(1.0, np.zeros(n))
+    d.defer_depth = depth
+    d.prime(grads[0])
+    for i in range(k):
+        beta = (b0[i], None if np.isnan(b1[i]) else b1[i])
+        assert int(d.cut(int(kinds[i]), beta)) == 0
+        assert abs(d.tsq() - ta[i]) <= 1e-12 * abs(ta[i]), f"cut {i}"
+        d.commit(grads[i + 1] if i + 1 < k else None)
+        if i == 4:
+            d.flush()
+        if i == 10:
+            assert np.max(np.abs(d.mq - q_mid)) <= 1e-12 * np.max(np.abs(q_mid))
+        if i == 17:
+            e = d.clone()
+            assert np.max(np.abs(e.mq - c.mq)) <= 1e-12 * np.max(np.abs(c.mq))
+    assert np.max(np.abs(a.mq - d.mq)) <= 1e-12 * np.max(np.abs(a.mq))
+    # and the oracle agrees with all of them
+    o = orc.OracleEll.new_with_scalar(1.0, np.zeros(n))
+    for i in range(k):
+        assert o.update(int(kinds[i]), grads[i], b0[i], None if np.isnan(b1[i]) else b1[i]) == 0
+    for sp in (a, b, d):
+        assert np.max(np.abs(sp.mq - o.mq)) <= TOL * np.max(np.abs(o.mq))
+        assert np.max(np.abs(sp.xc() - o.xc)) <= TOL * np.max(np.abs(o.xc))

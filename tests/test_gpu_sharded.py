@@ -85,6 +85,11 @@ def _worker(rank, world, port, backend, n, k, fused, defer, errq, symmetric=Fals
         sh.queue_upload(kinds[half:], grads[half:], b0[half:], b1[half:])
         ref.queue_upload(kinds[half:], grads[half:], b0[half:], b1[half:])
         sh.queue_run(0, 2, fused=fused)
+        if defer != 1:
+            # as bench.py does between its regions: apply the recorded updates while (pipelined schedule) cut 2 is
+            # primed -- the shard drops that GEMV (it belonged to the old base) and the next run primes + exchanges again
+            sh.flush()
+            assert sh._primed_index == -1
         sh.queue_run(2, k - half - 2, fused=fused)
         ref.queue_run(0, k - half)
         st_s, ts_s = sh.queue_results()
