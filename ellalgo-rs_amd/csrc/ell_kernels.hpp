@@ -456,7 +456,9 @@ __global__ __launch_bounds__(256) void k_sweep_apply(const double* Q, double* Qo
                                                      double* __restrict__ gv_out,
                                                      const DevState* __restrict__ st, int reverse) {
     __shared__ double red[4][RW];
-    if (st->halted) return;
+    // (no `halted` test here or in k_apply_lower / k_pend_reset: updates recorded BEFORE a queue halted belong to
+    // successful cuts and must reach Q whenever something observes it; applying them early is always legal)
+    (void)st;
     using V = typename VecT<VEC>::type;
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -603,7 +605,7 @@ __global__ __launch_bounds__(256) void k_apply_lower(double* __restrict__ Q, lon
                                                      const double* __restrict__ cpend,
                                                      const DevState* __restrict__ st) {
     __shared__ double coef[NP][APL_TR];
-    if (st->halted) return;
+    (void)st;
     const long long tile = (long long)gridDim.x - 1 - blockIdx.x;  // last (longest) rows first
     const long long lr0 = tile * APL_TR;                            // first local row of the tile
     if (lr0 >= nrows) return;
@@ -651,7 +653,6 @@ __global__ __launch_bounds__(256) void k_apply_lower(double* __restrict__ Q, lon
 // After a flush: forget the pending updates (unused slots must read as exact zeros).
 __global__ __launch_bounds__(256) void k_pend_reset(double* __restrict__ pend, double* __restrict__ cpend,
                                                     long long total, DevState* __restrict__ st) {
-    if (st->halted) return;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
          i += (long long)gridDim.x * blockDim.x)
         pend[i] = 0.0;

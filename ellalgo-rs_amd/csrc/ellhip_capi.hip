@@ -122,8 +122,9 @@ struct ellhip_space {
     int dir = 0;                  // direction of the next pass over Q (serpentine)
     long long primed_qindex = -1; // queue index the primed gradient belongs to (-1: a direct gradient)
 
-    // cached scalars (refreshed by every synchronous read-back)
+    // cached scalars (refreshed by every synchronous read-back; `scalars_stale`: queue cuts have been issued since)
     double kappa = 1.0, tsq = 0.0;
+    bool scalars_stale = false;
 
     // device-resident cut queue
     long long qk = 0;
@@ -598,6 +599,7 @@ int read_back(ellhip_space* s) {
     HIPCHK(hipStreamSynchronize(s->stream));
     s->kappa = s->h_result->kappa;
     s->tsq = s->h_result->tsq;
+    s->scalars_stale = false;
     if (s->h_result->solve_err)
         return fail(ELLHIP_E_HIP, "EllStable persistent solve: a flag wait timed out (set ELLHIP_STABLE_PERSIST=0)");
     return 0;
@@ -884,6 +886,7 @@ int queue_cut_impl(ellhip_space* s, long long index) {
     int rc = do_cut(s, s->g_cur, s->d_qparams + index, none, 1, s->d_qstatus + index, s->d_qtsq + index);
     if (rc) return rc;
     s->shrink_pending = true;  // whether it really applies is decided on the device (DevState.apply)
+    s->scalars_stale = true;   // kappa / tsq now live on the device until the next read-back
     return 0;
 }
 
@@ -1014,6 +1017,23 @@ int ellhip_clone(const ellhip_space* src_c, ellhip_space** out) {
         ellhip_destroy(s);
         return fail(ELLHIP_E_HIP, "clone copy", e);
     }
+    // The device state is the truth (the source's host cache lags behind asynchronous queue cuts); the clone has no
+    // queue, so it does not inherit a halted one.
+    rc = read_back(s);
+    if (!rc) {
+        s->h_result->halted = 0;
+        s->h_result->halted_in = 0;
+        s->h_result->stop = STOP_NONE;
+        s->h_result->tol = -1.0;
+        s->h_result->niter = 0;
+        e = hipMemcpyAsync(s->d_st, s->h_result, sizeof(DevState), hipMemcpyHostToDevice, s->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
+        if (e != hipSuccess) rc = fail(ELLHIP_E_HIP, "clone state", e);
+    }
+    if (rc) {
+        ellhip_destroy(s);
+        return rc;
+    }
     if (src->defer > 1) {
         rc = ellhip_set_defer_depth(s, src->defer);
         if (rc) {
@@ -1132,8 +1152,26 @@ int ellhip_update(ellhip_space* s, int kind, const double* grad, double beta0, i
     return ellhip_update_end(s);
 }
 
-double ellhip_tsq(const ellhip_space* s) { return s ? s->tsq : 0.0; }
-double ellhip_kappa(const ellhip_space* s) { return s ? s->kappa : 0.0; }
+namespace {
+// kappa / tsq are cached on the host by every synchronous call; after asynchronous queue cuts they are fetched
+void refresh_scalars(const ellhip_space* s_c) {
+    if (!s_c->scalars_stale) return;
+    ellhip_space* s = const_cast<ellhip_space*>(s_c);
+    DeviceGuard guard(s->device);
+    (void)read_back(s);
+}
+}  // namespace
+
+double ellhip_tsq(const ellhip_space* s) {
+    if (!s) return 0.0;
+    refresh_scalars(s);
+    return s->tsq;
+}
+double ellhip_kappa(const ellhip_space* s) {
+    if (!s) return 0.0;
+    refresh_scalars(s);
+    return s->kappa;
+}
 int64_t ellhip_ndim(const ellhip_space* s) { return s ? s->n : 0; }
 
 int ellhip_get_xc(const ellhip_space* s, double* xc_out) {

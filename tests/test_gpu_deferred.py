@@ -345,3 +345,33 @@ def test_observers_between_prime_and_cut_keep_the_primed_gradient_valid(gpu, orc
     for sp in (a, b, d):
         assert np.max(np.abs(sp.mq - o.mq)) <= TOL * np.max(np.abs(o.mq))
         assert np.max(np.abs(sp.xc() - o.xc)) <= TOL * np.max(np.abs(o.xc))
+
+
+def test_observers_on_a_halted_queue_see_the_recorded_updates(gpu, orc):
+    """A queue halts at its first failing cut; the updates recorded before it belong to successful cuts and must
+    reach Q for whoever looks (get_mq, clone, a depth switch) even before ellhip_queue_results has been read."""
+    n, k = 64, 14
+    rng = np.random.default_rng(29)
+    grads = rng.standard_normal((k, n))
+    kinds = np.zeros(k, dtype=np.int32)
+    b0 = np.full(k, 0.01)
+    b0[10] = 1e9
+    g = gpu.Ell.new_with_scalar(1.0, np.zeros(n))
+    g.defer_depth = 8
+    o = orc.OracleEll.new_with_scalar(1.0, np.zeros(n))
+    for i in range(11):
+        o.update(0, grads[i], b0[i])
+    g.queue_upload(kinds, grads, b0)
+    g.queue_run(0, k, fused=True)
+    assert np.max(np.abs(g.mq - o.mq)) <= 1e-10 * np.max(np.abs(o.mq))     # 2 updates were still recorded
+    c = g.clone()
+    g.defer_depth = 1
+    st, _ = g.queue_results()
+    assert list(st) == [0] * 10 + [1] + [3] * 3
+    assert_state_close(g, o, what="halted queue, depth switched")
+    assert_state_close(c, o, what="clone of a halted queue")
+    for sp in (g, c):
+        assert int(sp.update_bias_cut((grads[11], 0.01))) == 0
+    assert o.update(0, grads[11], 0.01) == 0
+    assert_state_close(g, o, what="after recovery (depth 1)")
+    assert_state_close(c, o, what="after recovery (clone, depth 8)")
