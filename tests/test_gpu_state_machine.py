@@ -196,3 +196,115 @@ def test_random_walks_match_oracle_ellstable(gpu, orc, n, seed):
     """EllStable (src/ell_stable.rs) under the same drivers: the whole buffer -- diagonal, factor and the scratch
     triangle a failed cut rewrites -- stays equal to the oracle's."""
     Walk(gpu, orc, n, 9000 + 17 * seed + n, (1,), stable=True).run(24)
+
+
+class ShardWalk:
+    """The same idea for a row shard driven through ellalgo_rs_amd.sharded.ShardedEll (one rank, in process: the
+    exchange is the identity, every code path of the shard -- two-phase updates, queue in pieces, dropped primes --
+    is the multi-GPU one)."""
+
+    def __init__(self, gpu, orc, n, seed, symmetric):
+        from ellalgo_rs_amd.sharded import ShardedEll
+        self.n, self.symmetric = n, symmetric
+        self.rng = np.random.default_rng(seed)
+        xc0 = self.rng.standard_normal(n)
+        self.g = ShardedEll.new_with_scalar(3.0, xc0, rank=0, world=1, exchange=lambda gt, row0, nrows: None,
+                                            symmetric=symmetric)
+        self.o = orc.OracleEll.new_with_scalar(3.0, xc0)
+        self.depths = (8, 16) if symmetric else (1, 8)
+        self.i = 0
+        self.log = []
+
+    def check(self, what):
+        q, qo = self.g.mq_rows, self.o.mq
+        if self.symmetric:   # rows are current up to their diagonal only
+            q, qo = np.tril(q), np.tril(qo)
+        assert np.max(np.abs(q - qo)) <= TOL * np.max(np.abs(qo)), (what, self.log[-10:])
+        assert np.max(np.abs(self.g.xc() - self.o.xc)) <= TOL * np.max(np.abs(self.o.xc)), (what, self.log[-10:])
+        assert abs(self.g.kappa - self.o.kappa) <= TOL * abs(self.o.kappa), (what, self.log[-10:])
+
+    def observe(self):
+        r = int(self.rng.integers(0, 5))
+        self.log.append(f"observe{r}")
+        if r == 0:
+            self.g.flush()
+        elif r == 1:
+            self.check("observer")
+        elif r == 2:
+            self.g.set_defer_depth(int(self.rng.choice(self.depths)))
+
+    def op_update(self):
+        for _ in range(int(self.rng.integers(1, 6))):
+            g = _grad(self.rng, self.n)
+            kind, b0, b1 = mixed_cut(self.i, g, _tau(self.o, g), self.rng)
+            self.i += 1
+            so = self.o.update(kind, g, b0, b1)
+            assert int(self.g._update(kind, (g, beta_of(b0, b1)))) == so, self.log[-10:]
+            assert abs(self.g.tsq() - self.o.tsq) <= TOL * abs(self.o.tsq), self.log[-10:]
+
+    def op_queue(self):
+        m = int(self.rng.integers(3, 20))
+        fail_at = int(self.rng.integers(0, m)) if self.rng.random() < 0.25 else -1
+        kinds = np.zeros(m, dtype=np.int32)
+        grads = np.empty((m, self.n))
+        b0 = np.empty(m)
+        b1 = np.full(m, np.nan)
+        tau0 = None
+        for j in range(m):
+            g = _grad(self.rng, self.n)
+            if tau0 is None:
+                tau0 = _tau(self.o, g)
+            kind, c0, c1 = mixed_cut(self.i % 7, g, 0.5 * tau0, self.rng)
+            self.i += 1
+            if j == fail_at:
+                kind, c0, c1 = 0, 50.0 * tau0, None
+            kinds[j], grads[j], b0[j] = kind, g, c0
+            if c1 is not None:
+                b1[j] = c1
+        self.g.queue_upload(kinds, grads, b0, b1)
+        want, halted, done = [], False, 0
+
+        def catch_up(upto):
+            nonlocal halted, done
+            while done < upto and not halted:
+                so = self.o.update(int(kinds[done]), grads[done], b0[done], None if np.isnan(b1[done]) else b1[done])
+                want.append(so)
+                halted = so != 0
+                done += 1
+
+        pos = 0
+        while pos < m:
+            step = int(self.rng.integers(1, m - pos + 1))
+            self.g.queue_run(pos, step, fused=bool(self.rng.integers(0, 2)))
+            pos += step
+            if pos < m and self.rng.random() < 0.4:
+                catch_up(pos)
+                self.observe()
+        catch_up(m)
+        st, _ = self.g.queue_results()
+        assert list(st[:len(want)]) == want and all(s == 3 for s in st[len(want):]), (list(st), want, self.log[-10:])
+
+    def op_set_xc(self):
+        x = self.rng.standard_normal(self.n)
+        self.g.set_xc(x)
+        self.o.set_xc(x)
+
+    def op_depth(self):
+        self.g.set_defer_depth(int(self.rng.choice(self.depths)))
+
+    def run(self, nops):
+        ops = [self.op_update, self.op_queue, self.op_set_xc, self.op_depth]
+        weights = np.array([3.0, 4.0, 1.0, 2.0])
+        for k in range(nops):
+            op = ops[int(self.rng.choice(len(ops), p=weights / weights.sum()))]
+            self.log.append(op.__name__)
+            op()
+            if k % 3 == 2:
+                self.check(f"after op {k}")
+        self.check("final")
+
+
+@pytest.mark.parametrize("seed", range(5))
+@pytest.mark.parametrize("n,symmetric", [(96, False), (640, False), (640, True), (1024, True)])
+def test_random_walks_match_oracle_row_shard(gpu, orc, n, symmetric, seed):
+    ShardWalk(gpu, orc, n, 11000 + 13 * seed + n + int(symmetric), symmetric).run(24)
