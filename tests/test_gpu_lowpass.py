@@ -340,3 +340,33 @@ def test_cpp_host_mirror_three_drivers_agree_with_the_oracle_loop(gpu, orc):
         assert r["niter"] == nitero and r["has_x"] == (xo is not None), case
         assert rel_inf(np.array(r["x"]), xo) <= 1e-8
     assert res["feas_host"]["x"] == res["feas_device"]["x"]
+
+
+@pytest.mark.parametrize("depth", [8, 16])
+@pytest.mark.parametrize("max_iters", [16, 40, 70])
+def test_optim_loop_on_the_lower_triangle_schedule(gpu, orc, depth, max_iters, monkeypatch):
+    """The device-resident loop over the schedule a large handle runs by default (lower-triangle GEMV, recorded
+    updates applied 8 / 16 at a time; forced on at n = 640 here): same cut sequence and state as the oracle loop."""
+    monkeypatch.setenv("ELLHIP_SYMV_MIN_N", "512")
+    n = 640
+    c = CONSTANT_SETS["corrected"]
+    dev_o = gpu.LowpassOracle(n, *c)
+    g, _ = make_spaces(gpu, orc, "ell", n, 40.0, depth)
+    assert g.defer_depth == depth
+    cpu_o, o, xbo, nitero, gammao, last = cpu_lockstep(orc, "ell", n, c, 40.0, max_iters, False)
+    xb, niter, gamma = dev_o.cutting_plane_optim(g, c[4], max_iters, 1e-14)
+    assert niter == nitero == max_iters and last == 0
+    assert (xb is None) == (xbo is None)
+    sd, sc = dev_o.state(), cpu_o.state()
+    assert (sd["idx1"], sd["idx2"], sd["idx3"]) == (sc["idx1"], sc["idx2"], sc["idx3"])
+    tol = 1e-10 if max_iters <= 16 else max(1e-10, 100.0 * sensitivity(orc, "ell", n, c, 40.0, max_iters))
+    assert tol < 1e-5, tol
+    assert abs(gamma - gammao) <= tol * abs(gammao)
+    if xbo is not None:
+        assert rel_inf(xb, xbo) <= tol
+    assert_state_close(g, o, tol=tol, what=f"lower-triangle schedule depth {depth}, {max_iters} iterations")
+    # resume (the loop leaves recorded updates behind; the next call continues from them)
+    xb2, niter2, gamma2 = dev_o.cutting_plane_optim(g, gamma, 10, 1e-14)
+    xbo2, nitero2, gammao2, _ = cpu_o.cutting_plane_optim(o, gammao, 10, 1e-14)
+    assert niter2 == nitero2
+    assert_state_close(g, o, tol=max(tol, 1e-9), what="resumed")
