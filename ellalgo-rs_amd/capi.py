@@ -52,6 +52,33 @@ def lib_path() -> str:
     return _build.LIB_PATH
 
 
+def _one_hip_runtime_per_process() -> None:
+    """PyTorch-ROCm wheels bundle their own libamdhip64.so / libhsa-runtime64.so (same SONAMEs as /opt/rocm's) and
+    open them BY PATH.  If libellhip.so came first, it has already pulled in /opt/rocm's copies and a later
+    `import torch` (the multi-GPU path imports it for RCCL) adds a SECOND HIP + HSA runtime to the process -- two
+    runtimes driving one GPU, which showed up as a rare hang of the first torch call.  So in a Python process that
+    has PyTorch-ROCm installed, its runtime is opened first and libellhip.so binds to it (SONAME match), whichever
+    of the two is imported first.  (C / C++ / Rust hosts link /opt/rocm's runtime and never see torch.)
+    ELLHIP_SYSTEM_HIP=1 skips this."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules or os.environ.get("ELLHIP_SYSTEM_HIP", "0") == "1":
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        return
+    if spec is None or not spec.submodule_search_locations:
+        return
+    libdir = os.path.join(list(spec.submodule_search_locations)[0], "lib")
+    hip = os.path.join(libdir, "libamdhip64.so")
+    if os.path.exists(hip):
+        try:
+            C.CDLL(hip, mode=C.RTLD_GLOBAL)  # its RPATH ($ORIGIN) brings the bundled libhsa-runtime64.so along
+        except OSError:
+            pass  # not loadable here: fall back to the system runtime
+
+
 def load():
     """dlopen libellhip.so (built in-tree by ellalgo-rs_amd/build.py) and type its entry points."""
     global _lib
@@ -61,6 +88,7 @@ def load():
     if not os.path.exists(path):
         raise EllHipError(f"{path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                           "(the ellipsoid engine has no CPU fallback)")
+    _one_hip_runtime_per_process()
     L = C.CDLL(path, mode=C.RTLD_GLOBAL)
     vp, dbl, i32, i64 = C.c_void_p, C.c_double, C.c_int, C.c_int64
     sig = {

@@ -390,16 +390,44 @@ __global__ __launch_bounds__(256) void k_symv(const double* __restrict__ Q, long
 // y[i] = sum_{J <= i/SEG} rowpart[J][i] + sum_{I >= i/H} colpart[I][i]   (fixed order)
 // One workgroup per 128 columns: lane = column pair (16-byte loads, 1 KiB per wave-instruction), wave w
 // takes the strips I0 + w, I0 + w + 4, ...; the four wave sums are combined as ((w0+w1)+w2)+w3.
+//
+// NP > 0 (unsharded handle, deferred depth NP): the kernel also produces the dot products the scalar stage needs,
+// so that k_scalar_dot_def's launch disappears from the update's dependency chain:
+//     partial[b][0]     = sum over this workgroup's 128 columns of g[i] * y[i]
+//     partial[b][1 + j] = sum over the same columns of pend[j][i] * g[i]          (v_j . g, j < NP)
+// (per lane x-then-y, xor butterfly over the wave; k_scalar_apply_def adds the workgroups' values in index order)
+// and workgroup 0 takes the halted / kappa snapshots k_scalar_dot_def would have taken.
+template <int NP>
 __global__ __launch_bounds__(256) void k_symv_reduce(long long n, long long row0, long long nrows, long long seg,
                                                      const double* __restrict__ rowpart,
                                                      const double* __restrict__ colpart,
-                                                     double* __restrict__ y, const DevState* __restrict__ st) {
+                                                     double* __restrict__ y, DevState* __restrict__ st,
+                                                     const double* __restrict__ g, const double* __restrict__ pend,
+                                                     double* __restrict__ partial) {
     __shared__ double2_t part[4][64];
-    if (st->halted) return;
+    const int halted = st->halted;
+    if (NP > 0 && blockIdx.x == 0 && threadIdx.x == 0) {
+        st->halted_in = halted;
+        st->kappa_in = st->kappa;
+    }
+    if (halted) return;
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const long long i = (long long)blockIdx.x * 128 + 2 * lane;  // columns i, i+1 (n is even)
     const long long nstrips = (nrows + SYMV_H - 1) / SYMV_H;     // local strips
+    // operands of the dot products: requested first, so their latency hides behind the strip loop
+    constexpr int NPW = (NP + 3) / 4;  // pending vectors per wave (wave w takes j = w, w + 4, ...)
+    double2_t gi = {0.0, 0.0};
+    double2_t pv[NPW > 0 ? NPW : 1];
+    if (NP > 0) {
+        if (i < n) gi = *reinterpret_cast<const double2_t*>(g + i);
+#pragma unroll
+        for (int k = 0; k < NPW; ++k) {
+            const int j = wave + 4 * k;
+            pv[k] = (i < n && j < NP) ? *reinterpret_cast<const double2_t*>(pend + (long long)j * n + i)
+                                      : double2_t{0.0, 0.0};
+        }
+    }
     // A row shard yields its PARTIAL sums for every column (zeros right of its last row); the ranks' partial
     // vectors are added by the caller's all-reduce.  (row0 is a multiple of SYMV_H, so pairs never straddle.)
     double2_t s = {0.0, 0.0};
@@ -424,6 +452,7 @@ __global__ __launch_bounds__(256) void k_symv_reduce(long long n, long long row0
     }
     part[wave][lane] = s;
     __syncthreads();
+    double2_t yv = {0.0, 0.0};  // this lane's pair of y (wave 0 only)
     if (wave == 0 && i < n) {
         double2_t r = {0.0, 0.0};
         const bool local = i >= row0 && i < row0 + nrows;
@@ -436,6 +465,24 @@ __global__ __launch_bounds__(256) void k_symv_reduce(long long n, long long row0
         r.x += ((c0.x + c1.x) + c2.x) + c3.x;
         r.y += ((c0.y + c1.y) + c2.y) + c3.y;
         *reinterpret_cast<double2_t*>(y + i) = r;
+        if (NP > 0) yv = r;
+    }
+    if (NP > 0) {
+        double* out = partial + (long long)blockIdx.x * (NP + 1);
+        if (wave == 0) {
+            double sgy = gi.x * yv.x;
+            sgy += gi.y * yv.y;
+            sgy = wave_allreduce_sum(sgy);
+            if (lane == 0) out[0] = sgy;
+        }
+#pragma unroll
+        for (int k = 0; k < NPW; ++k) {
+            const int j = wave + 4 * k;
+            double sv = pv[k].x * gi.x;
+            sv += pv[k].y * gi.y;
+            sv = wave_allreduce_sum(sv);
+            if (lane == 0 && j < NP) out[1 + j] = sv;
+        }
     }
 }
 
@@ -818,7 +865,8 @@ __global__ __launch_bounds__(256) void k_scalar_apply_def(long long n, const dou
                                                           DevState* __restrict__ st, EllCalcDev calc,
                                                           const CutParams* __restrict__ cp_dev, CutParams cp_val,
                                                           int slot, int queue_mode, int* __restrict__ q_status,
-                                                          double* __restrict__ q_tsq) {
+                                                          double* __restrict__ q_tsq, int npart) {
+    // npart = number of partial-sum rows: scalar_groups(n) after k_scalar_dot_def, ceil(n / 128) after k_symv_reduce<NP>
     // `slot` = number of updates already pending = index of the (all-zero) slot this cut records into.
     // The host passes it: it equals the device's count as long as the queue has not halted, and a halted
     // queue ignores every later launch.
@@ -835,12 +883,29 @@ __global__ __launch_bounds__(256) void k_scalar_apply_def(long long n, const dou
         return;
     }
     __shared__ double dsum[NP + 1];
-    if (tid <= NP) {  // one thread per partial-sum column, workgroups in index order
-        const int G = scalar_groups(n);
-        double a = 0.0;
-        for (int b = 0; b < G; ++b) a += partial[(long long)b * (NP + 1) + tid];
-        dsum[tid] = a;
+    // Sum the npart rows of partial sums, per column: 8 interleaved running sums (thread group q takes rows q, q + 8,
+    // ...; four loads in flight per thread), combined in a fixed order -- one memory round trip instead of npart / 8.
+    __shared__ double psum[8][32];
+    {
+        const int c = tid & 31, q = tid >> 5;
+        if (c <= NP) {
+            double a = 0.0;
+            int b = q;
+            for (; b + 24 < npart; b += 32) {
+                double v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v[u] = partial[(long long)(b + 8 * u) * (NP + 1) + c];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) a += v[u];
+            }
+            for (; b < npart; b += 8) a += partial[(long long)b * (NP + 1) + c];
+            psum[q][c] = a;
+        }
     }
+    __syncthreads();
+    if (tid <= NP)
+        dsum[tid] = ((((((psum[0][tid] + psum[1][tid]) + psum[2][tid]) + psum[3][tid]) + psum[4][tid]) + psum[5][tid]) +
+                     psum[6][tid]) + psum[7][tid];
     __syncthreads();
     if (tid == 0) {
         double d[NP + 1];

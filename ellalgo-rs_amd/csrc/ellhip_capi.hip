@@ -90,6 +90,8 @@ struct ellhip_space {
     bool shard_symmetric = false;    // row shard whose GEMVs are partial symmetric sums (ellhip_set_shard_symmetric)
     int symv_seg = SYMV_SEG;         // segment width of the lower-triangle GEMV's tiles (see symv_alloc)
     int apply_lower = 1;             // with symv: apply passes touch the lower triangle only (ELLHIP_APPLY_LOWER)
+    int fuse_dots = 1;               // unsharded lower-triangle schedule: k_symv_reduce also yields the scalar stage's dot products (ELLHIP_FUSE_DOTS)
+    int dots_np = 0;                 // > 0: d_partial holds [ceil(n/128)][dots_np + 1] dot products of the primed gradient
     int apply_kernel = 1;            // depth 8: 1 = k_apply_lower (16-row tiles, 0.40 ms at n = 16384), 0 = k_sweep_apply<LOWER> (0.44 ms)
     bool upper_stale = false;        // strict upper triangle of Q is out of date (see flush_pending)
     int defer = 1;                   // 1 = shrink Q at every cut; MAXPEND = record and apply in batches
@@ -228,6 +230,7 @@ void pick_shape(ellhip_space* s) {
     s->symv_min_n = env_int("ELLHIP_SYMV_MIN_N", 8192);
     s->apply_lower = env_int("ELLHIP_APPLY_LOWER", 1);
     s->apply_kernel = env_int("ELLHIP_APPLY_KERNEL", 1);
+    s->fuse_dots = env_int("ELLHIP_FUSE_DOTS", 1);
     s->sh_apply = {4, 1, s->sh_fused.nt};  // 8 pending vectors per column step: more rows per workgroup amortise them
     s->sh_apply.rw = env_int("ELLHIP_APPLY_RW", s->sh_apply.rw);
     s->sh_apply.unr = env_int("ELLHIP_APPLY_UNR", s->sh_apply.unr);
@@ -508,16 +511,26 @@ int launch_symv(ellhip_space* s, const double* g_dev, double* y_out) {
         HIPCHK(hipGetLastError());
     }
     ProfScope ps(s, CLS_SYMV_REDUCE);
-    hipLaunchKernelGGL(k_symv_reduce, dim3((unsigned)((s->n + 127) / 128)), dim3(256), 0, s->stream, s->n, s->row0,
-                       s->nrows, (long long)seg, (const double*)s->d_rowpart, (const double*)s->d_colpart, y_out,
-                       s->d_st);
+    // unsharded: the reduction also yields the scalar stage's dot products (a shard's y is partial until the owner's
+    // all-reduce has run, so its dot products wait for k_scalar_dot_def)
+    const int np = (!s->sharded && s->fuse_dots) ? s->defer : 0;
+#define REDUCE_GO(NPV)                                                                                                \
+    hipLaunchKernelGGL(k_symv_reduce<NPV>, dim3((unsigned)((s->n + 127) / 128)), dim3(256), 0, s->stream, s->n, s->row0, \
+                       s->nrows, (long long)seg, (const double*)s->d_rowpart, (const double*)s->d_colpart, y_out,      \
+                       s->d_st, g_dev, (const double*)s->d_pend, s->d_partial)
+    if (np == 16) REDUCE_GO(16);
+    else if (np == 8) REDUCE_GO(8);
+    else REDUCE_GO(0);
+#undef REDUCE_GO
     HIPCHK(hipGetLastError());
+    s->dots_np = np;
     return 0;
 }
 
 // gt[slot] = Q * g  (Ell only; EllStable has no separate first pass)
 int do_prime(ellhip_space* s, const double* g_dev, int slot) {
     if (s->variant != ELLHIP_SPACE_ELL) return 0;
+    s->dots_np = 0;  // whatever d_partial held belonged to an earlier gradient
     if (symv_ok(s)) return launch_symv(s, g_dev, s->d_gt[slot]);
     if (s->shard_symmetric)
         return fail(ELLHIP_E_STATE, "symmetric row shard: only the deferred (depth 8) schedule is available");
@@ -536,15 +549,21 @@ int do_cut(ellhip_space* s, const double* g_dev, const CutParams* cp_dev, CutPar
     if (deferring(s)) {
         // gt currently holds y = Q_base * g; the stage corrects it with the pending updates and records the
         // cut as pending update number s->npend (optimistically counted; see ellhip_queue_results / callers)
+        // The dot products come from k_symv_reduce when THIS gradient was primed by it at the depth in force
+        // (dots_np); any other history (full-row GEMV, a shard, a depth or mode switch since) takes the separate launch.
+        const bool have_dots = s->dots_np == s->defer;
+        const int npart = have_dots ? (int)((s->n + 127) / 128) : (int)G;
 #define SCALAR_DEF(NPV)                                                                                           \
-    hipLaunchKernelGGL(k_scalar_dot_def<NPV>, dim3(G), dim3(256), 0, s->stream, s->n, g_dev, gt,                   \
-                       (const double*)s->d_pend, s->d_partial, s->d_st);                                          \
+    if (!have_dots)                                                                                               \
+        hipLaunchKernelGGL(k_scalar_dot_def<NPV>, dim3(G), dim3(256), 0, s->stream, s->n, g_dev, gt,               \
+                           (const double*)s->d_pend, s->d_partial, s->d_st);                                      \
     hipLaunchKernelGGL(k_scalar_apply_def<NPV>, dim3(G), dim3(256), 0, s->stream, s->n, gt, s->d_xc, s->d_pend,    \
                        s->d_cpend, (const double*)s->d_partial, s->d_st, calc, cp_dev, cp_val, s->npend, queue_mode, \
-                       qst, qtsq)
+                       qst, qtsq, npart)
         if (s->defer == 16) { SCALAR_DEF(16); } else { SCALAR_DEF(8); }
 #undef SCALAR_DEF
         HIPCHK(hipGetLastError());
+        s->dots_np = 0;  // consumed: the recorded vectors change with this cut
         s->npend += 1;
         return 0;
     }
@@ -697,7 +716,9 @@ int alloc_common(ellhip_space* s) {
         HIPCHK(hipMemsetAsync(s->d_gt_own[k], 0, vbytes, s->stream));
     }
     HIPCHK(hipMalloc(&s->d_st, sizeof(DevState)));
-    HIPCHK(hipMalloc(&s->d_partial, 64 * (MAXPEND + 1) * sizeof(double)));
+    // partial sums of the scalar stage: [scalar_groups(n) <= 64][MAXPEND + 1], or [ceil(n / 128)][depth + 1] when the
+    // lower-triangle GEMV's reduction produces them
+    HIPCHK(hipMalloc(&s->d_partial, (size_t)std::max<long long>(64, (n + 127) / 128) * (MAXPEND + 1) * sizeof(double)));
     if (s->variant == ELLHIP_SPACE_ELL) {
         HIPCHK(hipMalloc(&s->d_pend, (size_t)MAXPEND * vbytes));
         HIPCHK(hipMalloc(&s->d_cpend, MAXPEND * sizeof(double)));

@@ -74,3 +74,31 @@ def test_product_package_never_imports_the_oracle():
                 if re.search(r"(from|import)\s+oracle\b|ell_oracle\.h|oracle/lowpass_oracle|[\"<]lowpass_oracle\.h[\">]|libell_oracle", text):
                     offenders.append(os.path.join(base, f))
     assert not offenders, offenders
+
+
+def test_one_hip_runtime_whatever_the_import_order():
+    """PyTorch-ROCm bundles its own libamdhip64 / libhsa-runtime64 and opens them by path; the package makes sure
+    libellhip.so and torch share ONE runtime per process in either import order (a second runtime on the same GPU
+    showed up as a rare hang of the first torch call).  Checked in fresh interpreters through /proc/self/maps."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    prog = r"""
+import sys
+sys.path.insert(0, %r)
+order = sys.argv[1]
+if order == "torch-first":
+    import torch
+import ellalgo_rs_amd as pkg
+pkg.capi.load()
+if order == "lib-first":
+    import torch
+libs = sorted({l.split()[-1] for l in open("/proc/self/maps") if "libamdhip64" in l or "libhsa-runtime64" in l})
+print(";".join(libs))
+""" % root
+    for order in ("lib-first", "torch-first"):
+        out = subprocess.run([sys.executable, "-c", prog, order], capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr
+        libs = out.stdout.strip().split(";")
+        assert sum("libamdhip64" in l for l in libs) == 1, (order, libs)
+        assert sum("libhsa-runtime64" in l for l in libs) == 1, (order, libs)

@@ -92,7 +92,7 @@ int main(int argc, char** argv) {
                   }, {}});
     SYMVV(2, true, 0) SYMVV(2, true, 1) SYMVV(2, true, 2) SYMVV(4, true, 0) SYMVV(4, true, 1) SYMVV(2, false, 0)
     vs.push_back({"symv reduce", 0.0, [=](hipStream_t q, int) {
-                      hipLaunchKernelGGL(k_symv_reduce, dim3((unsigned)((n + 127) / 128)), dim3(256), 0, q, n, 0LL, n, (long long)SYMV_SEG, rowpart, colpart, gt2, st);
+                      hipLaunchKernelGGL(k_symv_reduce<0>, dim3((unsigned)((n + 127) / 128)), dim3(256), 0, q, n, 0LL, n, (long long)SYMV_SEG, rowpart, colpart, gt2, st, (const double*)nullptr, (const double*)nullptr, (double*)nullptr);
                   }, {}});
     hipEvent_t a, b;
     CK(hipEventCreate(&a));
