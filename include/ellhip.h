@@ -174,7 +174,7 @@ int ellhip_commit(ellhip_space *s, const double *next_grad);
  * unsharded handle's at depth 8 (both stay within the parity tolerance; shards agree with each other bit for
  * bit); a symmetric row shard (below) runs the lower-triangle schedule on its trapezoid.
  * depth = 16: the same with 16 recorded updates per apply pass (4.5 n^2 bytes per update); lower-triangle schedule
- * only (ELLHIP_E_INVALID otherwise).  The fastest schedule on MI355X where it exists (4100 vs 3800 updates/s at
+ * only (ELLHIP_E_INVALID otherwise).  The fastest schedule on MI355X where it exists (4300 vs 3960 updates/s at
  * n = 16384) and bench.py's default there. */
 int ellhip_set_defer_depth(ellhip_space *s, int depth);
 int ellhip_defer_depth(const ellhip_space *s);
