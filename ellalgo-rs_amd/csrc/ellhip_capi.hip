@@ -859,10 +859,15 @@ int create_impl(ellhip_space** out, int variant, long long n, long long row0, lo
     // n >= 8192: 4.5 n^2 instead of 24 n^2 bytes per update, results within the parity tolerance of depth 1, Q made
     // current for every observer), otherwise the reference's data flow (depth 1).  ELLHIP_AUTO_DEFER=0 keeps depth 1
     // everywhere; ellhip_set_defer_depth overrides either way.  Row shards stay at 1 until their owner chooses.
-    if (variant == ELLHIP_SPACE_ELL && !sharded && env_int("ELLHIP_AUTO_DEFER", 1) && s->symv && s->apply_lower &&
-        (n % 2) == 0 && n >= s->symv_min_n) {
-        rc = ellhip_set_defer_depth(s, 16);
-        if (rc) return bail(rc);
+    // Between 3072 and that size (and for odd n) depth 8 with full-row GEMVs is the faster one, for synchronous calls
+    // and for queues alike (tools/depth_sweep.py: n = 4096: 15 800 vs 10 400 calls/s; below ~3000 depth 1 wins).
+    if (variant == ELLHIP_SPACE_ELL && !sharded && env_int("ELLHIP_AUTO_DEFER", 1)) {
+        const bool lower = s->symv && s->apply_lower && (n % 2) == 0 && n >= s->symv_min_n;
+        const int depth = lower ? 16 : (n >= 3072 ? 8 : 1);
+        if (depth != 1) {
+            rc = ellhip_set_defer_depth(s, depth);
+            if (rc) return bail(rc);
+        }
     }
     *out = s;
     return 0;

@@ -235,7 +235,8 @@ class Ell(_SpaceBase):
     @property
     def defer_depth(self) -> int:
         """1 = shrink Q at every cut (reference data flow); 8 / 16 = record cuts and apply them in batches.
-        A new handle with even n >= 8192 starts at 16 (include/ellhip.h, "deferred shrink"), anything else at 1."""
+        A new handle with even n >= 8192 starts at 16, another one with n >= 3072 at 8 (include/ellhip.h, "deferred
+        shrink"), anything smaller at 1."""
         return self._lib.ellhip_defer_depth(self._h)
 
     @defer_depth.setter

@@ -155,9 +155,10 @@ int ellhip_commit(ellhip_space *s, const double *next_grad);
 
 /* ---- deferred shrink: 8 n^2 (1 + 1/8) bytes per update (Ell) -----------------------------------
  * depth = 1: Q is rewritten at every successful cut, exactly as src/ell.rs:117-128 does.  This is what a new handle
- * starts with, EXCEPT an unsharded Ell handle with even n >= 8192, which starts at depth 16 (the fastest schedule
- * there; same results to the parity tolerance).  ELLHIP_AUTO_DEFER=0 in the environment makes every handle start at
- * depth 1; ellhip_set_defer_depth(h, 1) does it for one handle.
+ * starts with, EXCEPT an unsharded Ell handle with n >= 3072: it starts at depth 16 when n is even and >= 8192 and
+ * at depth 8 otherwise (the fastest schedules at those sizes; same results to the parity tolerance).
+ * ELLHIP_AUTO_DEFER=0 in the environment makes every handle start at depth 1; ellhip_set_defer_depth(h, 1) does
+ * it for one handle.
  * depth = 8: successful cuts are RECORDED as pairs (sigma/omega, gt); the next GEMV reads the unchanged
  * matrix (a read-only pass) and is corrected with the recorded pairs,
  *     gt = Q_base*g - sum_j c_j (v_j.g) v_j ,   omega = g.(Q_base*g) - sum_j c_j (v_j.g)^2 ,

@@ -259,10 +259,12 @@ def test_apply_kernels_agree_bit_for_bit(gpu, monkeypatch):
 
 
 def test_default_depth_of_new_handles(gpu, monkeypatch):
-    """ellhip_create: depth 16 wherever the lower-triangle schedule exists (unsharded Ell, even n >= 8192), else the
-    reference's data flow; ELLHIP_AUTO_DEFER=0 keeps depth 1 everywhere; clones inherit; the setter overrides."""
-    assert gpu.Ell.new_with_scalar(1.0, np.zeros(4096)).defer_depth == 1
-    assert gpu.Ell.new_with_scalar(1.0, np.zeros(8191)).defer_depth == 1      # odd n: no 16-byte pairs
+    """ellhip_create: depth 16 wherever the lower-triangle schedule exists (unsharded Ell, even n >= 8192), depth 8
+    for other n >= 3072, else the reference's data flow; ELLHIP_AUTO_DEFER=0 keeps depth 1 everywhere; clones
+    inherit; the setter overrides."""
+    assert gpu.Ell.new_with_scalar(1.0, np.zeros(2048)).defer_depth == 1
+    assert gpu.Ell.new_with_scalar(1.0, np.zeros(4096)).defer_depth == 8      # 3072 <= n < 8192: full-row GEMVs, depth 8
+    assert gpu.Ell.new_with_scalar(1.0, np.zeros(8191)).defer_depth == 8      # odd n: no 16-byte pairs, no lower schedule
     e = gpu.Ell.new_with_scalar(1.0, np.zeros(8192))
     assert e.defer_depth == 16 and e.clone().defer_depth == 16
     e.defer_depth = 1
