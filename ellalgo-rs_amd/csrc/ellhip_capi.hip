@@ -378,8 +378,8 @@ int ellstable_issue(ellhip_space* s, const double* g_dev, const CutParams* cp_de
     double* gg = z + n;
     double* q = gg + n;
     double* beta2 = q + n;
-    double* dscale = beta2 + n;
-    double* qpub = dscale + n;  // publish buffer of the persistent backward solve (data-as-flag hand-off)
+    double* qpub = beta2 + n;            // publish buffer of the persistent backward solve (data-as-flag hand-off)
+    double* cpre = qpub + n + (n & 1);   // chunk prefixes of the mid stage (ST_MID_T + 1 doubles)
     hipStream_t st = s->stream;
     // One launch per solve when every 128-column strip can have its own resident workgroup; otherwise
     // (n > 128 * 256) one launch per block.
@@ -404,11 +404,11 @@ int ellstable_issue(ellhip_space* s, const double* g_dev, const CutParams* cp_de
     {
         ProfScope ps(s, CLS_SCALAR);
         EllCalcDev calc = EllCalcDev::make(n, s->use_parallel_cut);
-        hipLaunchKernelGGL(k_st_mid, dim3(1), dim3(1024), 0, st, s->d_Q, ld, n, z, gg, q, beta2, dscale, s->d_st,
-                           calc, cp_dev, cp_val, queue_mode, qst, qtsq, persist ? w : (double*)nullptr,
-                           persist ? qpub : (double*)nullptr);
-        hipLaunchKernelGGL(k_st_diag, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, s->d_Q, ld, n,
-                           (const double*)dscale, s->d_st);
+        hipLaunchKernelGGL(k_st_mid, dim3(1), dim3(ST_MID_T), 0, st, n, (const double*)gg, cpre, s->d_st, calc, cp_dev,
+                           cp_val, queue_mode, qst, qtsq);
+        hipLaunchKernelGGL(k_st_post, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, s->d_Q, ld, n,
+                           (const double*)z, (const double*)gg, (const double*)cpre, q, beta2,
+                           persist ? qpub : (double*)nullptr, (const DevState*)s->d_st);
         HIPCHK(hipGetLastError());
     }
     // The factor update (reads S, rewrites U) and the backward solve (reads S, writes q) are independent.
@@ -735,7 +735,7 @@ int alloc_common(ellhip_space* s) {
         HIPCHK(hipEventCreateWithFlags(&s->ev_join, hipEventDisableTiming));
     }
     if (s->variant == ELLHIP_SPACE_ELL_STABLE) {
-        HIPCHK(hipMalloc(&s->d_work, vbytes * 7));
+        HIPCHK(hipMalloc(&s->d_work, vbytes * 7 + (ST_MID_T + 8) * sizeof(double)));  // w z gg q beta2 qpub (+1 spare) | cpre
     }
     HIPCHK(hipHostMalloc(&s->h_result, sizeof(DevState), hipHostMallocDefault));
     return 0;

@@ -168,7 +168,7 @@ __device__ __forceinline__ void st_raise_flag(int* flag, int epoch) {  // called
 // Data-as-flag form of the hand-off (persistent BACKWARD solve): the publish buffer qpub holds ST_SENTINEL (a
 // signalling-NaN payload no arithmetic produces) until its owner stores the value, so a consumer polls the VALUE
 // it needs and the separate flag round trip (store flag -> poll flag -> barrier -> load payload) disappears
-// (backward solve 1.16 -> 1.07 ms at n = 16384).  k_st_mid re-arms qpub before every backward solve.
+// (backward solve 1.16 -> 1.07 ms at n = 16384).  k_st_post re-arms qpub before every backward solve.
 constexpr unsigned long long ST_SENTINEL_BITS = 0x7FF4DEADC0DEBEEFull;
 __device__ __forceinline__ double st_sentinel() { return __longlong_as_double((long long)ST_SENTINEL_BITS); }
 __device__ __forceinline__ bool st_poll_value(const double* p, double& out) {
@@ -480,20 +480,22 @@ __global__ __launch_bounds__(256) void k_st_fwd_persist(double* __restrict__ M, 
 
 // ---------------------------------------------------------------------------------- mid -------
 // omega, tsq, EllCalc, kappa; prefix sums t_j; beta2_j; diagonal rescale; q <- z.
-// One workgroup of 1024 threads.  src/ell_stable.rs:78-90,107-113,120-122.
-__global__ __launch_bounds__(1024) void k_st_mid(double* __restrict__ M, long long ld, long long n,
-                                                 const double* __restrict__ z, const double* __restrict__ gg,
-                                                 double* __restrict__ q, double* __restrict__ beta2,
-                                                 double* __restrict__ dscale,
-                                                 DevState* __restrict__ st, EllCalcDev calc,
-                                                 const CutParams* __restrict__ cp_dev, CutParams cp_val,
-                                                 int queue_mode, int* __restrict__ q_status,
-                                                 double* __restrict__ q_tsq, double* __restrict__ w_rearm,
-                                                 double* __restrict__ qpub_rearm) {
+// src/ell_stable.rs:78-90,107-113,120-122.  Two launches:
+//   k_st_mid   one workgroup of 1024 threads: thread t sums its contiguous chunk of gg (m = ceil(n/1024) elements),
+//              the chunk totals are scanned, thread 0 runs the coefficient stage; the exclusive prefix of every
+//              chunk and t_0 = omega/mu go to `cpre` (1025 doubles)
+//   k_st_post  one thread per element, spread over the chip: t_{j-1} = (cpre[1024] + cpre[chunk]) + gg[lo] + ... in
+//              the same left-to-right order as a sequential walk of the chunk, then beta2_j, d_j *= t_{j-1}/t_j,
+//              q_j = z_j -- the two divisions per element no longer sit in one workgroup (mid stage 77 -> 25 us at
+//              n = 16384); it also re-arms the publish buffer of the persistent backward solve.
+constexpr int ST_MID_T = 1024;
+
+__global__ __launch_bounds__(ST_MID_T) void k_st_mid(long long n, const double* __restrict__ gg,
+                                                     double* __restrict__ cpre, DevState* __restrict__ st,
+                                                     EllCalcDev calc, const CutParams* __restrict__ cp_dev,
+                                                     CutParams cp_val, int queue_mode, int* __restrict__ q_status,
+                                                     double* __restrict__ q_tsq) {
     __shared__ double red[16];
-    __shared__ double tot[1024];
-    __shared__ double bc[2];
-    __shared__ int bc_status;
     const int tid = threadIdx.x;
     if (st->halted) {
         if (tid == 0) {
@@ -505,14 +507,8 @@ __global__ __launch_bounds__(1024) void k_st_mid(double* __restrict__ M, long lo
         }
         return;
     }
-    // persistent solves: re-arm the publish buffer of the backward solve that follows
-    (void)w_rearm;
-    if (qpub_rearm) {
-        const double sent = st_sentinel();
-        for (long long i = tid; i < n; i += 1024) qpub_rearm[i] = sent;
-    }
     // chunked sums: thread t owns the contiguous chunk [t*m, (t+1)*m)
-    const long long m = (n + 1023) / 1024;
+    const long long m = (n + ST_MID_T - 1) / ST_MID_T;
     const long long lo = (long long)tid * m;
     const long long hi = (lo + m < n) ? lo + m : n;
     double s = 0.0;
@@ -529,7 +525,7 @@ __global__ __launch_bounds__(1024) void k_st_mid(double* __restrict__ M, long lo
     __syncthreads();
     double wave_off = 0.0;
     for (int k = 0; k < (tid >> 6); ++k) wave_off += red[k];
-    tot[tid] = wave_off + (x - s);  // exclusive prefix of this thread's chunk
+    cpre[tid] = wave_off + (x - s);  // exclusive prefix of this thread's chunk
     if (tid == 0) {
         double omega = 0.0;
 #pragma unroll
@@ -557,28 +553,30 @@ __global__ __launch_bounds__(1024) void k_st_mid(double* __restrict__ M, long lo
             *q_status = status;
             *q_tsq = tsq;
         }
-        bc[0] = t0;
-        bc_status = status;
-    }
-    __syncthreads();
-    if (bc_status != ST_SUCCESS) return;
-    double told = bc[0] + tot[tid];  // t_{lo-1}
-    for (long long j = lo; j < hi; ++j) {
-        const double tnew = told + gg[j];      // :111
-        beta2[j] = z[j] / tnew;                // :112
-        dscale[j] = told / tnew;               // :113 / :121, applied by k_st_diag
-        q[j] = z[j];                           // :93
-        told = tnew;
+        cpre[ST_MID_T] = t0;
     }
 }
 
-// d[j] *= t_{j-1}/t_j  (src/ell_stable.rs:113,121): one strided element per thread, spread over the chip.
-__global__ __launch_bounds__(256) void k_st_diag(double* __restrict__ M, long long ld, long long n,
-                                                 const double* __restrict__ dscale,
+// One thread per element j: t_{j-1}, t_j, beta2_j, d_j *= t_{j-1}/t_j (src/ell_stable.rs:111-113,120-121), q_j = z_j
+// (:93).  qpub_rearm (persistent backward solve): every entry back to the sentinel before each solve that runs.
+__global__ __launch_bounds__(256) void k_st_post(double* __restrict__ M, long long ld, long long n,
+                                                 const double* __restrict__ z, const double* __restrict__ gg,
+                                                 const double* __restrict__ cpre, double* __restrict__ q,
+                                                 double* __restrict__ beta2, double* __restrict__ qpub_rearm,
                                                  const DevState* __restrict__ st) {
-    if (!st->apply) return;
     const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j < n) M[j * ld + j] = M[j * ld + j] * dscale[j];
+    if (j >= n) return;
+    if (!st->apply) return;  // failed cut / halted loop: nothing below runs, and neither does the backward solve
+    if (qpub_rearm) qpub_rearm[j] = st_sentinel();
+    const long long m = (n + ST_MID_T - 1) / ST_MID_T;
+    const long long chunk = j / m, lo = chunk * m;
+    double told = cpre[ST_MID_T] + cpre[chunk];  // t_{lo-1}
+    for (long long i = lo; i < j; ++i) told = told + gg[i];  // :111, left to right inside the chunk
+    const double tnew = told + gg[j];       // :111
+    const double zj = z[j];
+    beta2[j] = zj / tnew;                   // :112
+    M[j * ld + j] = M[j * ld + j] * (told / tnew);  // :113 / :121
+    q[j] = zj;                              // :93
 }
 
 // ------------------------------------------------------------------------------ backward ------
