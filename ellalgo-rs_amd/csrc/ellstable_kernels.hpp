@@ -104,6 +104,34 @@ __device__ __forceinline__ double st_fwd_half_chain(double* __restrict__ piece, 
     for (int j = 0; j < SH; ++j) piece[lane * BLK_PITCH + j] = u[j];
     return wi;
 }
+// The same chain on a column already held in registers (u[j] = piece[j][lane]); products stay in u.
+__device__ __forceinline__ double st_fwd_chain_regs(double (&u)[SH], double wi) {
+    const int lane = threadIdx.x & 63;
+    double t = wi;
+#pragma unroll
+    for (int j = 0; j < SH; ++j) {
+        const double wj = lane_bcast(t, j);  // lane j's value is final after step j-1
+        const double v = u[j] * wj;          // :65
+        u[j] = v;                            // :66 (meaningful for j < lane only)
+        t = wi - v;                          // :67
+        wi = (lane > j) ? t : wi;
+    }
+    return wi;
+}
+// Rows A (final; wa[j] = w[A0+j] in LDS, read as broadcasts) applied to the 64 columns of B held in registers.
+__device__ __forceinline__ double st_fwd_mini_regs(double (&u)[SH], const double* __restrict__ wa, double wb) {
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;  // four interleaved partial sums (16 steps deep instead of 64)
+#pragma unroll
+    for (int j = 0; j < SH; j += 4) {
+        const double v0 = u[j] * wa[j];
+        const double v1 = u[j + 1] * wa[j + 1];
+        const double v2 = u[j + 2] * wa[j + 2];
+        const double v3 = u[j + 3] * wa[j + 3];
+        u[j] = v0, u[j + 1] = v1, u[j + 2] = v2, u[j + 3] = v3;
+        a0 += v0, a1 += v1, a2 += v2, a3 += v3;
+    }
+    return wb - ((a0 + a1) + (a2 + a3));
+}
 // Rows A (final, lane j holds w[A0+j]) applied to the 64 columns of B: products left in piece[lane][j].
 __device__ __forceinline__ double st_fwd_mini_chain(double* __restrict__ piece, double wa, double wb) {
     const int lane = threadIdx.x & 63;
@@ -197,45 +225,77 @@ __device__ __forceinline__ bool st_wait_flag(const int* flag, int epoch) {
 //   lds: 3 * 64 * BLK_PITCH doubles; wpart[128]: partial w of the block's columns (LDS).
 //   PUBLISH: w is handed to other workgroups inside this launch (write-through stores + flag) before the
 //   parked products are written back.
+// The length-128 dependency chain is split over three waves so that only the chain steps themselves are serial:
+//   wave 0  column loads of AA, chain A                      | wave 1: column loads of AB | wave 2: column loads of BB
+//   -- barrier --   (w_A in LDS)
+//   wave 0  products of AA back to LDS, z / gg of A          | wave 1: mini panel A -> B (64 x 64, tree-summed)
+//   -- barrier --   (partial w_B in LDS)
+//   wave 1  products of AB back to LDS                       | wave 2: chain B, publish all 128 values + flag, z / gg of B
+// (one wave doing everything in sequence spent ~0.7 us of its ~4 us per block on the two later column loads and the
+// two earlier product stores; the arithmetic and its order are unchanged, so are the bits).
 template <bool PUBLISH>
 __device__ __forceinline__ void st_fwd_diag_block(double* __restrict__ M, long long ld, long long n, long long J0,
                                                   const Blk3& blk, double dreg, double* __restrict__ lds,
                                                   double* __restrict__ dlds, const double* __restrict__ wpart,
                                                   double* __restrict__ w, double* __restrict__ z,
-                                                  double* __restrict__ gg, int* flag = nullptr, int epoch = 0) {
+                                                  double* __restrict__ gg, int* flag = nullptr, int epoch = 0,
+                                                  bool parked = false) {
+    __shared__ double wab[2][SH];  // [0]: final w of half A; [1]: partial w of half B after the mini panel
     double* pAA = lds;
     double* pAB = lds + SH * BLK_PITCH;
     double* pBB = lds + 2 * SH * BLK_PITCH;
-    st_park_piece(pAA, blk.aa);
-    st_park_piece(pAB, blk.ab);
-    st_park_piece(pBB, blk.bb);
-    if (threadIdx.x < SB) dlds[threadIdx.x] = dreg;
-    __syncthreads();
+    if (!parked) {  // (the persistent solve parks while it waits for the previous block: st_fwd_park)
+        st_park_piece(pAA, blk.aa);
+        st_park_piece(pAB, blk.ab);
+        st_park_piece(pBB, blk.bb);
+        if (threadIdx.x < SB) dlds[threadIdx.x] = dreg;
+        __syncthreads();
+    }
     const bool has_b = J0 + SH < n;
-    if ((threadIdx.x >> 6) == 0) {
-        const int lane = threadIdx.x;
-        double wA = st_fwd_half_chain(pAA, wpart[lane]);
-        {
-            const long long c = J0 + lane;
-            if (c < n) {
-                const double zi = wA * dlds[lane];  // :74
-                if (PUBLISH) st_publish_store(w + c, wA); else w[c] = wA;
-                z[c] = zi;
-                gg[c] = zi * wA;  // :81
-            }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    double* mine = wave == 0 ? pAA : (wave == 1 ? pAB : pBB);
+    const bool busy = wave == 0 || (has_b && wave <= 2);
+    double u[SH];
+    if (busy) {
+#pragma unroll
+        for (int j = 0; j < SH; ++j) u[j] = mine[j * BLK_PITCH + lane];
+    }
+    if (wave == 0) wab[0][lane] = st_fwd_chain_regs(u, wpart[lane]);
+    __syncthreads();
+    if (wave == 0) {
+        const double wA = wab[0][lane];
+        const long long c = J0 + lane;
+        if (c < n) {
+            const double zi = wA * dlds[lane];  // :74
+            if (!PUBLISH) w[c] = wA;
+            else if (!has_b) st_publish_store(w + c, wA);
+            z[c] = zi;
+            gg[c] = zi * wA;  // :81
         }
-        if (has_b) {
-            double wB = st_fwd_mini_chain(pAB, wA, wpart[lane + SH]);
-            wB = st_fwd_half_chain(pBB, wB);
-            const long long c = J0 + SH + lane;
-            if (c < n) {
-                const double zi = wB * dlds[lane + SH];
-                if (PUBLISH) st_publish_store(w + c, wB); else w[c] = wB;
-                z[c] = zi;
-                gg[c] = zi * wB;
-            }
+        if (PUBLISH && !has_b) st_raise_flag(flag, epoch);
+    } else if (wave == 1 && has_b) {
+        wab[1][lane] = st_fwd_mini_regs(u, wab[0], wpart[lane + SH]);
+    }
+    __syncthreads();
+    if (wave == 2 && has_b) {
+        const double wB = st_fwd_chain_regs(u, wab[1][lane]);
+        const long long c = J0 + SH + lane;
+        if (PUBLISH) {  // all 128 values by this wave, then its flag store (half A always lies inside the matrix here)
+            st_publish_store(w + J0 + lane, wab[0][lane]);
+            if (c < n) st_publish_store(w + c, wB);
+            st_raise_flag(flag, epoch);
+        } else if (c < n) {
+            w[c] = wB;
         }
-        if (PUBLISH) st_raise_flag(flag, epoch);
+        if (c < n) {
+            const double zi = wB * dlds[lane + SH];
+            z[c] = zi;
+            gg[c] = zi * wB;
+        }
+    }
+    if (busy) {  // parked products: piece[lane][j] (transposed in place; every lane read its whole column long ago)
+#pragma unroll
+        for (int j = 0; j < SH; ++j) mine[lane * BLK_PITCH + j] = u[j];
     }
     __syncthreads();
     st_store_piece(M, ld, n, J0, J0, pAA, true);                       // S[A][A], strict lower
@@ -243,6 +303,14 @@ __device__ __forceinline__ void st_fwd_diag_block(double* __restrict__ M, long l
         st_store_piece(M, ld, n, J0 + SH, J0, pAB, false);             // S[B][A], full
         st_store_piece(M, ld, n, J0 + SH, J0 + SH, pBB, true);         // S[B][B], strict lower
     }
+}
+
+__device__ __forceinline__ void st_fwd_park(const Blk3& blk, double dreg, double* __restrict__ lds,
+                                            double* __restrict__ dlds) {
+    st_park_piece(lds, blk.aa);
+    st_park_piece(lds + SH * BLK_PITCH, blk.ab);
+    st_park_piece(lds + 2 * SH * BLK_PITCH, blk.bb);
+    if (threadIdx.x < SB) dlds[threadIdx.x] = dreg;
 }
 
 __device__ __forceinline__ void st_prefetch_block(const double* __restrict__ M, long long ld, long long n,
@@ -432,7 +500,12 @@ __global__ __launch_bounds__(256) void k_st_fwd_persist(double* __restrict__ M, 
 #pragma unroll
             for (int r = 0; r < 16; ++r) u[h][r] = *reinterpret_cast<const double2_t*>(M + (r0 + r) * ld + cl);
         }
-        if (kb == sblk - 1) st_prefetch_block(M, ld, n, c0, blk, dreg);
+        if (kb == sblk - 1) {
+            // the own diagonal block: fetched AND parked in LDS while the previous block's solve is still running
+            // (`lds` is free: the last row block's products are written back after the own solve)
+            st_prefetch_block(M, ld, n, c0, blk, dreg);
+            st_fwd_park(blk, dreg, lds, dlds);
+        }
         // (the data-as-flag hand-off of the backward solve was tried here too: 255 workgroups x 128 lanes polling the
         // values slowed the publishing wave down, forward solve 1.25 -> 1.34 ms; one polling lane per workgroup it is)
         if (threadIdx.x == 0) ok = st_wait_flag(flags + kb, epoch) ? 1 : 0;
@@ -471,7 +544,7 @@ __global__ __launch_bounds__(256) void k_st_fwd_persist(double* __restrict__ M, 
         }
     }
     __syncthreads();
-    st_fwd_diag_block<true>(M, ld, n, c0, blk, dreg, lds, dlds, wstrip, w, z, gg, flags + sblk, epoch);
+    st_fwd_diag_block<true>(M, ld, n, c0, blk, dreg, lds, dlds, wstrip, w, z, gg, flags + sblk, epoch, sblk > 0);
     if (sblk > 0) {
         __syncthreads();  // the parked pieces have been written back: `lds` is free for the transposes
         write_back((sblk - 1) * SB, true);
@@ -630,31 +703,103 @@ __device__ __forceinline__ void st_prefetch_block_bwd(const double* __restrict__
     st_load_piece(M, ld, n, J0, J0, blk.aa);
 }
 
-// Whole 128-wide diagonal block at J0 (upper half first), called by all 256 threads.
+// Register forms (sv[j] = piece[j][lane] already loaded).  nvalid = rows of the half that exist (64 except in the
+// ragged last block).  Full halves take the select off the dependency chain, as the forward chain does: the
+// broadcast for step j-1 reads the unselected difference of step j (lane j-1 is an active lane of step j).
+__device__ __forceinline__ double st_bwd_chain_regs(const double (&sv)[SH], int nvalid, double qi) {
+    const int lane = threadIdx.x & 63;
+    if (nvalid == SH) {
+        double t = qi;
+#pragma unroll
+        for (int j = SH - 1; j >= 1; --j) {
+            const double qj = lane_bcast(t, j);
+            const double v = sv[j] * qj;
+            t = qi - v;
+            qi = (lane < j) ? t : qi;
+        }
+        return qi;
+    }
+#pragma unroll
+    for (int j = SH - 1; j >= 1; --j) {
+        const double qj = lane_bcast(qi, j);
+        const double v = sv[j] * qj;
+        qi = (lane < j && j < nvalid) ? qi - v : qi;
+    }
+    return qi;
+}
+__device__ __forceinline__ double st_bwd_mini_regs(const double (&sv)[SH], const double* __restrict__ qb, int nvalid,
+                                                   double qa) {
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;  // four interleaved partial sums, not a 64-deep chain
+#pragma unroll
+    for (int j = 0; j < SH; j += 4) {
+        const double v0 = sv[j] * qb[j];
+        const double v1 = sv[j + 1] * qb[j + 1];
+        const double v2 = sv[j + 2] * qb[j + 2];
+        const double v3 = sv[j + 3] * qb[j + 3];
+        a0 += (j < nvalid) ? v0 : 0.0;
+        a1 += (j + 1 < nvalid) ? v1 : 0.0;
+        a2 += (j + 2 < nvalid) ? v2 : 0.0;
+        a3 += (j + 3 < nvalid) ? v3 : 0.0;
+    }
+    return qa - ((a0 + a1) + (a2 + a3));
+}
+
+// Whole 128-wide diagonal block at J0 (upper half first), called by all 256 threads.  Like the forward block the
+// chain is spread over three waves so that the column loads of the later pieces overlap the earlier chain:
+//   wave 0: BB columns, chain B | wave 1: BA columns | wave 2: AA columns   -- barrier (q_B in LDS) --
+//   wave 0: publishes q_B       | wave 1: mini panel B -> A                 -- barrier (partial q_A in LDS) --
+//   wave 2: chain A, publishes q_A.     Same arithmetic in the same order as the one-wave form.
 template <bool PUBLISH>
 __device__ __forceinline__ void st_bwd_diag_block(long long n, long long J0, const Blk3b& blk,
                                                   double* __restrict__ lds, const double* __restrict__ qpart,
-                                                  double* __restrict__ q, double* __restrict__ qpub = nullptr) {
+                                                  double* __restrict__ q, double* __restrict__ qpub = nullptr,
+                                                  bool parked = false) {
+    __shared__ double qab[2][SH];  // [0]: final q of half B; [1]: partial q of half A after the mini panel
     double* pBB = lds;
     double* pBA = lds + SH * BLK_PITCH;
     double* pAA = lds + 2 * SH * BLK_PITCH;
-    st_park_piece(pBB, blk.bb);
-    st_park_piece(pBA, blk.ba);
-    st_park_piece(pAA, blk.aa);
+    if (!parked) {  // (the persistent solve parks while it waits for the previous block's values)
+        st_park_piece(pBB, blk.bb);
+        st_park_piece(pBA, blk.ba);
+        st_park_piece(pAA, blk.aa);
+        __syncthreads();
+    }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const bool has_b = J0 + SH < n;
+    if (!has_b) {  // ragged last block with one half only: one wave, one chain
+        if (wave != 0) return;
+        double sv[SH];
+#pragma unroll
+        for (int j = 0; j < SH; ++j) sv[j] = pAA[j * BLK_PITCH + lane];
+        const int nvalid = (n - J0 < SH) ? (int)(n - J0) : SH;
+        const double qA = st_bwd_chain_regs(sv, nvalid, qpart[lane]);
+        if (J0 + lane < n) {
+            q[J0 + lane] = qA;
+            if (PUBLISH) st_publish_store(qpub + J0 + lane, qA);
+        }
+        return;
+    }
+    const int nvalid_b = (n - (J0 + SH) < SH) ? (int)(n - (J0 + SH)) : SH;
+    const double* mine = wave == 0 ? pBB : (wave == 1 ? pBA : pAA);
+    double sv[SH];
+    if (wave <= 2) {
+#pragma unroll
+        for (int j = 0; j < SH; ++j) sv[j] = mine[j * BLK_PITCH + lane];  // S[..+j][..+lane]
+    }
+    if (wave == 0) qab[0][lane] = st_bwd_chain_regs(sv, nvalid_b, qpart[lane + SH]);
     __syncthreads();
-    if ((threadIdx.x >> 6) != 0) return;
-    const int lane = threadIdx.x;
-    double qA = qpart[lane];
-    if (J0 + SH < n) {
-        double qB = st_bwd_half_chain(pBB, J0 + SH, n, qpart[lane + SH]);
+    if (wave == 0) {
         if (J0 + SH + lane < n) {
+            const double qB = qab[0][lane];
             q[J0 + SH + lane] = qB;
             if (PUBLISH) st_publish_store(qpub + J0 + SH + lane, qB);  // the value is its own flag
         }
-        qA = st_bwd_mini_chain(pBA, J0 + SH, n, qB, qA);
+    } else if (wave == 1) {
+        qab[1][lane] = st_bwd_mini_regs(sv, qab[0], nvalid_b, qpart[lane]);
     }
-    qA = st_bwd_half_chain(pAA, J0, n, qA);
-    if (J0 + lane < n) {
+    __syncthreads();
+    if (wave == 2) {
+        const double qA = st_bwd_chain_regs(sv, SH, qab[1][lane]);  // half A is complete whenever half B exists
         q[J0 + lane] = qA;
         if (PUBLISH) st_publish_store(qpub + J0 + lane, qA);
     }
@@ -771,7 +916,12 @@ __global__ __launch_bounds__(256) void k_st_bwd_persist(const double* __restrict
                 sv[h][r] = *reinterpret_cast<const double2_t*>(M + row * ld + c);
             }
         }
-        if (kb == sblk + 1) st_prefetch_block_bwd(M, ld, n, c0, blk);
+        if (kb == sblk + 1) {  // own diagonal block: fetched and parked in LDS while the values it waits for are computed
+            st_prefetch_block_bwd(M, ld, n, c0, blk);
+            st_park_piece(lds, blk.bb);
+            st_park_piece(lds + SH * BLK_PITCH, blk.ba);
+            st_park_piece(lds + 2 * SH * BLK_PITCH, blk.aa);
+        }
         if (threadIdx.x < SB) {
             double v = 0.0;
             if (J0 + threadIdx.x < n && !st_poll_value(qpub + J0 + threadIdx.x, v)) ok = 0;
@@ -803,7 +953,7 @@ __global__ __launch_bounds__(256) void k_st_bwd_persist(const double* __restrict
         __syncthreads();
     }
     __syncthreads();
-    st_bwd_diag_block<true>(n, c0, blk, lds, qstrip, q, qpub);
+    st_bwd_diag_block<true>(n, c0, blk, lds, qstrip, q, qpub, sblk < nblk - 1);
 }
 
 // xc -= (rho/omega) q   (src/ell_stable.rs:101-104)
