@@ -42,9 +42,9 @@ constexpr int SLDS_PAD = 18;  // doubles per LDS tile row (16 + 2: keeps 16-byte
 // ------------------------------------------------------------------------------ forward ------
 // The diagonal-block solve is a length-128 dependency chain, so it is kept free of memory latency:
 // all 4 waves of the owning workgroup prefetch the three 64x64 pieces of the block (AA, AB, BB) and
-// the 128 diagonal entries into registers before the panel work, park them in LDS, ONE wave runs the
-// chain out of LDS/registers and leaves the products in LDS, and all 4 waves write them back to the
-// scratch triangle as coalesced rows.
+// the 128 diagonal entries into registers before the panel work, park them in LDS, three waves share the
+// chain (st_fwd_diag_block) out of registers and leave the products in LDS, and all 4 waves write them back to
+// the scratch triangle as coalesced rows.
 constexpr int BLK_PITCH = 65;  // doubles per LDS row of a 64x64 piece: odd, so the column reads AND the
                                // transposed product writes of the chain wave are both bank-conflict-free
 
@@ -81,30 +81,11 @@ __device__ __forceinline__ void st_park_piece(double* __restrict__ lds, const do
     }
 }
 
-// Chain for 64 columns H0..: u[j] = piece[j][lane]; products are left in piece[lane][j] (transposed in
-// place: every lane has read its whole column before any lane writes).  src/ell_stable.rs:61-69
-__device__ __forceinline__ double st_fwd_half_chain(double* __restrict__ piece, double wi) {
-    const int lane = threadIdx.x & 63;
-    double u[SH];
-#pragma unroll
-    for (int j = 0; j < SH; ++j) u[j] = piece[j * BLK_PITCH + lane];
-    // Critical path per step: subtract -> broadcast lane j+1 -> multiply -> subtract.  The broadcast
-    // reads the unselected difference `t` (lane j+1 is always an active lane of step j), so the select
-    // that protects the already-final lanes <= j runs beside the chain, not in it.
-    double t = wi;
-#pragma unroll
-    for (int j = 0; j < SH; ++j) {
-        const double wj = lane_bcast(t, j);  // lane j's value is final after step j-1
-        const double v = u[j] * wj;          // :65
-        u[j] = v;                            // parked product, :66 (meaningful for j < lane only)
-        t = wi - v;                          // :67
-        wi = (lane > j) ? t : wi;
-    }
-#pragma unroll
-    for (int j = 0; j < SH; ++j) piece[lane * BLK_PITCH + j] = u[j];
-    return wi;
-}
-// The same chain on a column already held in registers (u[j] = piece[j][lane]); products stay in u.
+// Chain over 64 columns held in registers (u[j] = piece[j][lane]); the products stay in u and are parked transposed
+// (piece[lane][j]) by the caller.  src/ell_stable.rs:61-69
+// Critical path per step: subtract -> broadcast lane j+1 -> multiply -> subtract.  The broadcast reads the unselected
+// difference `t` (lane j+1 is always an active lane of step j), so the select that protects the already-final lanes
+// <= j runs beside the chain, not in it.
 __device__ __forceinline__ double st_fwd_chain_regs(double (&u)[SH], double wi) {
     const int lane = threadIdx.x & 63;
     double t = wi;
@@ -132,29 +113,6 @@ __device__ __forceinline__ double st_fwd_mini_regs(double (&u)[SH], const double
     }
     return wb - ((a0 + a1) + (a2 + a3));
 }
-// Rows A (final, lane j holds w[A0+j]) applied to the 64 columns of B: products left in piece[lane][j].
-__device__ __forceinline__ double st_fwd_mini_chain(double* __restrict__ piece, double wa, double wb) {
-    const int lane = threadIdx.x & 63;
-    double u[SH];
-#pragma unroll
-    for (int j = 0; j < SH; ++j) u[j] = piece[j * BLK_PITCH + lane];
-    // not a dependency chain: four interleaved partial sums (16 steps deep instead of 64)
-    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-#pragma unroll
-    for (int j = 0; j < SH; j += 4) {
-        const double v0 = u[j] * lane_bcast(wa, j);
-        const double v1 = u[j + 1] * lane_bcast(wa, j + 1);
-        const double v2 = u[j + 2] * lane_bcast(wa, j + 2);
-        const double v3 = u[j + 3] * lane_bcast(wa, j + 3);
-        u[j] = v0, u[j + 1] = v1, u[j + 2] = v2, u[j + 3] = v3;
-        a0 += v0, a1 += v1, a2 += v2, a3 += v3;
-    }
-    wb = wb - ((a0 + a1) + (a2 + a3));
-#pragma unroll
-    for (int j = 0; j < SH; ++j) piece[lane * BLK_PITCH + j] = u[j];
-    return wb;
-}
-
 // All threads: write the parked products of a piece to S rows R0.., columns C0..; `lower_only`: only
 // the strict lower triangle of the piece belongs to S (the rest is factor / diagonal, never touched).
 __device__ __forceinline__ void st_store_piece(double* __restrict__ M, long long ld, long long n,
@@ -655,44 +613,7 @@ __global__ __launch_bounds__(256) void k_st_post(double* __restrict__ M, long lo
 // ------------------------------------------------------------------------------ backward ------
 // q = z; for j descending: q[t] -= S[j][t] * q[j], t < j   (src/ell_stable.rs:93-98; rows of the scratch
 // triangle, bug-compatible).  Same structure as the forward solve, without stores: the three pieces of
-// the diagonal block (BB, BA, AA) are prefetched by all 4 waves, one wave runs the chain out of LDS.
-__device__ __forceinline__ double st_bwd_half_chain(const double* __restrict__ piece, long long H0, long long n,
-                                                    double qi) {
-    const int lane = threadIdx.x & 63;
-    double sv[SH];
-#pragma unroll
-    for (int j = 0; j < SH; ++j) sv[j] = piece[j * BLK_PITCH + lane];  // S[H0+j][H0+lane]; used for j > lane
-    const int nvalid = (n - H0 < SH) ? (int)(n - H0) : SH;  // rows of this half that exist
-#pragma unroll
-    for (int j = SH - 1; j >= 1; --j) {
-        const double qj = lane_bcast(qi, j);
-        const double v = sv[j] * qj;
-        qi = (lane < j && j < nvalid) ? qi - v : qi;
-    }
-    return qi;
-}
-__device__ __forceinline__ double st_bwd_mini_chain(const double* __restrict__ piece, long long B0, long long n,
-                                                    double qb, double qa) {
-    const int lane = threadIdx.x & 63;
-    double sv[SH];
-#pragma unroll
-    for (int j = 0; j < SH; ++j) sv[j] = piece[j * BLK_PITCH + lane];  // S[B0+j][A0+lane]
-    const int nvalid = (n - B0 < SH) ? (int)(n - B0) : SH;
-    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;  // four interleaved partial sums, not a 64-deep chain
-#pragma unroll
-    for (int j = 0; j < SH; j += 4) {
-        const double v0 = sv[j] * lane_bcast(qb, j);
-        const double v1 = sv[j + 1] * lane_bcast(qb, j + 1);
-        const double v2 = sv[j + 2] * lane_bcast(qb, j + 2);
-        const double v3 = sv[j + 3] * lane_bcast(qb, j + 3);
-        a0 += (j < nvalid) ? v0 : 0.0;
-        a1 += (j + 1 < nvalid) ? v1 : 0.0;
-        a2 += (j + 2 < nvalid) ? v2 : 0.0;
-        a3 += (j + 3 < nvalid) ? v3 : 0.0;
-    }
-    return qa - ((a0 + a1) + (a2 + a3));
-}
-
+// the diagonal block (BB, BA, AA) are prefetched by all 4 waves and parked in LDS; three waves share the chain.
 struct Blk3b {
     double2_t bb[8], ba[8], aa[8];
 };
