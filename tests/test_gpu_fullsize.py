@@ -192,3 +192,28 @@ def test_ell_n32768_matches_oracle(gpu, orc):
     scale = 1.0   # Q0 = I and two small rank-1 corrections: the largest element stays ~1
     for r in (0, n // 2 - 256, n - 512):
         assert np.max(np.abs(qg[r:r + 512] - qo[r:r + 512])) <= TOL * scale
+
+
+def test_ellstable_n32768_persistent_equals_per_block_launches(gpu, monkeypatch):
+    """n = 32768 is the largest size the persistent solves cover (256 column strips = one workgroup per CU).  Three
+    deep cuts; the flag-chained single launch must give the bits of the one-launch-per-block path (same arithmetic,
+    no inter-workgroup hand-off), and the first update has a closed form (identity factor: only the diagonal moves)."""
+    from ellalgo_rs_amd import synth
+    n, k = 32768, 3
+    kinds, grads, b0, _ = synth.deep_cuts(n, k)
+    a = gpu.EllStable.new_with_scalar(1.0, np.zeros(n))
+    monkeypatch.setenv("ELLHIP_STABLE_PERSIST", "0")
+    b = gpu.EllStable.new_with_scalar(1.0, np.zeros(n))
+    monkeypatch.delenv("ELLHIP_STABLE_PERSIST")
+    for i in range(k):
+        sa = int(a.update_bias_cut((grads[i], float(b0[i]))))
+        sb = int(b.update_bias_cut((grads[i], float(b0[i]))))
+        assert sa == sb == 0
+        assert a.tsq() == b.tsq() and a.kappa == b.kappa
+        if i == 0:
+            g = grads[0]
+            assert abs(a.tsq() - float(g @ g)) <= 1e-12     # kappa0 = 1, w = g, omega = g.g
+    assert np.array_equal(a.xc(), b.xc())
+    qa, qb = a.mq, b.mq
+    for r in range(0, n, 4096):
+        assert np.array_equal(qa[r:r + 4096], qb[r:r + 4096])
