@@ -51,17 +51,19 @@ int lp_issue(ellhip_lowpass* o, hipStream_t st, const double* x_dev, int mode, D
         std::unique_ptr<ProfScope> ps;
         if (prof) ps.reset(new ProfScope(prof, CLS_LP_SCAN));
         const bool vec2 = (o->P.n % 2) == 0;
-#define LP_LAUNCH(KERNEL)                                                                                          \
-    hipLaunchKernelGGL(KERNEL, dim3(o->grid), dim3(256), 0, st, (const double*)o->d_A, o->P, x_dev, o->d_vals, \
-                       o->d_ls, halted)
+        // two launches per scan: the first one sized from the previous walk, the second one the rest (lp_range)
+#define LP_LAUNCH(KERNEL)                                                                                             \
+    for (int ph = 0; ph < 2; ++ph)                                                                                    \
+        hipLaunchKernelGGL(KERNEL, dim3(o->grid), dim3(256), 0, st, (const double*)o->d_A, o->P, x_dev, o->d_vals,    \
+                           o->d_ls, halted, ph);
         if (o->wide) {
-            if (vec2 && o->nt) LP_LAUNCH((k_lp_scan_wide<2, true>));
-            else if (vec2) LP_LAUNCH((k_lp_scan_wide<2, false>));
-            else LP_LAUNCH((k_lp_scan_wide<1, false>));
+            if (vec2 && o->nt) LP_LAUNCH((k_lp_scan_wide<2, true>))
+            else if (vec2) LP_LAUNCH((k_lp_scan_wide<2, false>))
+            else LP_LAUNCH((k_lp_scan_wide<1, false>))
         } else {
-            if (vec2 && o->nt) LP_LAUNCH((k_lp_scan<2, true>));
-            else if (vec2) LP_LAUNCH((k_lp_scan<2, false>));
-            else LP_LAUNCH((k_lp_scan<1, false>));
+            if (vec2 && o->nt) LP_LAUNCH((k_lp_scan<2, true>))
+            else if (vec2) LP_LAUNCH((k_lp_scan<2, false>))
+            else LP_LAUNCH((k_lp_scan<1, false>))
         }
 #undef LP_LAUNCH
         HIPCHK(hipGetLastError());

@@ -47,7 +47,25 @@ struct LpState {
     double fmax;           // :19
     double sp_sq;          // :15 (and the caller's gamma in assess_optim)
     long long rows_total;  // rows the reference's walk visits, summed over calls (work measure for the roofline)
+    unsigned hint;         // visiting positions the first scan launch of the NEXT call covers (1.5 x this walk's length)
 };
+
+// A scan is two launches over the visiting order: [0, a) and [a, mdim), a = clamp(hint, LP_FIRST_MIN chunks, all).
+// The walk usually ends about where the previous one did -- a few rows behind the cursor for long stretches of a
+// run, thousands of rows later in others -- so the first launch is sized from the previous walk: a short walk costs
+// one small launch (a full-grid launch reads a chip-wide round of rows, 134 MB at n = 4096, before anybody can stop),
+// a long one runs at full width at once, and a misprediction is caught by the second launch (which leaves at once
+// when the first one found the violation).
+constexpr unsigned LP_FIRST_MIN = 64;  // chunks
+__device__ __forceinline__ void lp_range(const LpState* ls, unsigned total, unsigned per_step, int phase,
+                                         unsigned& cb, unsigned& ce) {
+    const unsigned nchunks = (total + per_step - 1) / per_step;
+    unsigned a = (ls->hint + per_step - 1) / per_step;
+    if (a < LP_FIRST_MIN) a = LP_FIRST_MIN;
+    if (a > nchunks) a = nchunks;
+    cb = phase == 0 ? 0u : a;
+    ce = phase == 0 ? a : nchunks;
+}
 
 constexpr unsigned LP_NONE = 0xffffffffu;
 constexpr int LP_RPW = 4;     // rows per wave and step
@@ -88,15 +106,17 @@ __device__ __forceinline__ int lp_full_cycle(int idx, int base, int len) {
 template <int VEC, bool NT>
 __global__ __launch_bounds__(256) void k_lp_scan(const double* __restrict__ A, LpParams P,
                                                  const double* __restrict__ x, double* __restrict__ vals,
-                                                 LpState* __restrict__ ls, const int* __restrict__ halted) {
+                                                 LpState* __restrict__ ls, const int* __restrict__ halted,
+                                                 int phase) {
     if (*halted) return;
     using V = typename VecT<VEC>::type;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int idx1 = ls->idx1, idx2 = ls->idx2, idx3 = ls->idx3;
     const double sp_sq = ls->sp_sq;
     const unsigned total = (unsigned)P.mdim;
-    const unsigned nchunks = (total + LP_CHUNK - 1) / LP_CHUNK;
-    for (unsigned c = blockIdx.x; c < nchunks; c += gridDim.x) {
+    unsigned chunk_begin, chunk_end;  // this launch's share of the walk (lp_range)
+    lp_range(ls, total, LP_CHUNK, phase, chunk_begin, chunk_end);
+    for (unsigned c = chunk_begin + blockIdx.x; c < chunk_end; c += gridDim.x) {
         const unsigned p0 = c * LP_CHUNK;
         // a violation before this chunk has already been found: nothing from here on can be the first
         if (__hip_atomic_load(&ls->pos, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < p0) return;
@@ -144,7 +164,8 @@ constexpr long long LP_WIDE_N = 1024;
 template <int VEC, bool NT>
 __global__ __launch_bounds__(256) void k_lp_scan_wide(const double* __restrict__ A, LpParams P,
                                                       const double* __restrict__ x, double* __restrict__ vals,
-                                                      LpState* __restrict__ ls, const int* __restrict__ halted) {
+                                                      LpState* __restrict__ ls, const int* __restrict__ halted,
+                                                      int phase) {
     if (*halted) return;
     using V = typename VecT<VEC>::type;
     __shared__ double red[4][LP_RPW];
@@ -153,8 +174,9 @@ __global__ __launch_bounds__(256) void k_lp_scan_wide(const double* __restrict__
     const int idx1 = ls->idx1, idx2 = ls->idx2, idx3 = ls->idx3;
     const double sp_sq = ls->sp_sq;
     const unsigned total = (unsigned)P.mdim;
-    const unsigned nchunks = (total + LP_RPW - 1) / LP_RPW;
-    for (unsigned c = blockIdx.x; c < nchunks; c += gridDim.x) {
+    unsigned chunk_begin, chunk_end;
+    lp_range(ls, total, LP_RPW, phase, chunk_begin, chunk_end);
+    for (unsigned c = chunk_begin + blockIdx.x; c < chunk_end; c += gridDim.x) {
         const unsigned p0 = c * LP_RPW;
         if (tid == 0) s_pos = __hip_atomic_load(&ls->pos, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __syncthreads();  // one decision per workgroup (also fences the reuse of red[])
@@ -361,7 +383,9 @@ __global__ __launch_bounds__(256) void k_lp_final(const double* __restrict__ A, 
         ls->has_cut = has_cut;
         if (copy_x) ls->has_best = 1;
         ls->pos = LP_NONE;  // ready for the next scan
-        ls->rows_total += (pos == LP_NONE) ? (long long)P.mdim : (long long)pos + 1;
+        const long long walked = (pos == LP_NONE) ? (long long)P.mdim : (long long)pos + 1;
+        ls->rows_total += walked;
+        ls->hint = (unsigned)(walked + walked / 2);
         *cp = c;
         sh_row = row;
         sh_sign = sign;
