@@ -373,23 +373,31 @@ int ellstable_issue(ellhip_space* s, const double* g_dev, const CutParams* cp_de
                     int* qst, double* qtsq) {
     const long long n = s->n, ld = s->ld;
     const long long nb = (n + SB - 1) / SB;
-    double* w = s->d_work;
-    double* z = w + n;
+    double* w0 = s->d_work;
+    double* z = w0 + n;
     double* gg = z + n;
     double* q = gg + n;
     double* beta2 = q + n;
     double* qpub = beta2 + n;            // publish buffer of the persistent backward solve (data-as-flag hand-off)
-    double* cpre = qpub + n + (n & 1);   // chunk prefixes of the mid stage (ST_MID_T + 1 doubles)
+    double* w1 = qpub + n;               // second publish buffer of the persistent forward solve (see below)
+    double* cpre = w1 + n + (n & 1);     // chunk prefixes of the mid stage (ST_MID_T + 1 doubles)
     hipStream_t st = s->stream;
     // One launch per solve when every 128-column strip can have its own resident workgroup; otherwise
     // (n > 128 * 256) one launch per block.
     const bool persist = s->stable_persist && nb <= 256;
+    // Persistent forward solve: the workgroup that is next in the chain polls the VALUES of the block it waits for
+    // (sentinel until stored, like the backward solve's qpub), everybody else the block's flag.  The published
+    // vector therefore has to be all-sentinel when a solve starts: two buffers alternate by launch parity, and the
+    // mid stage of every update re-arms the one the NEXT solve will use (whatever this update's status).
+    if (persist) ++s->epoch;
+    double* w = (persist && (s->epoch & 1)) ? w1 : w0;
+    double* w_next = (persist && (s->epoch & 1)) ? w0 : w1;
     int* err = reinterpret_cast<int*>(reinterpret_cast<char*>(s->d_st) + offsetof(DevState, solve_err));
     {
         ProfScope ps(s, CLS_ST_FWD);
         if (persist) {
             hipLaunchKernelGGL(k_st_fwd_persist, dim3((unsigned)nb), dim3(256), 0, st, s->d_Q, ld, n, g_dev, w, z, gg,
-                               s->d_flags, err, ++s->epoch, s->d_st);
+                               s->d_flags, err, s->epoch, s->d_st);
         } else {
             HIPCHK(hipMemcpyAsync(w, g_dev, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, st));
             hipLaunchKernelGGL(k_st_fwd_first, dim3(1), dim3(256), 0, st, s->d_Q, ld, n, g_dev, w, z, gg, s->d_st);
@@ -408,7 +416,8 @@ int ellstable_issue(ellhip_space* s, const double* g_dev, const CutParams* cp_de
                            cp_val, queue_mode, qst, qtsq);
         hipLaunchKernelGGL(k_st_post, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, s->d_Q, ld, n,
                            (const double*)z, (const double*)gg, (const double*)cpre, q, beta2,
-                           persist ? qpub : (double*)nullptr, (const DevState*)s->d_st);
+                           persist ? qpub : (double*)nullptr, persist ? w_next : (double*)nullptr,
+                           (const DevState*)s->d_st);
         HIPCHK(hipGetLastError());
     }
     // The factor update (reads S, rewrites U) and the backward solve (reads S, writes q) are independent.
@@ -735,7 +744,11 @@ int alloc_common(ellhip_space* s) {
         HIPCHK(hipEventCreateWithFlags(&s->ev_join, hipEventDisableTiming));
     }
     if (s->variant == ELLHIP_SPACE_ELL_STABLE) {
-        HIPCHK(hipMalloc(&s->d_work, vbytes * 7 + (ST_MID_T + 8) * sizeof(double)));  // w z gg q beta2 qpub (+1 spare) | cpre
+        HIPCHK(hipMalloc(&s->d_work, vbytes * 8 + (ST_MID_T + 8) * sizeof(double)));  // w0 z gg q beta2 qpub w1 (+1 spare) | cpre
+        // both publish buffers of the persistent forward solve start out all-sentinel
+        hipLaunchKernelGGL(k_st_arm, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream, s->d_work, n);
+        hipLaunchKernelGGL(k_st_arm, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream, s->d_work + 6 * n, n);
+        HIPCHK(hipGetLastError());
     }
     HIPCHK(hipHostMalloc(&s->h_result, sizeof(DevState), hipHostMallocDefault));
     return 0;

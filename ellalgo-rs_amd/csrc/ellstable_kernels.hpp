@@ -466,14 +466,32 @@ __global__ __launch_bounds__(256) void k_st_fwd_persist(double* __restrict__ M, 
         }
         // (the data-as-flag hand-off of the backward solve was tried here too: 255 workgroups x 128 lanes polling the
         // values slowed the publishing wave down, forward solve 1.25 -> 1.34 ms; one polling lane per workgroup it is)
-        if (threadIdx.x == 0) ok = st_wait_flag(flags + kb, epoch) ? 1 : 0;
-        __syncthreads();
-        if (!ok) {
-            if (threadIdx.x == 0) atomicExch(err, 1);
-            return;
+        if (kb == sblk - 1) {
+            // next in the chain: poll the 128 values themselves (the buffer is all-sentinel when the launch starts),
+            // no flag round trip and no wait for the publisher's store drain.  Only ONE workgroup polls a block's
+            // values at any time -- all of them doing so slowed the publishing wave down (1.25 -> 1.34 ms).
+            if (threadIdx.x == 0) ok = 1;
+            __syncthreads();
+            if (threadIdx.x < SB) {
+                double v = 0.0;
+                if (!st_poll_value(w + J0 + threadIdx.x, v)) ok = 0;
+                wblk[threadIdx.x] = v;
+            }
+            __syncthreads();
+            if (!ok) {
+                if (threadIdx.x == 0) atomicExch(err, 1);
+                return;
+            }
+        } else {
+            if (threadIdx.x == 0) ok = st_wait_flag(flags + kb, epoch) ? 1 : 0;
+            __syncthreads();
+            if (!ok) {
+                if (threadIdx.x == 0) atomicExch(err, 1);
+                return;
+            }
+            if (threadIdx.x < SB) wblk[threadIdx.x] = st_published_load(w + J0 + threadIdx.x);
+            __syncthreads();
         }
-        if (threadIdx.x < SB) wblk[threadIdx.x] = st_published_load(w + J0 + threadIdx.x);
-        __syncthreads();
         double p0 = 0.0, p1 = 0.0;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
@@ -588,15 +606,23 @@ __global__ __launch_bounds__(ST_MID_T) void k_st_mid(long long n, const double* 
     }
 }
 
+__global__ __launch_bounds__(256) void k_st_arm(double* __restrict__ p, long long n) {
+    const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < n) p[j] = st_sentinel();
+}
+
 // One thread per element j: t_{j-1}, t_j, beta2_j, d_j *= t_{j-1}/t_j (src/ell_stable.rs:111-113,120-121), q_j = z_j
 // (:93).  qpub_rearm (persistent backward solve): every entry back to the sentinel before each solve that runs.
 __global__ __launch_bounds__(256) void k_st_post(double* __restrict__ M, long long ld, long long n,
                                                  const double* __restrict__ z, const double* __restrict__ gg,
                                                  const double* __restrict__ cpre, double* __restrict__ q,
                                                  double* __restrict__ beta2, double* __restrict__ qpub_rearm,
-                                                 const DevState* __restrict__ st) {
+                                                 double* __restrict__ w_rearm, const DevState* __restrict__ st) {
     const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n) return;
+    // the publish buffer of the NEXT persistent forward solve: armed whatever happened to this update (a failed cut and
+    // a halted loop still alternate the buffers, see ellstable_issue)
+    if (w_rearm) w_rearm[j] = st_sentinel();
     if (!st->apply) return;  // failed cut / halted loop: nothing below runs, and neither does the backward solve
     if (qpub_rearm) qpub_rearm[j] = st_sentinel();
     const long long m = (n + ST_MID_T - 1) / ST_MID_T;
