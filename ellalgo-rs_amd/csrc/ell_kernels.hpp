@@ -857,7 +857,10 @@ __global__ __launch_bounds__(256) void k_scalar_dot_def(long long n, const doubl
         partial[(long long)blockIdx.x * (NP + 1) + tid] = ((red[0][tid] + red[1][tid]) + red[2][tid]) + red[3][tid];
 }
 
-template <int NP>
+// GY: the partial sums' column 0 (g . y) does not exist yet (k_sweep_gemv_dots produced the other columns beside the
+// GEMV that produced y): every workgroup forms the scalar_groups(n) slice sums itself, in k_scalar_dot_def's shape, and
+// they enter the reduction below exactly where the stored column would -- the same bits either way.
+template <int NP, bool GY = false>
 __global__ __launch_bounds__(256) void k_scalar_apply_def(long long n, const double* __restrict__ y,
                                                           double* __restrict__ xc, double* __restrict__ pend,
                                                           double* __restrict__ cpend,
@@ -865,7 +868,8 @@ __global__ __launch_bounds__(256) void k_scalar_apply_def(long long n, const dou
                                                           DevState* __restrict__ st, EllCalcDev calc,
                                                           const CutParams* __restrict__ cp_dev, CutParams cp_val,
                                                           int slot, int queue_mode, int* __restrict__ q_status,
-                                                          double* __restrict__ q_tsq, int npart) {
+                                                          double* __restrict__ q_tsq, int npart,
+                                                          const double* __restrict__ g_own) {
     // npart = number of partial-sum rows: scalar_groups(n) after k_scalar_dot_def, ceil(n / 128) after k_symv_reduce<NP>
     // `slot` = number of updates already pending = index of the (all-zero) slot this cut records into.
     // The host passes it: it equals the device's count as long as the queue has not halted, and a halted
@@ -886,19 +890,40 @@ __global__ __launch_bounds__(256) void k_scalar_apply_def(long long n, const dou
     // Sum the npart rows of partial sums, per column: 8 interleaved running sums (thread group q takes rows q, q + 8,
     // ...; four loads in flight per thread), combined in a fixed order -- one memory round trip instead of npart / 8.
     __shared__ double psum[8][32];
+    __shared__ double gy_part[64];
+    __shared__ double gy_w[64][4];
+    if (GY) {  // (npart = scalar_groups(n) <= 64 in this mode)
+        const long long m = scalar_slice(n);
+        for (int b = 0; b < npart; ++b) {
+            const long long lo = (long long)b * m;
+            const long long hi = (lo + m < n) ? lo + m : n;
+            double sgy = 0.0;
+#pragma unroll 4
+            for (long long i = lo + tid; i < hi; i += 256) sgy += g_own[i] * y[i];
+            sgy = wave_allreduce_sum(sgy);
+            if ((tid & 63) == 0) gy_w[b][tid >> 6] = sgy;
+        }
+        __syncthreads();
+        if (tid < npart) gy_part[tid] = ((gy_w[tid][0] + gy_w[tid][1]) + gy_w[tid][2]) + gy_w[tid][3];
+        __syncthreads();
+    }
     {
         const int c = tid & 31, q = tid >> 5;
         if (c <= NP) {
             double a = 0.0;
             int b = q;
-            for (; b + 24 < npart; b += 32) {
-                double v[4];
+            if (GY && c == 0) {
+                for (; b < npart; b += 8) a += gy_part[b];
+            } else {
+                for (; b + 24 < npart; b += 32) {
+                    double v[4];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) v[u] = partial[(long long)(b + 8 * u) * (NP + 1) + c];
+                    for (int u = 0; u < 4; ++u) v[u] = partial[(long long)(b + 8 * u) * (NP + 1) + c];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) a += v[u];
+                    for (int u = 0; u < 4; ++u) a += v[u];
+                }
+                for (; b < npart; b += 8) a += partial[(long long)b * (NP + 1) + c];
             }
-            for (; b < npart; b += 8) a += partial[(long long)b * (NP + 1) + c];
             psum[q][c] = a;
         }
     }
@@ -968,6 +993,56 @@ __global__ __launch_bounds__(256) void k_scalar_apply_def(long long n, const dou
         vnew[i] = gt;                    // slot `slot` was all zeros until now: its own term above was an exact 0
         xc[i] = xc[i] - roo * gt;        // :113-115
     }
+}
+
+// Full-row GEMV pass of the deferred schedule (handles without the lower-triangle schedule: n < 8192, odd n) with
+// the scalar stage's v_j . g dot products computed BESIDE it: the grid has scalar_groups(n) extra workgroups behind
+// the row tiles; extra workgroup b does for slice b exactly what k_scalar_dot_def does for columns 1..NP (same thread
+// mapping, same reduction shape, same bits) and takes its halted / kappa snapshots.  g . y cannot be formed here (y is
+// this very launch's output): k_scalar_apply_def<NP, true> forms it, again in k_scalar_dot_def's shape.  Net effect:
+// the scalar stage is one launch on the update's dependency chain instead of two (n = 4096: 13.6 -> ~9 us).
+template <int RW, int UNR, int VEC, bool NT, int NP>
+__global__ __launch_bounds__(256) void k_sweep_gemv_dots(const double* Q, long long ld, long long n, long long nrows,
+                                                         long long row0, const double* __restrict__ gvec,
+                                                         double* __restrict__ gv_out, DevState* __restrict__ st,
+                                                         int reverse, unsigned ntiles, const double* __restrict__ pend,
+                                                         double* __restrict__ partial) {
+    __shared__ double red[4][RW > NP ? RW : NP];
+    const int halted = st->halted;
+    const int tid = threadIdx.x;
+    if (blockIdx.x >= ntiles) {
+        const long long b = (long long)blockIdx.x - ntiles;
+        if (b == 0 && tid == 0) {
+            st->halted_in = halted;
+            st->kappa_in = st->kappa;
+        }
+        if (halted) return;
+        const long long m = scalar_slice(n);
+        const long long lo = b * m;
+        const long long hi = (lo + m < n) ? lo + m : n;
+        double sd[NP];
+#pragma unroll
+        for (int j = 0; j < NP; ++j) sd[j] = 0.0;
+        for (long long i = lo + tid; i < hi; i += 256) {
+            const double gi = gvec[i];
+#pragma unroll
+            for (int j = 0; j < NP; ++j) sd[j] += pend[(long long)j * n + i] * gi;
+        }
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            const double w = wave_allreduce_sum(sd[j]);
+            if ((tid & 63) == 0) red[tid >> 6][j] = w;
+        }
+        __syncthreads();
+        if (tid < NP) partial[b * (NP + 1) + 1 + tid] = ((red[0][tid] + red[1][tid]) + red[2][tid]) + red[3][tid];
+        return;
+    }
+    if (halted) return;
+    const long long tile = reverse ? (long long)ntiles - 1 - blockIdx.x : (long long)blockIdx.x;
+    const long long row_base = tile * RW;
+    if (row_base >= nrows) return;
+    sweep_rows<RW, UNR, VEC, NT, false, true, false>(Q, const_cast<double*>(Q), ld, n, nrows, row0, row_base, nullptr, gvec,
+                                                     gv_out, 0.0, 1.0, reinterpret_cast<double(*)[RW]>(&red[0][0]));
 }
 
 constexpr long long SCALAR_SPLIT_N = 8192;

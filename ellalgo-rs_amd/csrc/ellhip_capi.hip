@@ -91,7 +91,9 @@ struct ellhip_space {
     int symv_seg = SYMV_SEG;         // segment width of the lower-triangle GEMV's tiles (see symv_alloc)
     int apply_lower = 1;             // with symv: apply passes touch the lower triangle only (ELLHIP_APPLY_LOWER)
     int fuse_dots = 1;               // unsharded lower-triangle schedule: k_symv_reduce also yields the scalar stage's dot products (ELLHIP_FUSE_DOTS)
-    int dots_np = 0;                 // > 0: d_partial holds [ceil(n/128)][dots_np + 1] dot products of the primed gradient
+    int dots_np = 0;                 // > 0: d_partial holds dot products of the primed gradient for this depth: [ceil(n/128)][dots_np + 1]
+                                     // from k_symv_reduce, or [scalar_groups(n)][...] WITHOUT the g.y column from k_sweep_gemv_dots
+    bool dots_need_gy = false;       // the latter: k_scalar_apply_def forms g.y itself
     int apply_kernel = 1;            // depth 8: 1 = k_apply_lower (16-row tiles, 0.40 ms at n = 16384), 0 = k_sweep_apply<LOWER> (0.44 ms)
     bool upper_stale = false;        // strict upper triangle of Q is out of date (see flush_pending)
     int defer = 1;                   // 1 = shrink Q at every cut; MAXPEND = record and apply in batches
@@ -284,6 +286,39 @@ int launch_sweep(ellhip_space* s, const Shape& sh, const double* gt_r1, const do
     if (rc) return rc;
     HIPCHK(hipGetLastError());
     s->dir ^= 1;  // the next pass over Q runs the other way
+    return 0;
+}
+
+// Full-row GEMV of the deferred schedule with the v_j . g dot products computed beside it (k_sweep_gemv_dots).
+template <int VEC, bool NT>
+int launch_gemv_dots_t(ellhip_space* s, const Shape& sh, const double* gvec, double* gv_out) {
+    const long long nr = s->nrows;
+    const unsigned ntiles = (unsigned)((nr + sh.rw - 1) / sh.rw);
+    const unsigned grid = ntiles + (unsigned)scalar_groups(s->n);
+#define DOTS_CASE(RW, UNR)                                                                                          \
+    if (sh.rw == RW && sh.unr == UNR) {                                                                             \
+        hipLaunchKernelGGL((k_sweep_gemv_dots<RW, UNR, VEC, NT, 8>), dim3(grid), dim3(256), 0, s->stream,           \
+                           (const double*)s->d_Q, s->ld, s->n, nr, s->row0, gvec, gv_out + s->row0, s->d_st, s->dir, \
+                           ntiles, (const double*)s->d_pend, s->d_partial);                                         \
+        return 0;                                                                                                   \
+    }
+    DOTS_CASE(1, 4) DOTS_CASE(1, 8) DOTS_CASE(2, 4) DOTS_CASE(2, 8) DOTS_CASE(4, 2) DOTS_CASE(4, 4)
+    DOTS_CASE(8, 1) DOTS_CASE(8, 2)
+#undef DOTS_CASE
+    return fail(ELLHIP_E_INVALID, "unsupported RW/UNR launch shape (supported: 1x4 1x8 2x4 2x8 4x2 4x4 8x1 8x2)");
+}
+
+int launch_gemv_dots(ellhip_space* s, const double* gvec, double* gv_out) {
+    const bool even = (s->n % 2) == 0;
+    const bool nt = even && s->sh_gemv.nt;
+    int rc = !even ? launch_gemv_dots_t<1, false>(s, s->sh_gemv, gvec, gv_out)
+                   : (nt ? launch_gemv_dots_t<2, true>(s, s->sh_gemv, gvec, gv_out)
+                         : launch_gemv_dots_t<2, false>(s, s->sh_gemv, gvec, gv_out));
+    if (rc) return rc;
+    HIPCHK(hipGetLastError());
+    s->dir ^= 1;
+    s->dots_np = 8;
+    s->dots_need_gy = true;
     return 0;
 }
 
@@ -540,10 +575,15 @@ int launch_symv(ellhip_space* s, const double* g_dev, double* y_out) {
 int do_prime(ellhip_space* s, const double* g_dev, int slot) {
     if (s->variant != ELLHIP_SPACE_ELL) return 0;
     s->dots_np = 0;  // whatever d_partial held belonged to an earlier gradient
+    s->dots_need_gy = false;
     if (symv_ok(s)) return launch_symv(s, g_dev, s->d_gt[slot]);
     if (s->shard_symmetric)
         return fail(ELLHIP_E_STATE, "symmetric row shard: only the deferred (depth 8) schedule is available");
     ProfScope ps(s, CLS_GEMV);
+    // deferred depth 8 on full rows (no lower-triangle schedule at this size): the dot products ride along.  Up to
+    // n = 8192 only: every workgroup of the scalar stage re-forms g.y from all of g and y, which stops paying beyond.
+    if (deferring(s) && s->defer == 8 && !s->sharded && s->fuse_dots && s->n <= 8192)
+        return launch_gemv_dots(s, g_dev, s->d_gt[slot]);
     return launch_sweep<false, true>(s, s->sh_gemv, nullptr, g_dev, s->d_gt[slot]);
 }
 
@@ -551,6 +591,11 @@ int do_prime(ellhip_space* s, const double* g_dev, int slot) {
 int do_cut(ellhip_space* s, const double* g_dev, const CutParams* cp_dev, CutParams cp_val, int queue_mode, int* qst,
            double* qtsq) {
     if (s->variant != ELLHIP_SPACE_ELL) return ellstable_issue(s, g_dev, cp_dev, cp_val, queue_mode, qst, qtsq);
+    // The dot products a prime left in d_partial belong to THIS cut only: whatever path the cut takes (also the
+    // non-deferred one, after a depth switch between prime and cut) they are spent now, and a gradient primed later
+    // by a fused pass (rank-1 + GEMV, apply + GEMV) has none.
+    const int dots_np_now = s->dots_np;
+    s->dots_np = 0;
     ProfScope ps(s, CLS_SCALAR);
     EllCalcDev calc = EllCalcDev::make(s->n, s->use_parallel_cut);
     const unsigned G = (unsigned)scalar_groups(s->n);
@@ -560,19 +605,24 @@ int do_cut(ellhip_space* s, const double* g_dev, const CutParams* cp_dev, CutPar
         // cut as pending update number s->npend (optimistically counted; see ellhip_queue_results / callers)
         // The dot products come from k_symv_reduce when THIS gradient was primed by it at the depth in force
         // (dots_np); any other history (full-row GEMV, a shard, a depth or mode switch since) takes the separate launch.
-        const bool have_dots = s->dots_np == s->defer;
-        const int npart = have_dots ? (int)((s->n + 127) / 128) : (int)G;
+        const bool have_dots = dots_np_now == s->defer;
+        const bool gy_inside = have_dots && s->dots_need_gy;
+        const int npart = (have_dots && !gy_inside) ? (int)((s->n + 127) / 128) : (int)G;
 #define SCALAR_DEF(NPV)                                                                                           \
     if (!have_dots)                                                                                               \
         hipLaunchKernelGGL(k_scalar_dot_def<NPV>, dim3(G), dim3(256), 0, s->stream, s->n, g_dev, gt,               \
                            (const double*)s->d_pend, s->d_partial, s->d_st);                                      \
-    hipLaunchKernelGGL(k_scalar_apply_def<NPV>, dim3(G), dim3(256), 0, s->stream, s->n, gt, s->d_xc, s->d_pend,    \
-                       s->d_cpend, (const double*)s->d_partial, s->d_st, calc, cp_dev, cp_val, s->npend, queue_mode, \
-                       qst, qtsq, npart)
+    if (gy_inside)                                                                                                \
+        hipLaunchKernelGGL((k_scalar_apply_def<NPV, true>), dim3(G), dim3(256), 0, s->stream, s->n, gt, s->d_xc,   \
+                           s->d_pend, s->d_cpend, (const double*)s->d_partial, s->d_st, calc, cp_dev, cp_val,     \
+                           s->npend, queue_mode, qst, qtsq, npart, g_dev);                                        \
+    else                                                                                                          \
+        hipLaunchKernelGGL(k_scalar_apply_def<NPV>, dim3(G), dim3(256), 0, s->stream, s->n, gt, s->d_xc, s->d_pend, \
+                           s->d_cpend, (const double*)s->d_partial, s->d_st, calc, cp_dev, cp_val, s->npend,      \
+                           queue_mode, qst, qtsq, npart, (const double*)nullptr)
         if (s->defer == 16) { SCALAR_DEF(16); } else { SCALAR_DEF(8); }
 #undef SCALAR_DEF
         HIPCHK(hipGetLastError());
-        s->dots_np = 0;  // consumed: the recorded vectors change with this cut
         s->npend += 1;
         return 0;
     }
@@ -1035,6 +1085,7 @@ int ellhip_clone(const ellhip_space* src_c, ellhip_space** out) {
     s->symv_min_n = src->symv_min_n;
     s->apply_lower = src->apply_lower;
     s->apply_kernel = src->apply_kernel;
+    s->fuse_dots = src->fuse_dots;
     s->shard_symmetric = src->shard_symmetric;
     s->upper_stale = src->upper_stale;
     s->symv_seg = src->symv_seg;
