@@ -402,3 +402,29 @@ def test_long_run_stays_inside_the_parity_tolerance(gpu, orc, depth, monkeypatch
         assert_state_close(e, o, what=f"depth {depth} after {upto} updates")
     st, ts = e.queue_results()
     assert np.all(st == 0)
+
+
+@pytest.mark.parametrize("n,depth", [(40, 8), (640, 8), (640, 16)])
+def test_depth_switches_between_prime_and_cut_do_not_leak_dot_products(gpu, orc, n, depth, monkeypatch):
+    """A prime on a recorded schedule leaves the scalar stage's dot products behind for the NEXT cut.  If the depth is
+    switched to 1 before that cut, a fused pass primes the following gradient without any, and the depth is switched
+    back, the old ones must not be taken for the new gradient's."""
+    monkeypatch.setenv("ELLHIP_SYMV_MIN_N", "512")
+    rng = np.random.default_rng(77)
+    gs = [rng.standard_normal(n) for _ in range(6)]
+    e = gpu.Ell.new_with_scalar(1.0, np.zeros(n))
+    o = orc.OracleEll.new_with_scalar(1.0, np.zeros(n))
+    e.defer_depth = depth
+    for g in gs[:3]:                                   # a few recorded updates first
+        assert int(e.update_bias_cut((g, 0.01))) == o.update(0, g, 0.01) == 0
+    e.prime(gs[3])                                     # dot products of gs[3] are in place
+    e.defer_depth = 1                                  # (applies the recorded updates, re-primes)
+    assert int(e.cut(0, (0.01, None))) == o.update(0, gs[3], 0.01) == 0
+    e.commit(gs[4])                                    # fused rank-1 + GEMV primes gs[4]: no dot products
+    e.defer_depth = depth
+    assert int(e.cut(0, (0.01, None))) == o.update(0, gs[4], 0.01) == 0
+    assert abs(e.tsq() - o.tsq) <= 1e-10 * abs(o.tsq)
+    e.commit(gs[5])
+    assert int(e.cut(0, (0.01, None))) == o.update(0, gs[5], 0.01) == 0
+    e.commit(None)
+    assert_state_close(e, o, what=f"n={n} depth {depth}")
