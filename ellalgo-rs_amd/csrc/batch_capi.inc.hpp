@@ -45,14 +45,22 @@ int batch_shape(ellhip_batch* h) {
     if (h->epw < 1) h->epw = 1;
     h->lds_bytes = (size_t)h->epw * per_bytes;
     if (h->lds_bytes > 160 * 1024) return fail(ELLHIP_E_INVALID, "batched engine: n too large for LDS");
-    // more than the default 64 KiB of dynamic LDS needs an opt-in per kernel
+    // more than the default 64 KiB of dynamic LDS needs an opt-in per kernel.  The attribute belongs to the kernel,
+    // not to this handle: it is only ever RAISED, so that a handle with a larger footprint created earlier keeps
+    // launching after a smaller one has been set up.
+    static std::atomic<int> granted[3] = {{0}, {0}, {0}};
+    const int slot = h->T == 64 ? 0 : (h->T == 128 ? 1 : 2);
+    if ((int)h->lds_bytes > granted[slot].load()) {
 #define BATCH_ATTR(TT)                                                                         \
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_batch_update<TT>),             \
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes))
-    if (h->T == 64) BATCH_ATTR(64);
-    else if (h->T == 128) BATCH_ATTR(128);
-    else BATCH_ATTR(256);
+        if (h->T == 64) BATCH_ATTR(64);
+        else if (h->T == 128) BATCH_ATTR(128);
+        else BATCH_ATTR(256);
 #undef BATCH_ATTR
+        int seen = granted[slot].load();
+        while (seen < (int)h->lds_bytes && !granted[slot].compare_exchange_weak(seen, (int)h->lds_bytes)) {}
+    }
     return 0;
 }
 

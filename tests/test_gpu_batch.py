@@ -236,3 +236,17 @@ def test_cpp_batch_mirror_runs_config1_in_bulk(gpu):
         # this problem's optimum lies outside the start ball, so 2000 cuts amplify the engines' 1e-16 differences
         assert abs(r["gamma_batch"] - r["gamma_single"]) <= 1e-3 * r["gamma_single"], r
         assert r["max_dx"] < 1.0, r
+
+
+def test_two_populations_with_different_lds_footprints(gpu, orc):
+    """The dynamic-LDS opt-in belongs to the kernel, not to a handle: a population with a large footprint (n = 100)
+    must keep launching after a small one (n = 8) has been set up, and the other way round."""
+    rng = np.random.default_rng(3)
+    big = gpu.EllBatch.new_with_scalar(np.ones(3), np.zeros((3, 100)))
+    small = gpu.EllBatch.new_with_scalar(np.ones(5), np.zeros((5, 8)))
+    for batch, n, B in ((big, 100, 3), (small, 8, 5), (big, 100, 3)):
+        g = rng.standard_normal((1, B, n))
+        st, _ = batch.update(np.zeros((1, B), dtype=np.int32), g, np.full((1, B), 0.01))
+        assert np.all(st == 0)
+    o = orc.OracleEll.new_with_scalar(1.0, np.zeros(8))
+    assert np.isfinite(small.tsq()).all() and np.isfinite(big.tsq()).all()
