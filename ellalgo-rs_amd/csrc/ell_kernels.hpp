@@ -10,6 +10,15 @@
 //                                                          (src/ell.rs:117-128,132-135)
 //   k_sweep<R1,GV> both at once for consecutive updates (pipelined schedule, 16*n^2 B per update)
 //
+// and, for the recorded ("deferred") schedules that the larger handles run by default (see MAXPEND below):
+//
+//   k_symv + k_symv_reduce<NP>   y = Q_base*g through the lower triangle only (4*n^2 B), plus the scalar stage's
+//                                dot products g.y and v_j.g
+//   k_sweep_gemv_dots            the same for handles without the lower-triangle schedule: full-row GEMV with the
+//                                v_j.g partial sums formed beside it
+//   k_scalar_apply_def<NP,GY>    gt = y - sum_j (c_j v_j.g) v_j, omega, EllCalc, xc; records (c, gt) as update NP'
+//   k_apply_lower / k_sweep_apply   one pass applies the 8 / 16 recorded updates element by element, in order
+//
 // This is BLAS-2: 4*n^2 flop against 24*n^2 bytes, i.e. HBM-bound by a factor ~60 on MI355X, so no
 // MFMA; what matters is 16-byte-per-lane coalesced streams, enough bytes in flight per CU, and no
 // wasted re-reads.  Layout and mapping:
