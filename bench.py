@@ -471,7 +471,14 @@ def main() -> None:
     lib = pkg.capi.load()
     n, variant, cutgen, desc = WORKLOADS[args.workload]
     K, W, P = args.steps, args.warmup, args.profile_steps
-    H = args.host_path_steps if not sharded else 0
+    # EllStable does not shard (its triangular solves are sequential along the partitioned dimension): with N > 1
+    # every rank runs an independent replica on its own GPU, no collective in the data path ("replicas only",
+    # DESIGN.md section 7); the process group is used for the fences and the max-over-ranks clock only.
+    multi = sharded
+    replicas = sharded and variant != "ell"
+    if replicas:
+        sharded = False
+    H = args.host_path_steps if not multi else 0
     fused = args.schedule == "pipelined" and variant == "ell"
     depth = args.defer if variant == "ell" else 1
     if depth == 0:  # auto: 16 pending updates per apply pass where the lower-triangle schedule runs, else 8
@@ -503,9 +510,7 @@ def main() -> None:
             if alt != (args.schedule, depth):
                 alts.append(alt)
     total = W + K + P + 2 * C2 * len(alts) + H
-    if sharded and variant != "ell":
-        raise SystemExit("EllStable does not shard: replicas only (see DESIGN.md)")
-    if n % world and not shard_sym:
+    if sharded and n % world and not shard_sym:
         raise SystemExit(f"n={n} is not divisible by {world} ranks")
 
     t_gen = time.perf_counter()
@@ -531,7 +536,7 @@ def main() -> None:
 
     def fence() -> None:
         torch.cuda.synchronize()
-        if sharded:
+        if multi:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -550,7 +555,7 @@ def main() -> None:
     fence()
     t1 = time.perf_counter()
     elapsed = t1 - t0
-    if sharded:
+    if multi:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -629,9 +634,9 @@ def main() -> None:
         dist.destroy_process_group()
         return
 
-    n2w = float(n) * float(n) / world  # n^2 per GPU
+    n2w = float(n) * float(n) / (1 if replicas else world)  # n^2 per GPU
     ms_per_step = elapsed / K * 1e3
-    value = K / elapsed
+    value = K / elapsed * (world if replicas else 1)  # replicas: every rank completed K updates of its own
     # algorithmic bytes per launch of each kernel class (per GPU)
     symv_mode = ((not sharded) and n % 2 == 0 and n >= int(os.environ.get("ELLHIP_SYMV_MIN_N", "8192"))
                  and os.environ.get("ELLHIP_SYMV", "1") != "0") or shard_sym
@@ -724,7 +729,7 @@ def main() -> None:
         "warmup": W,
         "ms_per_step": ms_per_step,
         "higher_is_better": True,
-        "scaling": "strong",
+        "scaling": "weak" if replicas else "strong",
         "vs_baseline": None,
         "dtype": "f64",
         "data": "synthetic",
@@ -733,8 +738,10 @@ def main() -> None:
                    "defer_depth": depth,
                    "description": desc,
                    "partition": (f"symmetric row shards x{world} (boundaries at n*sqrt(r/P), all-reduce)" if shard_sym
-                                 else f"row-block x{world} (all-gather)") if sharded else "none",
-                   "q_bytes_per_gpu": 8.0 * n * n / world},
+                                 else f"row-block x{world} (all-gather)") if sharded
+                                else (f"replicas only x{world} (independent search spaces, no data-path collective)"
+                                      if replicas else "none"),
+                   "q_bytes_per_gpu": 8.0 * n * n / (1 if replicas else world)},
         "roofline": roofline,
     }
     if others:
@@ -745,7 +752,7 @@ def main() -> None:
         log("[rank 0] timing the CPU oracle (bounded sample) ...")
         out["cpu_baseline"] = cpu_baseline(n, variant, kinds, grads, b0, b1, args.cpu_budget)
     print(json.dumps(out), file=real_stdout, flush=True)
-    if sharded:
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
 
