@@ -437,6 +437,9 @@ def main() -> None:
                     help="run the row-partitioned (multi-GPU) code path even with one rank (rehearsal)")
     args = ap.parse_args()
 
+    if args.workload in LOWPASS_WORKLOADS or args.workload in BATCH_WORKLOADS or args.workload in LMI_WORKLOADS:
+        if args.gpus != 1 or int(os.environ.get("WORLD_SIZE", "1")) != 1:
+            raise SystemExit(f"{args.workload} is a single-GPU workload (rows f2-f4 of the scope table): run it with --gpus 1")
     if args.workload in LOWPASS_WORKLOADS:
         return lowpass_bench(args, real_stdout)
     if args.workload in BATCH_WORKLOADS:
