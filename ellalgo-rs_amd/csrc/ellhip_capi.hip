@@ -512,6 +512,9 @@ int symv_alloc(ellhip_space* s) {
     // 0.067; P = 2: 0.109 vs 0.104; unsharded n = 8192, 256 tiles: 0.076 vs 0.066)
     const double area = ((double)(s->row0 + s->nrows) * (double)(s->row0 + s->nrows) - (double)s->row0 * (double)s->row0) / 2.0;
     s->symv_seg = (area / (64.0 * SYMV_SEG) < 200.0) ? SYMV_SEG_SMALL : SYMV_SEG;
+    // rows in flight per thread: with about one 64 x 2048 tile per CU (n = 8192: 256 tiles) the workgroup itself has to
+    // keep more loads in the air -- 4 rows: 61 vs 65 us per pass; with several tiles per CU (n = 16384) 2 and 4 tie
+    if (!getenv("ELLHIP_SYMV_RW")) s->symv_rw = (area / (64.0 * SYMV_SEG) < 600.0) ? 4 : 2;
     s->symv_seg = env_int("ELLHIP_SYMV_SEG", s->symv_seg);
     if (s->symv_seg != SYMV_SEG && s->symv_seg != SYMV_SEG_SMALL) return fail(ELLHIP_E_INVALID, "ELLHIP_SYMV_SEG must be 512 or 2048");
     const size_t nsegs = (size_t)((s->n + s->symv_seg - 1) / s->symv_seg), nstrips = (size_t)((s->nrows + SYMV_H - 1) / SYMV_H);
