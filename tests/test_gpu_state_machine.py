@@ -12,6 +12,10 @@ from util import TOL, assert_state_close, beta_of, mixed_cut
 
 pytestmark = pytest.mark.gpu
 
+# more walks for a soak run:  ELLHIP_FUZZ_SEEDS=200 python -m pytest tests/test_gpu_state_machine.py
+import os
+_EXTRA = int(os.environ.get("ELLHIP_FUZZ_SEEDS", "0"))
+
 
 def _tau(o, g):
     return float(np.sqrt(max(o.kappa * (g @ (o.mq @ g)), 0.0)))
@@ -182,7 +186,7 @@ class Walk:
         assert_state_close(self.g, self.o, what=f"final: {self.log[-6:]}")
 
 
-@pytest.mark.parametrize("seed", range(12))
+@pytest.mark.parametrize("seed", range(max(12, _EXTRA)))
 @pytest.mark.parametrize("n", [40, 129, 640, 1024])
 def test_random_walks_match_oracle(gpu, orc, n, seed, monkeypatch):
     monkeypatch.setenv("ELLHIP_SYMV_MIN_N", "512")   # n = 640, 1024 run the lower-triangle schedule at depth 8 / 16
@@ -190,7 +194,7 @@ def test_random_walks_match_oracle(gpu, orc, n, seed, monkeypatch):
     Walk(gpu, orc, n, 7000 + 31 * seed + n, depths).run(36)
 
 
-@pytest.mark.parametrize("seed", range(6))
+@pytest.mark.parametrize("seed", range(max(6, _EXTRA // 2)))
 @pytest.mark.parametrize("n", [40, 129, 300])
 def test_random_walks_match_oracle_ellstable(gpu, orc, n, seed):
     """EllStable (src/ell_stable.rs) under the same drivers: the whole buffer -- diagonal, factor and the scratch
@@ -304,7 +308,7 @@ class ShardWalk:
         self.check("final")
 
 
-@pytest.mark.parametrize("seed", range(5))
+@pytest.mark.parametrize("seed", range(max(5, _EXTRA // 2)))
 @pytest.mark.parametrize("n,symmetric", [(96, False), (640, False), (640, True), (1024, True)])
 def test_random_walks_match_oracle_row_shard(gpu, orc, n, symmetric, seed):
     ShardWalk(gpu, orc, n, 11000 + 13 * seed + n + int(symmetric), symmetric).run(24)
