@@ -61,7 +61,7 @@ class Walk:
             del c
         elif r == 3:
             assert np.max(np.abs(self.g.xc() - self.o.xc)) <= TOL * max(np.max(np.abs(self.o.xc)), 1e-300), self.log[-12:]
-        elif r == 4 and not self.g.no_defer_trick:
+        elif r == 4:   # (also while no_defer_trick is on: the depth is kept and takes effect when the flag goes off)
             self.g.defer_depth = int(self.rng.choice(self.depths))
         # 5, 6: nothing
 
@@ -162,20 +162,19 @@ class Walk:
         self.o = self.o.clone()
 
     def op_depth(self):
-        if not self.g.no_defer_trick:
-            self.g.defer_depth = int(self.rng.choice(self.depths))
+        self.g.defer_depth = int(self.rng.choice(self.depths))
 
     def op_no_defer_trick(self):
+        # whatever depth is in force: the scaled data flow rewrites Q at every cut, so the recorded schedule is
+        # suspended while the flag is on (ellhip.h) and resumes afterwards
         flag = not self.g.no_defer_trick
-        if flag:
-            self.g.defer_depth = 1   # (the scaled data flow rewrites Q at every cut)
         self.g.no_defer_trick = flag
         self.o.set_no_defer_trick(flag)
 
     def run(self, nops):
         ops = [self.op_update, self.op_pipelined, self.op_queue, self.op_set_xc, self.op_clone, self.op_depth,
                self.op_no_defer_trick]
-        weights = np.array([3, 4, 4, 1, 1, 0, 0] if self.stable else [3, 4, 4, 1, 1, 2, 0.5], dtype=float)
+        weights = np.array([3, 4, 4, 1, 1, 0, 0] if self.stable else [3, 4, 4, 1, 1, 2, 1], dtype=float)
         for k in range(nops):
             op = ops[int(self.rng.choice(len(ops), p=weights / weights.sum()))]
             self.log.append(op.__name__ if self.stable else f"{op.__name__}[depth {self.g.defer_depth}]")
