@@ -26,6 +26,9 @@ class OracleShardEngine:
         self.q = None
         self.halted = False
         self.pending = None
+        self.primed = -1            # queue index whose GEMV is in place (ellhip_queue_primed)
+        self.drop_on_flush = False  # emulate a shard on a recorded schedule: flush / mq_rows / a depth switch apply
+                                    # recorded updates, which invalidates a primed GEMV (the real library drops it)
 
     symmetric = False
 
@@ -35,7 +38,7 @@ class OracleShardEngine:
         self.symmetric = bool(flag)
 
     def set_defer_depth(self, depth):
-        pass
+        self._observer()
 
     # ---- the three primitives (mirror of prime / cut / commit in csrc/ellhip_capi.hip)
     def _gemv(self, g):
@@ -102,11 +105,14 @@ class OracleShardEngine:
         if not self.halted:
             self.cut = self._qcut(i)
             self._gemv(self.cut[1])
+            self.primed = i
 
     def queue_cut(self, i):
         if self.halted:
             self.qstatus[i] = 3
             return
+        assert self.primed == i, f"cut {i} taken without its GEMV in place (primed: {self.primed})"
+        self.primed = -1
         self.cut = self._qcut(i)
         st = self._scalar()
         self.qstatus[i], self.qtsq[i] = st, self.tsqv
@@ -119,6 +125,7 @@ class OracleShardEngine:
         self._shrink()
         if nxt >= 0:
             self._gemv(self._qcut(nxt)[1])   # GEMV of the next cut on the freshly shrunk rows
+            self.primed = nxt
 
     def queue_begin(self, i):
         self.queue_prime(i)
@@ -133,8 +140,20 @@ class OracleShardEngine:
 
     def xc(self): return self.xcv.copy()
     def set_xc(self, x): self.xcv = np.array(x, dtype=np.float64)
-    def mq_rows(self): return self.Q.copy()
+    def mq_rows(self):
+        self._observer()
+        return self.Q.copy()
     def kappa(self): return self.kap
     def tsq(self): return self.tsqv
     def synchronize(self): pass
-    def flush(self): pass
+
+    def queue_primed(self) -> int:
+        return self.primed
+
+    def _observer(self):
+        if self.drop_on_flush and self.primed >= 0:
+            self.primed = -1
+            self.gt_np[:] = np.nan   # whoever uses this vector without priming (and exchanging) again is caught
+
+    def flush(self):
+        self._observer()

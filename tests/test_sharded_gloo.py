@@ -66,7 +66,7 @@ def _worker(rank, world, port, n, k, mode, errq):
                     assert abs(sh.tsq() - ref.tsq) <= 1e-12 * abs(ref.tsq)
                 else:
                     assert sh.tsq() == ref.tsq
-        if mode in ("queue", "queue_fused"):
+        if mode in ("queue", "queue_fused", "queue_fused_observed"):
             # the queue halts at the first failure, so replay only the successful prefix rule: build a
             # fresh reference that stops like the drivers do
             ref = oracle.OracleEll.new_with_scalar(2.0, xc0)
@@ -77,6 +77,21 @@ def _worker(rank, world, port, n, k, mode, errq):
             sh.queue_upload(kinds, grads, b0s, b1s)
             if mode == "queue":
                 sh.queue_run(0, k)
+            elif mode == "queue_fused_observed":
+                # as bench.py drives a shard on a recorded schedule: flush / look at the rows / switch the depth between
+                # pipelined runs; each of those drops the shard's primed GEMV (here: poisoned with NaN), and every rank
+                # has to prime -- and exchange -- again before the next cut
+                sh.engine.drop_on_flush = True
+                sh.queue_run(0, 3, fused=True)
+                sh.flush()
+                assert sh._primed_index == -1
+                sh.queue_run(3, 4, fused=True)
+                _ = sh.mq_rows
+                assert sh._primed_index == -1
+                sh.queue_run(7, 2, fused=True)
+                sh.set_defer_depth(8)
+                sh.queue_run(9, k - 9, fused=True)
+                sh.engine.drop_on_flush = False
             else:   # pipelined schedule, split in two calls like the benchmark (warm-up, then timed)
                 sh.queue_run(0, 3, fused=True)
                 sh.queue_run(3, k - 3, fused=True)
@@ -140,6 +155,11 @@ def test_sharded_queue_bit_identical_and_halts():
 
 def test_sharded_pipelined_queue_bit_identical_and_halts():
     _run(2, 48, 16, "queue_fused")
+
+
+@pytest.mark.parametrize("mode,n", [("queue_fused_observed", 64), ("sym_queue_fused_observed", 192)])
+def test_sharded_pipelined_queue_with_observers_between_runs(mode, n):
+    _run(2, n, 20, mode)
 
 
 @pytest.mark.parametrize("world,n,mode", [(2, 128, "sym_direct"), (3, 320, "sym_direct"), (2, 192, "sym_queue_fused"),
