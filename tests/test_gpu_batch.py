@@ -250,3 +250,62 @@ def test_two_populations_with_different_lds_footprints(gpu, orc):
         assert np.all(st == 0)
     o = orc.OracleEll.new_with_scalar(1.0, np.zeros(8))
     assert np.isfinite(small.tsq()).all() and np.isfinite(big.tsq()).all()
+
+
+@pytest.mark.parametrize("seed", range(6))
+@pytest.mark.parametrize("n", [3, 16, 40, 100])
+def test_random_walk_over_the_batch_api_is_exact(gpu, orc, n, seed):
+    """Random sequences of the batched engine's calls -- launches of 1..7 cuts per ellipsoid, centres replaced, the
+    two flags toggled between launches -- against one CPU oracle per ellipsoid: every status, tsq and the whole
+    state bit for bit."""
+    rng = np.random.default_rng(5000 + 37 * seed + n)
+    B = int(rng.integers(1, 9))
+    kappa = 0.5 + 2.0 * rng.random(B)
+    xc0 = rng.standard_normal((B, n))
+    batch = gpu.EllBatch.new_with_scalar(kappa, xc0)
+    ors = [orc.OracleEll.new_with_scalar(kappa[b], xc0[b]) for b in range(B)]
+    it = 0
+    ndt = False
+    par = True
+    for _ in range(12):
+        r = rng.random()
+        if r < 0.15:
+            x = rng.standard_normal((B, n))
+            batch.set_xc(x)
+            for b, o in enumerate(ors):
+                o.set_xc(x[b])
+        elif r < 0.25:
+            ndt = not ndt
+            batch.set_no_defer_trick(ndt)
+            for o in ors:
+                o.set_no_defer_trick(ndt)
+        elif r < 0.32:
+            par = not par
+            batch.set_use_parallel_cut(par)
+            for o in ors:
+                o.set_use_parallel_cut(par)
+        else:
+            K = int(rng.integers(1, 8))
+            kinds = np.zeros((K, B), dtype=np.int32)
+            grads = np.zeros((K, B, n))
+            b0 = np.zeros((K, B))
+            b1 = np.full((K, B), np.nan)
+            want = np.zeros((K, B), dtype=np.int32)
+            want_tsq = np.zeros((K, B))
+            for k in range(K):
+                for b, o in enumerate(ors):
+                    g = rng.standard_normal(n)
+                    tau = np.sqrt(max(o.kappa * float(g @ (o.mq @ g)), 0.0))
+                    kind, c0, c1 = mixed_cut(it + b, g, tau, rng)
+                    kinds[k, b], grads[k, b], b0[k, b] = kind, g, c0
+                    if c1 is not None:
+                        b1[k, b] = c1
+                    want[k, b] = o.update(kind, g, c0, c1)
+                    want_tsq[k, b] = o.tsq
+                it += 1
+            status, tsq = batch.update(kinds, grads, b0, b1)
+            np.testing.assert_array_equal(status, want)
+            np.testing.assert_array_equal(tsq, want_tsq)
+    np.testing.assert_array_equal(batch.mq, np.stack([o.mq for o in ors]))
+    np.testing.assert_array_equal(batch.xc(), np.stack([np.array(o.xc) for o in ors]))
+    np.testing.assert_array_equal(batch.kappa, np.array([o.kappa for o in ors]))
