@@ -4,7 +4,6 @@ arithmetic.  Cuts are arrays over the batch: `grads[B][n]`, `beta0[B]`, `beta1[B
 from __future__ import annotations
 
 import ctypes as C
-from typing import Optional
 
 import numpy as np
 

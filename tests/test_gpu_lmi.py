@@ -1,7 +1,6 @@
 """GPU: LDLTMgr / LMIOracle / LMI0Oracle on the device (include/ellhip_lmi.h) against the CPU oracle and the
 reference's own known answers, through the C ABI.  The factor (`storage` on every row the reference touches),
 `pos` and ep are compared EXACTLY; the witness and the cut gradient to rounding."""
-import math
 
 import numpy as np
 import pytest

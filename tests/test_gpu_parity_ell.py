@@ -5,7 +5,7 @@ import ctypes as C
 import numpy as np
 import pytest
 
-from util import TOL, assert_state_close, beta_of, rel_inf, run_mixed
+from util import assert_state_close, run_mixed
 
 pytestmark = pytest.mark.gpu
 

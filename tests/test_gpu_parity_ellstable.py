@@ -3,7 +3,7 @@ the reference's one-step known answers (src/ell_stable.rs:217-307)."""
 import numpy as np
 import pytest
 
-from util import TOL, assert_state_close, run_mixed
+from util import assert_state_close, run_mixed
 
 pytestmark = pytest.mark.gpu
 
