@@ -378,8 +378,8 @@ def cpu_baseline(n: int, variant: str, kinds, grads, b0, b1, budget_s: float = 2
     extra = None
     if variant == "ell":  # an all-cores line next to the reference's single-threaded loop, labelled as such
         om = cls.new_with_scalar(1.0, np.zeros(n))
-        nthr = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-        os.environ.setdefault("OMP_NUM_THREADS", str(nthr))
+        # the CPUs this job may really use (affinity capped by the cgroup quota), unless OMP_NUM_THREADS says otherwise
+        nthr = oracle.set_num_threads(0 if os.environ.get("OMP_NUM_THREADS") else oracle.cpu_share())
         d2, t2 = 0, 0.0
         while d2 < len(kinds) and (d2 < 3 or t2 < min(budget_s, 8.0)):
             t1 = time.perf_counter()

@@ -284,6 +284,19 @@ int orc_ell_update_rowwise(orc_ell *e, int kind, const double *grad, double b0, 
 /* NOT the reference's loop: the same arithmetic with the rows of the GEMV and of the row-wise rank-1 spread over
  * OpenMP threads (each row's sum is still a left fold; omega is folded serially), for the "all cores" line of
  * bench.py's cpu_baseline.  Bit-identical to orc_ell_update_rowwise.  Symmetric Q only. */
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+int orc_set_num_threads(int nthreads) {
+#ifdef _OPENMP
+    if (nthreads > 0) omp_set_num_threads(nthreads);
+    return omp_get_max_threads();
+#else
+    (void)nthreads;
+    return 1;
+#endif
+}
+
 int orc_ell_update_rowwise_mt(orc_ell *e, int kind, const double *grad, double b0, int has_b1, double b1) {
     const int64_t n = e->n;
     double *gt = e->gt;

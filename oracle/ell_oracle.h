@@ -80,6 +80,8 @@ int orc_ell_update_rowwise(orc_ell *e, int kind, const double *grad, double b0, 
 /* NOT the reference's loop: orc_ell_update_rowwise with its rows spread over OpenMP threads (bit-identical to
  * it); for the "all cores" line of bench.py's cpu_baseline only. */
 int orc_ell_update_rowwise_mt(orc_ell *e, int kind, const double *grad, double b0, int has_b1, double b1);
+/* Size of the OpenMP team of the _mt variant (0 = leave the runtime's default); returns the size in force. */
+int orc_set_num_threads(int nthreads);
 double orc_ell_kappa(const orc_ell *e);
 double orc_ell_tsq(const orc_ell *e);
 double *orc_ell_mq(orc_ell *e);

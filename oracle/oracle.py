@@ -102,6 +102,8 @@ def lib():
         L.orc_ell_update_rowwise.restype = C.c_int
         L.orc_ell_update_rowwise_mt.argtypes = L.orc_ell_update.argtypes
         L.orc_ell_update_rowwise_mt.restype = C.c_int
+        L.orc_set_num_threads.argtypes = [C.c_int]
+        L.orc_set_num_threads.restype = C.c_int
         L.orc_ell_set_no_defer_trick.argtypes = [C.c_void_p, C.c_int]
         L.orc_ell_set_use_parallel_cut.argtypes = [C.c_void_p, C.c_int]
         L.orc_ellstable_set_corrected.argtypes = [C.c_void_p, C.c_int]
@@ -291,6 +293,25 @@ class OracleEllStable(_Space):
     _pre = "orc_ellstable"
 
     def set_corrected(self, flag): lib().orc_ellstable_set_corrected(self.h, int(flag))
+
+
+def set_num_threads(nthreads: int = 0) -> int:
+    """OpenMP team of update_rowwise_mt (0: leave as is); returns the team size in force."""
+    return int(lib().orc_set_num_threads(int(nthreads)))
+
+
+def cpu_share() -> int:
+    """CPUs this process may really use: the affinity mask, capped by the cgroup's CPU quota when there is one (a GPU
+    box shows every logical CPU of the host to a job that owns a 16-CPU share)."""
+    import os
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = max(1, min(n, -(-int(quota) // int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
 
 
 def rows_gemv(n, row0, nrows, mq_local, grad, gt_full):
