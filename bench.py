@@ -42,8 +42,8 @@ WORKLOADS = {
     "n4096-deep": (4096, "ell", "deep", "config 2: n=4096 Ell, deep cuts (Q=128 MiB fits the 256 MiB Infinity Cache)"),
     "n8192-deep": (8192, "ell", "deep", "n=8192 Ell, deep cuts"),
     "n32768-deep": (32768, "ell", "deep", "config 4: n=32768 Ell, deep cuts (8 GiB Q)"),
-    "n16384-ellstable": (16384, "ellstable", "deep", "config 5: n=16384 EllStable, deep cuts"),
-    "n4096-ellstable": (4096, "ellstable", "deep", "n=4096 EllStable, deep cuts"),
+    "n16384-ellstable": (16384, "ellstable", "deep", "config 5: n=16384 EllStable (random unit-triangular factor), deep cuts"),
+    "n4096-ellstable": (4096, "ellstable", "deep", "n=4096 EllStable (random unit-triangular factor), deep cuts"),
 }
 
 
@@ -363,7 +363,11 @@ def cpu_baseline(n: int, variant: str, kinds, grads, b0, b1, budget_s: float = 2
     from oracle import oracle
     cls = oracle.OracleEll if variant == "ell" else oracle.OracleEllStable
     t0 = time.perf_counter()
-    o = cls.new_with_scalar(1.0, np.zeros(n))
+    if variant == "ell":
+        o = cls.new_with_scalar(1.0, np.zeros(n))
+    else:  # the same non-trivial factor the GPU space started from (from the identity U and S stay exactly zero)
+        from ellalgo_rs_amd import synth
+        o = cls.new_with_matrix(1.0, synth.stable_factor(n), np.zeros(n))
     t_init = time.perf_counter() - t0
     done, t_used = 0, 0.0
     while done < len(kinds) and (done < 2 or t_used < budget_s):
@@ -523,8 +527,14 @@ def main() -> None:
     # ---- build the search space (Q0 = I, xc0 = 0, kappa0 = 1)
     nrows = n // world
     row0 = rank * nrows
-    if not sharded:
-        space = (pkg.Ell if variant == "ell" else pkg.EllStable).new_with_scalar(1.0, np.zeros(n), device=local_rank)
+    if not sharded and variant != "ell":
+        # EllStable starts from a NON-trivial packed state (random unit-upper-triangular factor, random positive
+        # diagonal, junk in the scratch triangle; EllStable::new_with_matrix, src/ell_stable.rs:18-27): from the
+        # identity the bug-compatible arithmetic keeps the factor and the scratch triangle exactly zero
+        # and the solves would stream zeros.
+        space = pkg.EllStable.new_with_matrix(1.0, synth.stable_factor(n), np.zeros(n), device=local_rank)
+    elif not sharded:
+        space = pkg.Ell.new_with_scalar(1.0, np.zeros(n), device=local_rank)
     else:
         from ellalgo_rs_amd.sharded import ShardedEll
         space = ShardedEll.new_with_scalar(1.0, np.zeros(n), device=local_rank, symmetric=shard_sym,

@@ -75,3 +75,30 @@ def parallel_cuts(n: int, k: int, seed0: int = SEED0):
             beta0[i] = 0.05 * u[2 * i]
             beta1[i] = beta0[i] + 0.05 + 0.40 * u[2 * i + 1]
     return kinds, grads, beta0, beta1
+
+
+def stable_factor(n: int, seed: int = 0x5EEDFAC7, chunk_rows: int = 1024) -> np.ndarray:
+    """A non-trivial packed EllStable state for `EllStable::new_with_matrix` (src/ell_stable.rs:18-27): one n x n
+    row-major buffer with a positive diagonal d ~ U[0.5, 1.5), a unit-upper-triangular factor whose strict upper
+    entries are N(0, 1) * 0.1 / sqrt(n) (so every row of L stays O(0.1) in norm) and a strict lower (scratch)
+    triangle filled with junk of the same size -- the reference overwrites every scratch entry in the forward solve
+    before anything reads it (src/ell_stable.rs:61-69), so the junk must never show in a result.  With the identity
+    factor of `new_with_scalar` the strict upper and scratch triangles stay exactly zero forever, which
+    exercises none of the triangular-solve arithmetic; this factor does."""
+    m = np.empty((n, n), dtype=np.float64)
+    scale = 0.1 / np.sqrt(float(n))
+    for r0 in range(0, n, chunk_rows):
+        rows = min(chunk_rows, n - r0)
+        cnt = rows * n
+        cnt2 = cnt + (cnt & 1)
+        u = uniform01(seed + 7919 * (r0 // chunk_rows + 1), cnt2)
+        h = cnt2 // 2
+        rad = np.sqrt(-2.0 * np.log(u[:h]))
+        ang = 2.0 * np.pi * u[h:]
+        z = np.empty(cnt2, dtype=np.float64)
+        z[0::2] = rad * np.cos(ang)
+        z[1::2] = rad * np.sin(ang)
+        m[r0:r0 + rows] = (scale * z[:cnt]).reshape(rows, n)
+    d = 0.5 + uniform01(seed ^ 0xD1A6, n)
+    m[np.arange(n), np.arange(n)] = d
+    return m

@@ -154,21 +154,38 @@ def test_ell_default_schedule_matches_oracle_at_full_size(gpu, orc):
 
 
 def test_ellstable_matches_oracle_at_full_size(gpu, orc):
-    """BASELINE config 5 (n = 16384 EllStable, deep cuts): the persistent flag-chained solves over all 128
-    column strips against the CPU oracle -- diagonal, factor AND scratch triangle, xc, kappa, tsq."""
+    """BASELINE config 5 (n = 16384 EllStable, deep cuts) from the NON-trivial factor bench.py uses
+    (synth.stable_factor: random unit-upper-triangular factor, random positive diagonal, junk in the scratch
+    triangle -- from the identity the off-diagonal part of the buffer stays exactly zero and the comparison would be
+    one of zeros): the persistent flag-chained solves over all 128 column strips against the serial CPU oracle --
+    diagonal, factor AND scratch triangle (each on its own scale), xc, kappa, tsq."""
     from ellalgo_rs_amd import synth
     from util import TOL
     k = 3
     kinds, grads, b0, _ = synth.deep_cuts(N, k)
-    e = gpu.EllStable.new_with_scalar(1.0, np.zeros(N))
-    o = orc.OracleEllStable.new_with_scalar(1.0, np.zeros(N))
+    f = synth.stable_factor(N)
+    e = gpu.EllStable.new_with_matrix(1.0, f, np.zeros(N))
+    o = orc.OracleEllStable.new_with_matrix(1.0, f, np.zeros(N))
+    del f
     for i in range(k):
         assert int(e.update_bias_cut((grads[i], float(b0[i])))) == o.update(0, grads[i], b0[i]) == 0
         assert abs(e.tsq() - o.tsq) <= TOL * abs(o.tsq)
     assert abs(e.kappa - o.kappa) <= TOL * abs(o.kappa)
     xo = np.array(o.xc)
     assert np.max(np.abs(e.xc() - xo)) <= TOL * np.max(np.abs(xo))
-    _close_in_blocks(e.mq, o.mq, TOL, "n=16384 EllStable")
+    qg, qo = e.mq, o.mq
+    _close_in_blocks(qg, qo, TOL, "n=16384 EllStable")
+    # the triangles separately (the scratch products are ~1e-3 of the diagonal's scale), on row bands
+    for r in (0, 4096 - 64, 8192 - 64, N - 1024):
+        a, b = qg[r:r + 1024], qo[r:r + 1024]
+        cols = np.arange(N)[None, :]
+        rows = np.arange(r, r + a.shape[0])[:, None]
+        for name, mask in (("factor", cols > rows), ("scratch", cols < rows)):
+            if not mask.any():
+                continue
+            sc = float(np.max(np.abs(b[mask])))
+            assert sc > 0.0, f"{name} rows {r}: the oracle's triangle is all zero"
+            assert float(np.max(np.abs(a[mask] - b[mask]))) <= TOL * sc, f"{name} rows {r}"
 
 
 def test_ell_n32768_matches_oracle(gpu, orc):

@@ -11,7 +11,10 @@ pytestmark = pytest.mark.gpu
 def run_ell(gpu, variant, n, k, depth):
     from ellalgo_rs_amd import synth
     kinds, grads, b0, b1 = synth.parallel_cuts(n, k)
-    e = (gpu.EllStable if variant == "stable" else gpu.Ell).new_with_scalar(1.0, np.zeros(n))
+    if variant == "stable":   # non-trivial factor: the hand-off chains of the solves carry real data
+        e = gpu.EllStable.new_with_matrix(1.0, synth.stable_factor(n), np.zeros(n))
+    else:
+        e = gpu.Ell.new_with_scalar(1.0, np.zeros(n))
     if variant == "ell":
         e.defer_depth = depth   # explicit: with the lowered threshold a new handle would start at depth 16
     e.queue_upload(kinds, grads, b0, b1)

@@ -8,7 +8,7 @@ observers of Q in the middle of all of it -- must describe the same ellipsoid as
 import numpy as np
 import pytest
 
-from util import TOL, assert_state_close, beta_of, mixed_cut
+from util import TOL, assert_state_close, beta_of, mixed_cut, random_factor, stable_tau
 
 pytestmark = pytest.mark.gpu
 
@@ -18,6 +18,8 @@ _EXTRA = int(os.environ.get("ELLHIP_FUZZ_SEEDS", "0"))
 
 
 def _tau(o, g):
+    if type(o).__name__ == "OracleEllStable":   # its packed buffer is not the shape matrix: ask a clone
+        return stable_tau(o, g)
     return float(np.sqrt(max(o.kappa * (g @ (o.mq @ g)), 0.0)))
 
 
@@ -39,8 +41,13 @@ class Walk:
         self.depths = depths
         self.stable = stable
         xc0 = self.rng.standard_normal(n)
-        self.g = (gpu.EllStable if stable else gpu.Ell).new_with_scalar(3.0, xc0)
-        self.o = (orc.OracleEllStable if stable else orc.OracleEll).new_with_scalar(3.0, xc0)
+        if stable:   # a NON-trivial factor: from the identity U and the scratch triangle stay exactly zero
+            f = random_factor(n, 1000 + seed)
+            self.g = gpu.EllStable.new_with_matrix(3.0, f, xc0)
+            self.o = orc.OracleEllStable.new_with_matrix(3.0, f, xc0)
+        else:
+            self.g = gpu.Ell.new_with_scalar(3.0, xc0)
+            self.o = orc.OracleEll.new_with_scalar(3.0, xc0)
         self.i = 0
         self.log = []
 

@@ -73,3 +73,44 @@ def run_mixed(gpu_space, orc_space, k, seed, g_scale=1.0, check_every=0, tol=TOL
 
 def beta_of(b0, b1):
     return float(b0) if b1 is None else (float(b0), float(b1))
+
+
+def random_factor(n, seed, junk=True):
+    """Packed EllStable state with a NON-trivial factor (src/ell_stable.rs:18-27 accepts any matrix): positive random
+    diagonal, unit-upper-triangular factor with entries ~ 0.1/sqrt(n), and junk in the scratch triangle (the forward
+    solve overwrites every scratch entry before anything reads it, src/ell_stable.rs:61-69)."""
+    rng = np.random.default_rng(seed)
+    m = rng.standard_normal((n, n)) * (0.1 / np.sqrt(n))
+    if not junk:
+        m = np.triu(m)
+    m[np.arange(n), np.arange(n)] = 0.5 + rng.random(n)
+    return np.ascontiguousarray(m)
+
+
+def stable_tau(orc_space, g):
+    """tau = sqrt(tsq) the NEXT cut with gradient g will see: from a clone of the oracle (its packed buffer is not the
+    shape matrix, so g'Mg means nothing for EllStable)."""
+    c = orc_space.clone()
+    c.update(1, g, 0.0, None)   # a central cut always succeeds and sets tsq = kappa * omega
+    return float(np.sqrt(max(c.tsq, 0.0)))
+
+
+def run_mixed_stable(gpu_space, orc_space, k, seed, check_every=0, tol=TOL):
+    """run_mixed for EllStable with a non-trivial factor: the same adaptive sequence over all six EllCalc entry
+    points (incl. a NoSoln cut every 8th step), tau taken from the oracle itself."""
+    n = orc_space.n
+    rng = np.random.default_rng(seed)
+    nsucc = 0
+    for i in range(k):
+        g = rng.standard_normal(n)
+        g /= np.linalg.norm(g)
+        tau = stable_tau(orc_space, g)
+        kind, b0, b1 = mixed_cut(i, g, tau, rng)
+        so = orc_space.update(kind, g, b0, b1)
+        sg = gpu_space._update(kind, (g, beta_of(b0, b1)))
+        assert int(sg) == int(so), f"step {i}: status gpu={int(sg)} oracle={so}"
+        assert abs(gpu_space.tsq() - orc_space.tsq) <= tol * abs(orc_space.tsq) + 1e-300, f"step {i}: tsq"
+        nsucc += int(so == 0)
+        if check_every and (i + 1) % check_every == 0:
+            assert_state_close(gpu_space, orc_space, tol, what=f"step {i}")
+    return nsucc
