@@ -441,8 +441,19 @@ __global__ __launch_bounds__(256) void k_symv_reduce(long long n, long long row0
     // vectors are added by the caller's all-reduce.  (row0 is a multiple of SYMV_H, so pairs never straddle.)
     double2_t s = {0.0, 0.0};
     if (i < n) {
-        // loads are independent of the running sums: keep 8 of them in flight, add in strip order
+        // loads are independent of the running sums: keep 16 (then 8) of them in flight, add in strip order (the
+        // first columns have n / 64 strips to add, 64 per wave: with 8 in flight the kernel took 8 round trips)
         long long I = (i < row0 ? 0 : (i - row0) / SYMV_H) + wave;
+        for (; I + 60 < nstrips; I += 64) {
+            double2_t v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) v[u] = *reinterpret_cast<const double2_t*>(colpart + (I + 4 * u) * n + i);
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                s.x += v[u].x;
+                s.y += v[u].y;
+            }
+        }
         for (; I + 28 < nstrips; I += 32) {
             double2_t v[8];
 #pragma unroll
@@ -459,17 +470,29 @@ __global__ __launch_bounds__(256) void k_symv_reduce(long long n, long long row0
             s.y += v.y;
         }
     }
+    // row partial sums (wave 0): requested eight at a time BEFORE the barrier, added in segment order (one load per
+    // loop trip after the barrier was a chain of up to n / seg dependent round trips)
+    double2_t r = {0.0, 0.0};
+    if (wave == 0 && i < n && i >= row0 && i < row0 + nrows) {
+        const long long nJ = i / seg + 1;
+        for (long long J = 0; J < nJ; J += 8) {
+            double2_t v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {  // unconditional loads (clamped), masked afterwards: adding +0.0 changes nothing
+                const long long Ju = (J + u < nJ) ? J + u : nJ - 1;
+                v[u] = *reinterpret_cast<const double2_t*>(rowpart + Ju * n + i);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                r.x += (J + u < nJ) ? v[u].x : 0.0;
+                r.y += (J + u < nJ) ? v[u].y : 0.0;
+            }
+        }
+    }
     part[wave][lane] = s;
     __syncthreads();
     double2_t yv = {0.0, 0.0};  // this lane's pair of y (wave 0 only)
     if (wave == 0 && i < n) {
-        double2_t r = {0.0, 0.0};
-        const bool local = i >= row0 && i < row0 + nrows;
-        for (long long J = 0; local && J <= i / seg; ++J) {
-            const double2_t v = *reinterpret_cast<const double2_t*>(rowpart + J * n + i);
-            r.x += v.x;
-            r.y += v.y;
-        }
         const double2_t c0 = part[0][lane], c1 = part[1][lane], c2 = part[2][lane], c3 = part[3][lane];
         r.x += ((c0.x + c1.x) + c2.x) + c3.x;
         r.y += ((c0.y + c1.y) + c2.y) + c3.y;
@@ -826,6 +849,8 @@ __global__ __launch_bounds__(256) void k_scalar_apply(long long n, const double*
     for (long long i = lo + tid; i < hi; i += 256) xc[i] = xc[i] - roo * gt[i];  // :113-115
 }
 
+constexpr int SC_LP_ROWS = 128;  // rows of partial sums staged through LDS per pass (a multiple of 8)
+
 // Deferred-mode scalar stage (see MAXPEND above).  y = Q_base*g comes from the GEMV pass.
 //   k_scalar_dot_def    partial[b][0] = slice of g.y ; partial[b][1+j] = slice of v_j.g
 //   k_scalar_apply_def  every workgroup: gy, d_j = v_j.g; omega = gy - sum_j c_j d_j^2; tsq, EllCalc; its slice
@@ -896,11 +921,33 @@ __global__ __launch_bounds__(256) void k_scalar_apply_def(long long n, const dou
         return;
     }
     __shared__ double dsum[NP + 1];
-    // Sum the npart rows of partial sums, per column: 8 interleaved running sums (thread group q takes rows q, q + 8,
-    // ...; four loads in flight per thread), combined in a fixed order -- one memory round trip instead of npart / 8.
+    // Sum the npart rows of partial sums, per column: 8 interleaved running sums (thread group q adds rows q, q + 8,
+    // ... in ascending order), combined in a fixed order.  The rows come through LDS, SC_LP_ROWS at a time, fetched by
+    // all 256 threads at once: one memory round trip per pass (the threads of a column used to fetch their rows
+    // themselves, four at a time: npart / 32 round trips on the update's dependency chain).
     __shared__ double psum[8][32];
     __shared__ double gy_part[64];
     __shared__ double gy_w[64][4];
+    __shared__ double lp[SC_LP_ROWS * (NP + 1)];
+    // The slice's operands do not depend on the coefficients: request them now, so that they arrive while the sums and
+    // the coefficient stage run (up to 4 elements per thread: slices are 1024 long up to n = 65536).
+    constexpr int EPT = 4;
+    const long long m_sl = scalar_slice(n);
+    const long long lo_sl = (long long)blockIdx.x * m_sl;
+    const long long hi_sl = (lo_sl + m_sl < n) ? lo_sl + m_sl : n;
+    const bool pre = m_sl <= 256 * EPT;
+    double py[EPT], px[EPT], pp[EPT][NP];
+    if (pre) {
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) {
+            const long long i = lo_sl + tid + 256 * e;
+            const bool in = i < hi_sl;
+            py[e] = in ? y[i] : 0.0;
+            px[e] = in ? xc[i] : 0.0;
+#pragma unroll
+            for (int j = 0; j < NP; ++j) pp[e][j] = in ? pend[(long long)j * n + i] : 0.0;
+        }
+    }
     if (GY) {  // (npart = scalar_groups(n) <= 64 in this mode)
         const long long m = scalar_slice(n);
         for (int b = 0; b < npart; ++b) {
@@ -918,23 +965,22 @@ __global__ __launch_bounds__(256) void k_scalar_apply_def(long long n, const dou
     }
     {
         const int c = tid & 31, q = tid >> 5;
-        if (c <= NP) {
-            double a = 0.0;
-            int b = q;
-            if (GY && c == 0) {
-                for (; b < npart; b += 8) a += gy_part[b];
-            } else {
-                for (; b + 24 < npart; b += 32) {
-                    double v[4];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) v[u] = partial[(long long)(b + 8 * u) * (NP + 1) + c];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) a += v[u];
+        double a = 0.0;
+        for (int b0 = 0; b0 < npart; b0 += SC_LP_ROWS) {
+            const int nb = (npart - b0 < SC_LP_ROWS) ? npart - b0 : SC_LP_ROWS;
+            const int total = nb * (NP + 1);
+            for (int k = tid; k < total; k += 256) lp[k] = partial[(long long)b0 * (NP + 1) + k];
+            __syncthreads();
+            if (c <= NP) {
+                if (GY && c == 0) {
+                    for (int b = q; b < nb; b += 8) a += gy_part[b0 + b];
+                } else {
+                    for (int b = q; b < nb; b += 8) a += lp[b * (NP + 1) + c];
                 }
-                for (; b < npart; b += 8) a += partial[(long long)b * (NP + 1) + c];
             }
-            psum[q][c] = a;
+            __syncthreads();
         }
+        if (c <= NP) psum[q][c] = a;
     }
     __syncthreads();
     if (tid <= NP)
@@ -992,15 +1038,26 @@ __global__ __launch_bounds__(256) void k_scalar_apply_def(long long n, const dou
 #pragma unroll
     for (int j = 0; j < NP; ++j) cd[j] = bc_cd[j];
     double* vnew = pend + (long long)slot * n;
-    const long long m = scalar_slice(n);
-    const long long lo = (long long)blockIdx.x * m;
-    const long long hi = (lo + m < n) ? lo + m : n;
-    for (long long i = lo + tid; i < hi; i += 256) {
+    if (pre) {
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) {
+            const long long i = lo_sl + tid + 256 * e;
+            if (i < hi_sl) {
+                double gt = py[e];
+#pragma unroll
+                for (int j = 0; j < NP; ++j) gt = gt - cd[j] * pp[e][j];
+                vnew[i] = gt;                // slot `slot` was all zeros until now: its own term above was an exact 0
+                xc[i] = px[e] - roo * gt;    // :113-115
+            }
+        }
+        return;
+    }
+    for (long long i = lo_sl + tid; i < hi_sl; i += 256) {
         double gt = y[i];
 #pragma unroll
         for (int j = 0; j < NP; ++j) gt = gt - cd[j] * pend[(long long)j * n + i];
-        vnew[i] = gt;                    // slot `slot` was all zeros until now: its own term above was an exact 0
-        xc[i] = xc[i] - roo * gt;        // :113-115
+        vnew[i] = gt;
+        xc[i] = xc[i] - roo * gt;
     }
 }
 

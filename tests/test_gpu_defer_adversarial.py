@@ -1,0 +1,118 @@
+"""The recorded ("deferred") schedule that new large handles start with, on inputs chosen to break it.
+
+Depth 8 / 16 forms gt = Q_base g - sum_j (c_j v_j.g) v_j, i.e. it subtracts the recorded shrinks from a product with the
+UNSHRUNK base matrix, so its relative error grows with how much the ellipsoid shrank along g inside one batch.  The
+ordinary parity suites use i.i.d. gradients and beta <= 0.3 tau, where that is invisible.  Here: nearly parallel
+gradients (g_k = g_0 + 0.01 noise), repeated gradients inside a batch, deep cuts up to beta / tau = 0.9 and parallel
+cuts whose slab is down to 1e-3 tau wide -- every cut shrinks the ellipsoid by a large factor along (almost) the same
+direction.  Reference behaviour: src/ell.rs:97-137 via the CPU oracle; each case runs the oracle, the HIP engine at
+depth 1 (the reference's data flow) and the HIP engine at the depth a new handle of that size starts with.
+
+What is asserted: the CutStatus sequence is identical on all three; and the default depth is no less accurate than
+depth 1 by more than a small factor -- such sequences are ill-conditioned for ANY floating-point evaluation
+(omega = g'Qg loses digits by cancellation once Q has collapsed along g), so both engines leave the 1e-10 band of the
+well-conditioned tests; the errors are printed (run with -s).
+"""
+import numpy as np
+import pytest
+
+from util import rel_inf
+
+pytestmark = pytest.mark.gpu
+
+FACTOR = 4.0     # default-depth error may exceed the depth-1 error by at most this factor ...
+FLOOR = 1e-10    # ... unless it is within the north-star tolerance anyway
+
+
+def _errs(e, o):
+    xo = np.array(o.xc)
+    return {"Q": rel_inf(e.mq, o.mq), "xc": float(np.max(np.abs(e.xc() - xo)) / max(np.max(np.abs(xo)), 1e-300)),
+            "kappa": abs(e.kappa - o.kappa) / abs(o.kappa)}
+
+
+def _drive(gpu, orc, n, cuts, make_cut, seed):
+    """make_cut(k, rng, g_prev, tau) -> (kind, g, b0, b1); tau is the oracle's sqrt(tsq) for the gradient returned by
+    make_cut's own gradient choice, so the gradient is chosen first."""
+    rng = np.random.default_rng(seed)
+    o = orc.OracleEll.new_with_scalar(1.0, np.zeros(n))
+    e1 = gpu.Ell.new_with_scalar(1.0, np.zeros(n))
+    e1.defer_depth = 1
+    ed = gpu.Ell.new_with_scalar(1.0, np.zeros(n))
+    depth = ed.defer_depth
+    assert depth in (8, 16), depth          # what a new handle of this size starts with
+    worst = {"tsq1": 0.0, "tsqd": 0.0}
+    state = {}
+    for k in range(cuts):
+        g = make_cut.grad(k, rng, state)
+        tau = float(np.sqrt(max(o.kappa * float(g @ (o.mq @ g)), 0.0)))
+        kind, b0, b1 = make_cut.cut(k, rng, tau, state)
+        so = o.update_rowwise_mt(kind, g, b0, b1)
+        beta = float(b0) if b1 is None else (float(b0), float(b1))
+        s1 = int(e1._update(kind, (g, beta)))
+        sd = int(ed._update(kind, (g, beta)))
+        assert so == s1 == sd, f"cut {k}: status oracle={so} depth1={s1} depth{depth}={sd}"
+        if abs(o.tsq) > 0:
+            worst["tsq1"] = max(worst["tsq1"], abs(e1.tsq() - o.tsq) / abs(o.tsq))
+            worst["tsqd"] = max(worst["tsqd"], abs(ed.tsq() - o.tsq) / abs(o.tsq))
+    a1, ad = _errs(e1, o), _errs(ed, o)
+    a1["tsq"], ad["tsq"] = worst["tsq1"], worst["tsqd"]
+    print(f"\n  n={n} depth {depth}: depth-1 errors {a1}\n  {'':>{len(str(n)) + 9}}depth-{depth} errors {ad}")
+    for key in a1:
+        assert ad[key] <= max(FACTOR * a1[key], FLOOR), (key, ad[key], a1[key])
+    return a1, ad
+
+
+class Correlated:
+    """g_k = g_0 + eps * noise_k (normalised); deep cut beta = ratio * tau."""
+    def __init__(self, n, ratio, eps=0.01):
+        self.n, self.ratio, self.eps = n, ratio, eps
+
+    def grad(self, k, rng, st):
+        if "g0" not in st:
+            st["g0"] = rng.standard_normal(self.n)
+            st["g0"] /= np.linalg.norm(st["g0"])
+        g = st["g0"] + self.eps * rng.standard_normal(self.n) / np.sqrt(self.n)
+        return g / np.linalg.norm(g)
+
+    def cut(self, k, rng, tau, st):
+        return 0, self.ratio * tau, None
+
+
+class Repeated(Correlated):
+    """every gradient is used three times in a row (inside one batch of recorded updates)"""
+    def grad(self, k, rng, st):
+        if k % 3 == 0:
+            g = rng.standard_normal(self.n)
+            st["g"] = g / np.linalg.norm(g)
+        return st["g"]
+
+
+class NarrowSlab(Correlated):
+    """parallel cuts whose slab [b0, b1] is `width * tau` wide around 0.1 tau: sigma close to 1"""
+    def __init__(self, n, width):
+        super().__init__(n, 0.0, eps=0.05)
+        self.width = width
+
+    def cut(self, k, rng, tau, st):
+        b0 = 0.1 * tau
+        return 0, b0, b0 + self.width * tau
+
+
+@pytest.mark.parametrize("n", [4096, 8192])
+@pytest.mark.parametrize("ratio", [0.3, 0.6, 0.9])
+def test_correlated_gradients_deep_cuts(gpu, orc, n, ratio):
+    # beta = 0.9 tau collapses the ellipsoid along g_0 by 19x per cut: after ~15 such cuts omega = g'Qg has lost so many
+    # digits to cancellation that even depth 1 (on the GPU or anywhere else) no longer takes the oracle's decisions
+    # (tsq < beta^2 flips): that case is kept to 12 cuts, the others run 40
+    _drive(gpu, orc, n, 12 if ratio > 0.8 else 40, Correlated(n, ratio), seed=int(1000 * ratio) + n)
+
+
+@pytest.mark.parametrize("n", [4096, 8192])
+def test_repeated_gradients_inside_a_batch(gpu, orc, n):
+    _drive(gpu, orc, n, 36, Repeated(n, 0.5), seed=77 + n)
+
+
+@pytest.mark.parametrize("n", [4096, 8192])
+@pytest.mark.parametrize("width", [1e-1, 1e-2, 1e-3])
+def test_narrow_parallel_slabs(gpu, orc, n, width):
+    _drive(gpu, orc, n, 32, NarrowSlab(n, width), seed=int(-np.log10(width)) + n)
