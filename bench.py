@@ -52,6 +52,10 @@ WORKLOADS = {
 LOWPASS_WORKLOADS = {"lowpass-n4096": 4096, "lowpass-n2048": 2048, "lowpass-n1024": 1024, "lowpass-n256": 256}
 
 
+# BASELINE.json configs 2, 3, 4 (its one-GPU form: the whole 8 GiB matrix on one card) and 5
+ALL_CONFIGS = ["n4096-deep", "n16384-parallel", "n32768-deep", "n16384-ellstable"]
+
+
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
@@ -439,7 +443,29 @@ def main() -> None:
                     help="extra timed steps for each OTHER schedule / depth, reported alongside (0 = skip)")
     ap.add_argument("--force-sharded", action="store_true",
                     help="run the row-partitioned (multi-GPU) code path even with one rank (rehearsal)")
+    ap.add_argument("--all-configs", action="store_true",
+                    help="run every BASELINE.json configuration that has a one-GPU form, one after the other (n4096-deep, "
+                         "n16384-parallel, n32768-deep, n16384-ellstable), each as its own process with the same "
+                         "--steps / --warmup: ONE JSON line of the usual contract per configuration")
     args = ap.parse_args()
+
+    if args.all_configs:
+        if args.gpus != 1 or int(os.environ.get("WORLD_SIZE", "1")) != 1:
+            raise SystemExit("--all-configs is a one-GPU run")
+        import subprocess
+        rc = 0
+        for wl in ALL_CONFIGS:
+            cmd = [sys.executable, os.path.abspath(__file__), "--workload", wl, "--steps", str(args.steps), "--warmup",
+                   str(args.warmup), "--profile-steps", str(args.profile_steps), "--compare-steps", str(args.compare_steps),
+                   "--host-path-steps", str(args.host_path_steps), "--cpu-budget", str(args.cpu_budget)]
+            if args.no_cpu_baseline:
+                cmd.append("--no-cpu-baseline")
+            log(f"[all-configs] {wl}")
+            out = subprocess.run(cmd, stdout=subprocess.PIPE, text=True)   # the child parks its own stdout the same way
+            rc = rc or out.returncode
+            real_stdout.write(out.stdout)
+            real_stdout.flush()
+        raise SystemExit(rc)
 
     if args.workload in LOWPASS_WORKLOADS or args.workload in BATCH_WORKLOADS or args.workload in LMI_WORKLOADS:
         if args.gpus != 1 or int(os.environ.get("WORLD_SIZE", "1")) != 1:

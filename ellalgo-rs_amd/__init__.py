@@ -9,6 +9,7 @@ from .ell import (CutStatus, Ell, EllStable, ParallelCut, SingleCut, calc)  # no
 from .batch import EllBatch  # noqa: F401
 from .lmi import LDLTMgr, LMI0Oracle, LMIOracle  # noqa: F401
 from .lowpass import LowpassOracle, create_lowpass_case, lowpass_case_constants  # noqa: F401
+from .sharded_abi import ShardedEllAbi  # noqa: F401
 
 __all__ = ["build", "capi", "synth", "CutStatus", "Ell", "EllStable", "ParallelCut", "SingleCut", "calc",
            "EllBatch", "LDLTMgr", "LMIOracle", "LMI0Oracle", "LowpassOracle", "create_lowpass_case", "lowpass_case_constants"]

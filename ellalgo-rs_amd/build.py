@@ -13,7 +13,7 @@ REPO_ROOT = os.path.dirname(PKG_DIR)
 SOURCES = ["ellhip_capi.hip"]
 HEADERS = ["ell_kernels.hpp", "ellstable_kernels.hpp", "ellcalc_device.hpp", "lowpass_kernels.hpp",
            "lowpass_capi.inc.hpp", "batch_kernels.hpp", "batch_capi.inc.hpp", "lmi_kernels.hpp",
-           "lmi_capi.inc.hpp"]
+           "lmi_capi.inc.hpp", "sharded_capi.inc.hpp"]
 
 # -ffp-contract=off: the reference never fuses a*b+c (two roundings per multiply-add); keeping
 # that makes the rank-1 pass bit-identical to the CPU arithmetic for the same gt.
@@ -32,7 +32,7 @@ def needs_build() -> bool:
     if not os.path.exists(LIB_PATH):
         return True
     t = os.path.getmtime(LIB_PATH)
-    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS] + [os.path.join(REPO_ROOT, "include", f) for f in ("ellhip.h", "ellhip_lowpass.h", "ellhip_batch.h", "ellhip_lmi.h")]
+    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS] + [os.path.join(REPO_ROOT, "include", f) for f in ("ellhip.h", "ellhip_lowpass.h", "ellhip_batch.h", "ellhip_lmi.h", "ellhip_sharded.h")]
     return any(os.path.getmtime(d) > t for d in deps)
 
 
@@ -42,7 +42,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         return LIB_PATH
     extra = os.environ.get("ELLHIP_EXTRA_HIPCC_FLAGS", "").split()  # tuning builds only
     cmd = [_hipcc()] + HIPCC_FLAGS + extra + ["-I", os.path.join(REPO_ROOT, "include"), "-o", LIB_PATH] + \
-          [os.path.join(CSRC, f) for f in SOURCES]
+          [os.path.join(CSRC, f) for f in SOURCES] + ["-ldl"]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

@@ -12,6 +12,9 @@ from . import build as _build
 SUCCESS, NOSOLN, NOEFFECT, UNKNOWN = 0, 1, 2, 3
 CUT_BIAS, CUT_CENTRAL, CUT_Q = 0, 1, 2
 SPACE_ELL, SPACE_ELL_STABLE = 0, 1
+E_NORCCL = -6
+SHARD_EQUAL_BLOCKS, SHARD_SYMMETRIC = 0, 1
+NCCL_ID_BYTES = 128
 E_INVALID, E_HIP, E_NODEVICE, E_NOMEM, E_STATE = -1, -2, -3, -4, -5
 NKERNEL_CLASSES = 13
 KERNEL_CLASS_NAMES = ("gemv", "scalar", "rank1", "stable_fwd", "stable_bwd", "stable_factor", "fused", "apply",
@@ -38,6 +41,12 @@ EXPORTS = [
     # include/ellhip_lmi.h
     "ellhip_lmi_create", "ellhip_lmi_destroy", "ellhip_lmi_assess_feas", "ellhip_lmi_pos", "ellhip_lmi_get_witness",
     "ellhip_lmi_get_storage", "ellhip_lmi_sqrt",
+    # include/ellhip_sharded.h
+    "ellhip_sharded_partition", "ellhip_sharded_unique_id", "ellhip_sharded_create", "ellhip_sharded_destroy",
+    "ellhip_sharded_update", "ellhip_sharded_tsq", "ellhip_sharded_kappa", "ellhip_sharded_get_xc",
+    "ellhip_sharded_set_xc", "ellhip_sharded_get_mq_rows", "ellhip_sharded_set_defer_depth", "ellhip_sharded_flush",
+    "ellhip_sharded_queue_upload", "ellhip_sharded_queue_run", "ellhip_sharded_queue_run_fused",
+    "ellhip_sharded_queue_results", "ellhip_sharded_synchronize", "ellhip_sharded_local", "ellhip_shards_exchange",
 ]
 
 
@@ -167,6 +176,26 @@ def load():
         "ellhip_lmi_get_witness": (i32, [vp, vp]),
         "ellhip_lmi_get_storage": (i32, [vp, vp]),
         "ellhip_lmi_sqrt": (i32, [vp, vp]),
+        # include/ellhip_sharded.h
+        "ellhip_sharded_partition": (i32, [i64, i32, i32, i32, C.POINTER(i64), C.POINTER(i64)]),
+        "ellhip_sharded_unique_id": (i32, [vp]),
+        "ellhip_sharded_create": (i32, [C.POINTER(vp), i64, dbl, vp, vp, vp, i32, i32, i32, vp, vp, i32, i32]),
+        "ellhip_sharded_destroy": (None, [vp]),
+        "ellhip_sharded_update": (i32, [vp, i32, vp, dbl, i32, dbl]),
+        "ellhip_sharded_tsq": (dbl, [vp]),
+        "ellhip_sharded_kappa": (dbl, [vp]),
+        "ellhip_sharded_get_xc": (i32, [vp, vp]),
+        "ellhip_sharded_set_xc": (i32, [vp, vp]),
+        "ellhip_sharded_get_mq_rows": (i32, [vp, vp]),
+        "ellhip_sharded_set_defer_depth": (i32, [vp, i32]),
+        "ellhip_sharded_flush": (i32, [vp]),
+        "ellhip_sharded_queue_upload": (i32, [vp, i64, vp, vp, vp, vp, vp]),
+        "ellhip_sharded_queue_run": (i32, [vp, i64, i64]),
+        "ellhip_sharded_queue_run_fused": (i32, [vp, i64, i64]),
+        "ellhip_sharded_queue_results": (i32, [vp, vp, vp]),
+        "ellhip_sharded_synchronize": (i32, [vp]),
+        "ellhip_sharded_local": (vp, [vp]),
+        "ellhip_shards_exchange": (i32, [vp, i32]),
     }
     for name in EXPORTS:
         fn = getattr(L, name)  # AttributeError if the library does not export it

@@ -1569,3 +1569,4 @@ int ellhip_profile_read(ellhip_space* s, double* ms_out, int64_t* count_out) {
 #include "lowpass_capi.inc.hpp"
 #include "batch_capi.inc.hpp"
 #include "lmi_capi.inc.hpp"
+#include "sharded_capi.inc.hpp"

@@ -1,0 +1,350 @@
+// sharded_capi.inc.hpp -- implementation of include/ellhip_sharded.h (included at the end of ellhip_capi.hip).
+//
+// One process per GPU; this rank's row block is an ordinary shard handle (ellhip_create_shard) and the ONE collective
+// of an update is issued by the library on the handle's stream through RCCL, which is opened at run time (dlopen), so
+// libellhip.so has no link-time dependency on it.  The orchestration is the one of ellalgo-rs_amd/sharded.py (which
+// drives the same shard handle through torch.distributed); see DESIGN.md section 7 for the schedule.
+#include "../../include/ellhip_sharded.h"
+
+#include <dlfcn.h>
+
+#include <cmath>
+
+namespace {
+
+// The few RCCL entry points used, with the types of <rccl/rccl.h> restated (ncclComm_t is an opaque pointer,
+// ncclUniqueId 128 bytes, ncclDouble = 8, ncclSum = 0, ncclSuccess = 0): nothing of RCCL is needed to build.
+struct IdBytes {
+    char internal[ELLHIP_NCCL_ID_BYTES];
+};
+struct Rccl {
+    void* lib = nullptr;
+    int (*GetUniqueId)(void*) = nullptr;
+    int (*CommInitRank)(void**, int, /* ncclUniqueId by value */ IdBytes, int) = nullptr;
+    int (*CommDestroy)(void*) = nullptr;
+    int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
+    int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+    std::string why;
+};
+constexpr int RCCL_DOUBLE = 8, RCCL_SUM = 0;
+
+Rccl* rccl() {
+    static Rccl r;
+    static bool tried = false;
+    if (tried) return &r;
+    tried = true;
+    const char* names[] = {"librccl.so.1", "librccl.so"};
+    for (const char* nm : names) {  // a copy the process has already mapped (PyTorch-ROCm's) is reused
+        r.lib = dlopen(nm, RTLD_NOW | RTLD_NOLOAD);
+        if (r.lib) break;
+    }
+    if (!r.lib) {
+        const char* env = getenv("ELLHIP_RCCL_PATH");
+        if (env && *env) r.lib = dlopen(env, RTLD_NOW | RTLD_GLOBAL);
+        for (const char* nm : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            if (r.lib) break;
+            r.lib = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
+        }
+    }
+    if (!r.lib) {
+        r.why = std::string("librccl could not be opened: ") + (dlerror() ? dlerror() : "?");
+        return &r;
+    }
+    auto sym = [&](const char* nm) -> void* {
+        void* p = dlsym(r.lib, nm);
+        if (!p && r.why.empty()) r.why = std::string("librccl lacks ") + nm;
+        return p;
+    };
+    r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(sym("ncclGetUniqueId"));
+    r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(sym("ncclCommInitRank"));
+    r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(sym("ncclCommDestroy"));
+    r.AllGather = reinterpret_cast<decltype(r.AllGather)>(sym("ncclAllGather"));
+    r.AllReduce = reinterpret_cast<decltype(r.AllReduce)>(sym("ncclAllReduce"));
+    r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(sym("ncclGetErrorString"));
+    return &r;
+}
+
+int rccl_fail(const char* what, int code) {
+    Rccl* r = rccl();
+    char buf[384];
+    snprintf(buf, sizeof buf, "%s: %s (%d)", what, (r->GetErrorString ? r->GetErrorString(code) : "?"), code);
+    return fail(ELLHIP_E_NORCCL, buf);
+}
+
+}  // namespace
+
+struct ellhip_sharded {
+    ellhip_space* sh = nullptr;
+    int rank = 0, nranks = 1, partition = ELLHIP_SHARD_EQUAL_BLOCKS;
+    long long n = 0, row0 = 0, nrows = 0;
+    void* comm = nullptr;
+    bool own_comm = false;
+    long long qk = 0, primed_index = -1;
+};
+
+namespace {
+
+// the collective of one update: in place on the buffer that holds Q*g of the gradient just primed
+int shard_exchange(ellhip_sharded* s) {
+    if (!s->comm) return 0;  // one rank, no communicator: the local pass already produced the whole vector
+    Rccl* r = rccl();
+    double* gt = ellhip_gt_dev(s->sh);
+    DeviceGuard guard(s->sh->device);
+    int rc;
+    if (s->partition == ELLHIP_SHARD_SYMMETRIC)
+        rc = r->AllReduce(gt, gt, (size_t)s->n, RCCL_DOUBLE, RCCL_SUM, s->comm, s->sh->stream);
+    else
+        rc = r->AllGather(gt + s->row0, gt, (size_t)s->nrows, RCCL_DOUBLE, s->comm, s->sh->stream);
+    if (rc != 0) return rccl_fail(s->partition == ELLHIP_SHARD_SYMMETRIC ? "ncclAllReduce" : "ncclAllGather", rc);
+    return 0;
+}
+
+// A shard whose recorded updates were applied by an observer (flush, get_mq_rows, a depth change) has dropped its
+// primed GEMV (it belonged to the old base): the next queue_run_fused primes -- and exchanges -- again.
+void sync_primed(ellhip_sharded* s) { s->primed_index = ellhip_queue_primed(s->sh); }
+
+}  // namespace
+
+extern "C" {
+
+int ellhip_sharded_partition(int64_t n, int nranks, int rank, int partition, int64_t* row0_out, int64_t* nrows_out) {
+    if (!row0_out || !nrows_out || n < 1 || nranks < 1 || rank < 0 || rank >= nranks)
+        return fail(ELLHIP_E_INVALID, "bad partition arguments");
+    if (partition == ELLHIP_SHARD_EQUAL_BLOCKS) {
+        if (n % nranks) return fail(ELLHIP_E_INVALID, "equal row blocks: n must be divisible by the number of ranks");
+        *nrows_out = n / nranks;
+        *row0_out = rank * (n / nranks);
+        return 0;
+    }
+    if (partition != ELLHIP_SHARD_SYMMETRIC) return fail(ELLHIP_E_INVALID, "unknown partition");
+    const int64_t align = SYMV_H;
+    if (n % align || n / align < nranks)
+        return fail(ELLHIP_E_INVALID, "symmetric row shards: n must be a multiple of 64 with at least one strip per rank");
+    // boundaries at n sqrt(r / P), rounded (half to even, as ellalgo-rs_amd/sharded.py's round()) to whole strips,
+    // strictly increasing, room left for the ranks behind
+    const int64_t nstrips = n / align;
+    int64_t lo = 0, hi = 0;
+    int64_t prev = 0;
+    for (int r = 1; r <= nranks; ++r) {
+        int64_t b;
+        if (r == nranks) {
+            b = nstrips;
+        } else {
+            b = (int64_t)std::nearbyint((double)nstrips * std::sqrt((double)r / (double)nranks));
+            b = std::min<int64_t>(std::max<int64_t>(b, prev + 1), nstrips - (nranks - r));
+        }
+        if (r - 1 == rank) {
+            lo = prev;
+            hi = b;
+        }
+        prev = b;
+    }
+    *row0_out = lo * align;
+    *nrows_out = (hi - lo) * align;
+    return 0;
+}
+
+int ellhip_sharded_unique_id(void* id_out) {
+    if (!id_out) return fail(ELLHIP_E_INVALID, "id_out is NULL");
+    Rccl* r = rccl();
+    if (!r->GetUniqueId) return fail(ELLHIP_E_NORCCL, r->why.c_str());
+    const int rc = r->GetUniqueId(id_out);
+    if (rc != 0) return rccl_fail("ncclGetUniqueId", rc);
+    return 0;
+}
+
+int ellhip_sharded_create(ellhip_sharded** out, int64_t n, double kappa, const double* mq_rows, const double* diag,
+                          const double* xc, int device, int rank, int nranks, const void* nccl_id, void* nccl_comm,
+                          int partition, int defer_depth) {
+    if (!out) return fail(ELLHIP_E_INVALID, "out is NULL");
+    *out = nullptr;
+    if (nccl_id && nccl_comm) return fail(ELLHIP_E_INVALID, "give either the unique id or a communicator, not both");
+    if (nranks > 1 && !nccl_id && !nccl_comm) return fail(ELLHIP_E_INVALID, "more than one rank needs a communicator");
+    if (defer_depth != 1 && defer_depth != 8 && defer_depth != 16) return fail(ELLHIP_E_INVALID, "defer depth must be 1, 8 or 16");
+    if (partition == ELLHIP_SHARD_SYMMETRIC && defer_depth == 1)
+        return fail(ELLHIP_E_INVALID, "symmetric row shards run the recorded schedule only (depth 8 or 16)");
+    int64_t row0 = 0, nrows = 0;
+    int rc = ellhip_sharded_partition(n, nranks, rank, partition, &row0, &nrows);
+    if (rc) return rc;
+    ellhip_sharded* s = new (std::nothrow) ellhip_sharded();
+    if (!s) return fail(ELLHIP_E_NOMEM, "host allocation failed");
+    s->rank = rank;
+    s->nranks = nranks;
+    s->partition = partition;
+    s->n = n;
+    s->row0 = row0;
+    s->nrows = nrows;
+    rc = ellhip_create_shard(&s->sh, n, row0, nrows, kappa, mq_rows, diag, xc, device);
+    if (!rc && partition == ELLHIP_SHARD_SYMMETRIC) rc = ellhip_set_shard_symmetric(s->sh, 1);
+    if (!rc && defer_depth != 1) rc = ellhip_set_defer_depth(s->sh, defer_depth);
+    if (!rc && (nccl_id || nccl_comm)) {
+        Rccl* r = rccl();
+        if (!r->CommInitRank || !r->AllGather || !r->AllReduce) {
+            rc = fail(ELLHIP_E_NORCCL, r->why.empty() ? "librccl is incomplete" : r->why.c_str());
+        } else if (nccl_comm) {
+            s->comm = nccl_comm;
+        } else {
+            DeviceGuard guard(s->sh->device);
+            IdBytes id;
+            memcpy(&id, nccl_id, sizeof id);
+            const int nrc = r->CommInitRank(&s->comm, nranks, id, rank);
+            if (nrc != 0) rc = rccl_fail("ncclCommInitRank", nrc);
+            else s->own_comm = true;
+        }
+    }
+    if (rc) {
+        ellhip_sharded_destroy(s);
+        return rc;
+    }
+    *out = s;
+    return 0;
+}
+
+void ellhip_sharded_destroy(ellhip_sharded* s) {
+    if (!s) return;
+    if (s->sh) (void)ellhip_synchronize(s->sh);
+    if (s->comm && s->own_comm) {
+        Rccl* r = rccl();
+        if (r->CommDestroy) (void)r->CommDestroy(s->comm);
+    }
+    if (s->sh) ellhip_destroy(s->sh);
+    delete s;
+}
+
+int ellhip_sharded_update(ellhip_sharded* s, int kind, const double* grad, double beta0, int has_beta1, double beta1) {
+    if (!s) return fail(ELLHIP_E_INVALID, "NULL handle");
+    int rc = ellhip_update_begin(s->sh, kind, grad, beta0, has_beta1, beta1);
+    if (rc) return rc;
+    rc = shard_exchange(s);
+    if (rc) return rc;
+    return ellhip_update_end(s->sh);
+}
+
+double ellhip_sharded_tsq(const ellhip_sharded* s) { return s ? ellhip_tsq(s->sh) : 0.0; }
+double ellhip_sharded_kappa(const ellhip_sharded* s) { return s ? ellhip_kappa(s->sh) : 0.0; }
+int ellhip_sharded_get_xc(const ellhip_sharded* s, double* xc_out) {
+    return s ? ellhip_get_xc(s->sh, xc_out) : fail(ELLHIP_E_INVALID, "NULL handle");
+}
+int ellhip_sharded_set_xc(ellhip_sharded* s, const double* xc) {
+    return s ? ellhip_set_xc(s->sh, xc) : fail(ELLHIP_E_INVALID, "NULL handle");
+}
+int ellhip_sharded_get_mq_rows(ellhip_sharded* s, double* rows_out) {
+    if (!s) return fail(ELLHIP_E_INVALID, "NULL handle");
+    const int rc = ellhip_get_mq(s->sh, rows_out);
+    sync_primed(s);
+    return rc;
+}
+int ellhip_sharded_set_defer_depth(ellhip_sharded* s, int depth) {
+    if (!s) return fail(ELLHIP_E_INVALID, "NULL handle");
+    const int rc = ellhip_set_defer_depth(s->sh, depth);
+    sync_primed(s);
+    return rc;
+}
+int ellhip_sharded_flush(ellhip_sharded* s) {
+    if (!s) return fail(ELLHIP_E_INVALID, "NULL handle");
+    const int rc = ellhip_flush(s->sh);
+    sync_primed(s);
+    return rc;
+}
+
+int ellhip_sharded_queue_upload(ellhip_sharded* s, int64_t k, const int32_t* kinds, const double* grads,
+                                const double* beta0, const int32_t* has_beta1, const double* beta1) {
+    if (!s) return fail(ELLHIP_E_INVALID, "NULL handle");
+    const int rc = ellhip_queue_upload(s->sh, k, kinds, grads, beta0, has_beta1, beta1);
+    if (rc) return rc;
+    s->qk = k;
+    s->primed_index = -1;
+    return 0;
+}
+
+int ellhip_sharded_queue_run(ellhip_sharded* s, int64_t first, int64_t count) {
+    if (!s || first < 0 || count < 0 || first + count > s->qk) return fail(ELLHIP_E_INVALID, "queue range");
+    for (int64_t i = first; i < first + count; ++i) {
+        int rc = ellhip_queue_begin(s->sh, i);
+        if (!rc) rc = shard_exchange(s);
+        if (!rc) rc = ellhip_queue_end(s->sh, i);
+        if (rc) return rc;
+    }
+    s->primed_index = -1;
+    return 0;
+}
+
+int ellhip_sharded_queue_run_fused(ellhip_sharded* s, int64_t first, int64_t count) {
+    if (!s || first < 0 || count < 0 || first + count > s->qk) return fail(ELLHIP_E_INVALID, "queue range");
+    if (count == 0) return 0;
+    int rc = 0;
+    // pipelined: one pass over the local rows per cut; the collective follows whichever call ran a GEMV
+    if (s->primed_index != first) {
+        rc = ellhip_queue_prime(s->sh, first);
+        if (!rc) rc = shard_exchange(s);
+        if (rc) return rc;
+    }
+    for (int64_t i = first; i < first + count; ++i) {
+        const int64_t nxt = (i + 1 < s->qk) ? i + 1 : -1;
+        rc = ellhip_queue_cut(s->sh, i);
+        if (!rc) rc = ellhip_queue_commit(s->sh, i, nxt);
+        if (!rc && nxt >= 0) rc = shard_exchange(s);
+        if (rc) return rc;
+        s->primed_index = nxt;
+    }
+    return 0;
+}
+
+int ellhip_sharded_queue_results(ellhip_sharded* s, int32_t* status_out, double* tsq_out) {
+    if (!s) return fail(ELLHIP_E_INVALID, "NULL handle");
+    std::vector<int32_t> st((size_t)std::max<long long>(s->qk, 1));
+    const int rc = ellhip_queue_results(s->sh, st.data(), tsq_out);
+    if (rc) return rc;
+    for (long long i = 0; i < s->qk; ++i)
+        if (st[(size_t)i] > 0) s->primed_index = -1;  // the queue halted: nothing stays primed
+    if (status_out) memcpy(status_out, st.data(), (size_t)s->qk * sizeof(int32_t));
+    return 0;
+}
+
+int ellhip_sharded_synchronize(ellhip_sharded* s) {
+    return s ? ellhip_synchronize(s->sh) : fail(ELLHIP_E_INVALID, "NULL handle");
+}
+
+ellhip_space* ellhip_sharded_local(ellhip_sharded* s) { return s ? s->sh : nullptr; }
+
+int ellhip_shards_exchange(ellhip_space* const* shards, int nshards) {
+    if (!shards || nshards < 1) return fail(ELLHIP_E_INVALID, "no shards");
+    long long covered = 0;
+    for (int a = 0; a < nshards; ++a) {
+        const ellhip_space* s = shards[a];
+        if (!s || !s->sharded || s->variant != ELLHIP_SPACE_ELL || s->shard_symmetric || s->n != shards[0]->n)
+            return fail(ELLHIP_E_INVALID, "ellhip_shards_exchange: equal-block Ell row shards of one matrix expected");
+        if (s->row0 != covered) return fail(ELLHIP_E_INVALID, "ellhip_shards_exchange: shards must be given in row order and tile the matrix");
+        covered += s->nrows;
+    }
+    if (covered != shards[0]->n) return fail(ELLHIP_E_INVALID, "ellhip_shards_exchange: the shards do not cover all rows");
+    // the local passes must have produced their rows before anybody copies them
+    for (int a = 0; a < nshards; ++a) {
+        DeviceGuard guard(shards[a]->device);
+        HIPCHK(hipStreamSynchronize(shards[a]->stream));
+    }
+    for (int d = 0; d < nshards; ++d) {
+        ellhip_space* dst = shards[d];
+        DeviceGuard guard(dst->device);
+        double* gt_d = dst->d_gt[dst->cur];
+        for (int a = 0; a < nshards; ++a) {
+            if (a == d) continue;
+            const ellhip_space* src = shards[a];
+            const double* gt_s = src->d_gt[src->cur];
+            const size_t bytes = (size_t)src->nrows * sizeof(double);
+            if (src->device == dst->device)
+                HIPCHK(hipMemcpyAsync(gt_d + src->row0, gt_s + src->row0, bytes, hipMemcpyDeviceToDevice, dst->stream));
+            else
+                HIPCHK(hipMemcpyPeerAsync(gt_d + src->row0, dst->device, gt_s + src->row0, src->device, bytes, dst->stream));
+        }
+    }
+    // a source's slot may be rewritten by its owner's next pass only after every reader has copied it
+    for (int d = 0; d < nshards; ++d) {
+        DeviceGuard guard(shards[d]->device);
+        HIPCHK(hipStreamSynchronize(shards[d]->stream));
+    }
+    return 0;
+}
+
+}  // extern "C"

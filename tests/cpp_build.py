@@ -21,7 +21,7 @@ def build_runner(src: str, backend: str) -> str:
     host = os.path.join(ROOT, "ellalgo-rs_amd", "host", "ellhip")
     deps = [os.path.join(CPP, f) for f in os.listdir(CPP) if f.endswith((".cpp", ".hpp"))]
     deps += [os.path.join(host, f) for f in os.listdir(host)]
-    deps += [os.path.join(ROOT, "include", f) for f in ("ellhip.h", "ellhip_lowpass.h", "ellhip_batch.h", "ellhip_lmi.h")]
+    deps += [os.path.join(ROOT, "include", f) for f in ("ellhip.h", "ellhip_lowpass.h", "ellhip_batch.h", "ellhip_lmi.h", "ellhip_sharded.h")]
     if backend == "oracle":
         from oracle import oracle
         oracle.build()

@@ -32,7 +32,29 @@ from util import mixed_cut  # noqa: E402
 REF_STATUS = {0: RefStatus.SUCCESS, 1: RefStatus.NO_SOLN, 2: RefStatus.NO_EFFECT, 3: RefStatus.UNKNOWN}
 
 
-def generate(n: int, k: int, seed: int, no_defer: bool):
+def q_cut(i, tau, n, rng):
+    """Discrete-q sequence (update_q only) that reaches every return of calc_parallel_q / calc_bias_cut_q
+    (src/ell_calc.rs:787-812, 892-908): NoEffect through eta = tsq + n b0 b1 <= 0 and through eta = tau + n beta < 0,
+    NoSoln (beta1 < beta0; tau < beta), the fall-back to the single cut (beta1^2 >= tsq) and both Success forms."""
+    sel = i % 8
+    if sel == 0:
+        return 2, -0.01 * tau * rng.random(), tau * (0.2 + 0.5 * rng.random())   # parallel, eta > 0: Success
+    if sel == 1:
+        return 2, -tau * (0.3 + 0.3 * rng.random()), tau * (0.5 + 0.3 * rng.random())  # parallel, eta <= 0: NoEffect
+    if sel == 2:
+        return 2, 0.1 * tau * rng.random(), None                                  # single, Success
+    if sel == 3:
+        return 2, -tau * (2.0 / n + 0.2 * rng.random()), None                     # single, eta < 0: NoEffect
+    if sel == 4:
+        return 2, 0.05 * tau, tau * (1.0 + rng.random())                          # beta1^2 >= tsq: single cut with beta0
+    if sel == 5:
+        return 2, 0.3 * tau, 0.1 * tau                                            # beta1 < beta0: NoSoln
+    if sel == 6:
+        return 2, -tau * (0.5 + 0.2 * rng.random()), tau * (1.2 + rng.random())   # fall-back, then eta < 0: NoEffect
+    return 2, 1.5 * tau, None                                                     # tau < beta: NoSoln
+
+
+def generate(n: int, k: int, seed: int, no_defer: bool, cuts=None):
     rng = np.random.default_rng(seed)
     kappa0 = 2.0
     xc0 = np.linspace(-1.0, 1.0, n)
@@ -45,7 +67,7 @@ def generate(n: int, k: int, seed: int, no_defer: bool):
         g = rng.standard_normal(n)
         g /= np.linalg.norm(g)
         tau = float(np.sqrt(max(ref.kappa * (g @ (ref.mq @ g)), 0.0)))
-        kind, b0, b1 = mixed_cut(i, g, tau, rng)
+        kind, b0, b1 = mixed_cut(i, g, tau, rng) if cuts is None else cuts(i, tau, n, rng)
         st = ref._update_core(g, (b0, b1), lambda beta, tsq: (
             lambda r: (REF_STATUS[r[0]], r[1]))(calc.dispatch(kind, beta[0], beta[1], tsq)))
         kinds.append(kind), grads.append(g), b0s.append(b0), b1s.append(np.nan if b1 is None else b1)
@@ -63,3 +85,9 @@ if __name__ == "__main__":
         name = os.path.join(HERE, f"ell_dense_n{n}{'_nodefer' if nd else ''}.npz")
         np.savez_compressed(name, **d)
         print(name, "statuses:", np.bincount(d["status"], minlength=3))
+    for n, k in [(16, 48)]:
+        d = generate(n, k, seed=2000 + n, no_defer=False, cuts=q_cut)
+        name = os.path.join(HERE, f"ell_dense_n{n}_qcuts.npz")
+        np.savez_compressed(name, **d)
+        print(name, "statuses:", np.bincount(d["status"], minlength=3))
+        assert np.all(np.bincount(d["status"], minlength=3) > 0)   # Success, NoSoln AND NoEffect all occur

@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def declared_functions():
     names = set()
-    for header in ("ellhip.h", "ellhip_lowpass.h", "ellhip_batch.h", "ellhip_lmi.h"):
+    for header in ("ellhip.h", "ellhip_lowpass.h", "ellhip_batch.h", "ellhip_lmi.h", "ellhip_sharded.h"):
         src = open(os.path.join(ROOT, "include", header)).read()
         src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
         names.update(re.findall(r"\b(ellhip_[a-z0-9_]+)\s*\(", src))

@@ -128,7 +128,10 @@ def _close_in_blocks(qg, qo, tol, what):
 def test_ell_default_schedule_matches_oracle_at_full_size(gpu, orc):
     """The timed configuration itself (n = 16384, parallel cuts, depth 16, lower-triangle GEMV + lower-trapezoid
     apply, pipelined queue) against the CPU oracle on the same 18 cuts -- one apply pass at cut 16, two cuts
-    still recorded when the state is read.  Whole state to the north-star tolerance."""
+    still recorded when the state is read.  Whole state to the north-star tolerance.
+    (The checker is the oracle's row-parallel loop `update_rowwise_mt`, used here for speed only: the reference's loop
+    order takes seconds per update at this size; tests/test_oracle_pins.py ties it bit for bit to the reference loop
+    at n = 37, 257 and 2048.)"""
     from ellalgo_rs_amd import synth
     from util import TOL
     k = 18

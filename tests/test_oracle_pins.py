@@ -197,3 +197,29 @@ def test_rowwise_openmp_variant_is_bit_identical_to_the_serial_row_wise_form():
         beta = 0.02 * (i % 3)
         assert a.update_rowwise(0, g, beta) == b.update_rowwise_mt(0, g, beta)
     assert np.array_equal(a.mq, b.mq) and np.array_equal(a.xc, b.xc) and a.kappa == b.kappa and a.tsq == b.tsq
+
+
+def test_three_oracle_loops_agree_bit_for_bit_at_n2048():
+    """The full-size GPU tests (tests/test_gpu_fullsize.py, n = 16384 / 32768) check against `update_rowwise_mt`
+    -- the row-parallel OpenMP form of the same arithmetic -- because the reference's loop order (column-strided mirror
+    stores, src/ell.rs:117-128) takes seconds per update there.  This pins that checker to the reference loop at a size
+    where all three still run quickly: `update` (reference loop order), `update_rowwise` and `update_rowwise_mt` must
+    leave bit-identical Q, xc, kappa, tsq and statuses over a mixed sequence (all six EllCalc entry points, one
+    failing cut)."""
+    import numpy as np
+    from oracle import oracle as O
+    from util import mixed_cut
+    n = 2048
+    rng = np.random.default_rng(2048)
+    xc0 = np.linspace(-1.0, 1.0, n)
+    a, b, c = (O.OracleEll.new_with_scalar(2.0, xc0) for _ in range(3))
+    for i in range(8):
+        g = rng.standard_normal(n)
+        g /= np.linalg.norm(g)
+        tau = float(np.sqrt(a.kappa * (g @ (a.mq @ g))))
+        kind, b0, b1 = mixed_cut(i, g, tau, rng)
+        sa, sb, sc = a.update(kind, g, b0, b1), b.update_rowwise(kind, g, b0, b1), c.update_rowwise_mt(kind, g, b0, b1)
+        assert sa == sb == sc == (1 if i == 7 else 0)
+        assert a.tsq == b.tsq == c.tsq and a.kappa == b.kappa == c.kappa
+    assert np.array_equal(a.mq, b.mq) and np.array_equal(a.mq, c.mq)
+    assert np.array_equal(a.xc, b.xc) and np.array_equal(a.xc, c.xc)
