@@ -562,9 +562,29 @@ def main() -> None:
     elif not sharded:
         space = pkg.Ell.new_with_scalar(1.0, np.zeros(n), device=local_rank)
     else:
-        from ellalgo_rs_amd.sharded import ShardedEll
-        space = ShardedEll.new_with_scalar(1.0, np.zeros(n), device=local_rank, symmetric=shard_sym,
-                                          defer_depth=depth if shard_sym else 8)
+        # The row-partitioned space behind the C ABI (include/ellhip_sharded.h): libellhip.so issues the one collective
+        # of an update through RCCL itself and the pipelined loop over the queue runs in C.  torch.distributed only
+        # carries the communicator's unique id to the ranks (and the fences / the max-over-ranks clock below).
+        # ELLHIP_BENCH_SHARDED=torch selects the older orchestration of the same shard handle through
+        # torch.distributed collectives (ellalgo-rs_amd/sharded.py); it is also the fallback if RCCL cannot be opened.
+        space = None
+        if os.environ.get("ELLHIP_BENCH_SHARDED", "abi") == "abi":
+            from ellalgo_rs_amd import sharded_abi
+            try:
+                ids = [sharded_abi.unique_id() if rank == 0 else None]
+                dist.broadcast_object_list(ids, src=0)
+                space = pkg.ShardedEllAbi.new_with_scalar(1.0, np.zeros(n), device=local_rank, rank=rank, nranks=world,
+                                                          nccl_id=ids[0], symmetric=shard_sym,
+                                                          defer_depth=depth if shard_sym else 8)
+                sharded_via = "c-abi (RCCL inside libellhip.so)"
+            except pkg.capi.EllHipError as e:
+                log(f"[rank {rank}] C-ABI sharded space unavailable ({e}); falling back to torch.distributed")
+                space = None
+        if space is None:
+            from ellalgo_rs_amd.sharded import ShardedEll
+            space = ShardedEll.new_with_scalar(1.0, np.zeros(n), device=local_rank, symmetric=shard_sym,
+                                              defer_depth=depth if shard_sym else 8)
+            sharded_via = "torch.distributed"
     nq = W + K + P + 2 * C2 * len(alts)
     if variant == "ell" and not shard_sym:   # always explicit: a new unsharded handle may start at depth 16 by itself
         space.set_defer_depth(depth) if sharded else setattr(space, "defer_depth", depth)
@@ -780,7 +800,8 @@ def main() -> None:
                                  else f"row-block x{world} (all-gather)") if sharded
                                 else (f"replicas only x{world} (independent search spaces, no data-path collective)"
                                       if replicas else "none"),
-                   "q_bytes_per_gpu": 8.0 * n * n / (1 if replicas else world)},
+                   "q_bytes_per_gpu": 8.0 * n * n / (1 if replicas else world),
+                   **({"collective_issued_by": sharded_via} if sharded else {})},
         "roofline": roofline,
     }
     if others:
