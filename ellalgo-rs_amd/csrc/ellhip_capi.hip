@@ -102,6 +102,8 @@ struct ellhip_space {
     int* d_flags = nullptr;          // EllStable persistent solves: block-ready flags (forward | backward)
     int epoch = 0;                   // hand-off epoch, bumped per persistent launch
     int stable_persist = 1;          // one-launch flag-chained solves (0: one launch per block)
+    int stable_pair = 0;             // experimental: two 128-blocks per workgroup (ELLHIP_STABLE_PAIR: bit 0 = forward, bit 1 = backward)
+    int persist_cap1 = 0, persist_cap2 = 0;  // workgroups of the one-block / paired persistent solves the device holds at once
     int stable_overlap = 1;          // factor update beside the persistent backward solve
     DevState* d_st = nullptr;
 
@@ -418,9 +420,13 @@ int ellstable_issue(ellhip_space* s, const double* g_dev, const CutParams* cp_de
     double* w1 = qpub + n;               // second publish buffer of the persistent forward solve (see below)
     double* cpre = w1 + n + (n & 1);     // chunk prefixes of the mid stage (ST_MID_T + 1 doubles)
     hipStream_t st = s->stream;
-    // One launch per solve when every 128-column strip can have its own resident workgroup; otherwise
-    // (n > 128 * 256) one launch per block.
-    const bool persist = s->stable_persist && nb <= 256;
+    // One launch per solve when every workgroup of the chain can be resident at once (a workgroup that waits for its
+    // predecessor holds its CU: the limit is what the DEVICE holds -- CU count x occupancy of the kernel, measured at
+    // handle creation -- not a constant); otherwise one launch per block.  Paired form: two 128-blocks per workgroup.
+    const long long npair = (nb + 1) / 2;
+    const bool pair_ok = s->stable_persist && npair <= s->persist_cap2;
+    const bool pair_fwd = pair_ok && (s->stable_pair & 1), pair_bwd = pair_ok && (s->stable_pair & 2);
+    const bool persist = pair_ok || (s->stable_persist && nb <= s->persist_cap1);
     // Persistent forward solve: the workgroup that is next in the chain polls the VALUES of the block it waits for
     // (sentinel until stored, like the backward solve's qpub), everybody else the block's flag.  The published
     // vector therefore has to be all-sentinel when a solve starts: two buffers alternate by launch parity, and the
@@ -431,7 +437,10 @@ int ellstable_issue(ellhip_space* s, const double* g_dev, const CutParams* cp_de
     int* err = reinterpret_cast<int*>(reinterpret_cast<char*>(s->d_st) + offsetof(DevState, solve_err));
     {
         ProfScope ps(s, CLS_ST_FWD);
-        if (persist) {
+        if (pair_fwd) {
+            hipLaunchKernelGGL(k_st_fwd_persist2, dim3((unsigned)npair), dim3(512), 0, st, s->d_Q, ld, n, g_dev, w, z, gg,
+                               s->d_flags, err, s->epoch, s->d_st);
+        } else if (persist) {
             hipLaunchKernelGGL(k_st_fwd_persist, dim3((unsigned)nb), dim3(256), 0, st, s->d_Q, ld, n, g_dev, w, z, gg,
                                s->d_flags, err, s->epoch, s->d_st);
         } else {
@@ -464,7 +473,10 @@ int ellstable_issue(ellhip_space* s, const double* g_dev, const CutParams* cp_de
     if (overlap) HIPCHK(hipEventRecord(s->ev_fork, st));
     {
         ProfScope ps(s, CLS_ST_BWD);
-        if (persist) {
+        if (pair_bwd) {
+            hipLaunchKernelGGL(k_st_bwd_persist2, dim3((unsigned)npair), dim3(512), 0, st, s->d_Q, ld, n, q, qpub, err,
+                               s->d_st);
+        } else if (persist) {
             hipLaunchKernelGGL(k_st_bwd_persist, dim3((unsigned)nb), dim3(256), 0, st, s->d_Q, ld, n, q, qpub, err,
                                s->d_st);
         } else {
@@ -682,8 +694,16 @@ int read_back(ellhip_space* s) {
     s->kappa = s->h_result->kappa;
     s->tsq = s->h_result->tsq;
     s->scalars_stale = false;
-    if (s->h_result->solve_err)
-        return fail(ELLHIP_E_HIP, "EllStable persistent solve: a flag wait timed out (set ELLHIP_STABLE_PERSIST=0)");
+    if (s->h_result->solve_err) {
+        // A bounded wait of a persistent solve gave up: this update's result is invalid and the call fails.  The
+        // error word is cleared once it has been reported and the handle falls back to one launch per block (no
+        // inter-workgroup waits), so the handle stays usable -- its state, though, is what the failed update left.
+        s->h_result->solve_err = 0;
+        (void)hipMemsetAsync(reinterpret_cast<char*>(s->d_st) + offsetof(DevState, solve_err), 0, sizeof(int), s->stream);
+        (void)hipStreamSynchronize(s->stream);
+        s->stable_persist = 0;
+        return fail(ELLHIP_E_HIP, "EllStable persistent solve: a bounded wait timed out; this handle now uses one launch per block");
+    }
     return 0;
 }
 
@@ -789,9 +809,27 @@ int alloc_common(ellhip_space* s) {
         HIPCHK(hipMemsetAsync(s->d_cpend, 0, MAXPEND * sizeof(double), s->stream));
     }
     if (s->variant == ELLHIP_SPACE_ELL_STABLE) {
-        HIPCHK(hipMalloc(&s->d_flags, 512 * sizeof(int)));
-        HIPCHK(hipMemsetAsync(s->d_flags, 0, 512 * sizeof(int), s->stream));
+        const size_t nflags = (size_t)std::max<long long>(512, (n + SB - 1) / SB);
+        HIPCHK(hipMalloc(&s->d_flags, nflags * sizeof(int)));
+        HIPCHK(hipMemsetAsync(s->d_flags, 0, nflags * sizeof(int), s->stream));
         s->stable_persist = env_int("ELLHIP_STABLE_PERSIST", 1);
+        s->stable_pair = env_int("ELLHIP_STABLE_PAIR", 0);   // measured slower than one block per workgroup
+        {   // how many workgroups of each persistent solve this device keeps resident at once
+            hipDeviceProp_t prop;
+            HIPCHK(hipGetDeviceProperties(&prop, s->device));
+            auto cap = [&](const void* fwd, const void* bwd, int threads) -> int {
+                int a = 0, b = 0;
+                if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, fwd, threads, 0) != hipSuccess) a = 0;
+                if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, bwd, threads, 0) != hipSuccess) b = 0;
+                return std::min(a, b) * prop.multiProcessorCount;
+            };
+            s->persist_cap1 = cap((const void*)k_st_fwd_persist, (const void*)k_st_bwd_persist, 256);
+            s->persist_cap2 = cap((const void*)k_st_fwd_persist2, (const void*)k_st_bwd_persist2, 512);
+            // (the factor update runs beside the backward solve on the auxiliary stream, launched after it: the
+            // solve's workgroups are placed first, and every wait in the solves is bounded)
+            s->persist_cap1 = env_int("ELLHIP_STABLE_CAP", s->persist_cap1);
+            s->persist_cap2 = env_int("ELLHIP_STABLE_CAP2", s->persist_cap2);
+        }
         s->stable_overlap = env_int("ELLHIP_STABLE_OVERLAP", 1);
         HIPCHK(hipStreamCreateWithFlags(&s->aux_stream, hipStreamNonBlocking));
         HIPCHK(hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming));
@@ -1094,6 +1132,10 @@ int ellhip_clone(const ellhip_space* src_c, ellhip_space** out) {
     s->upper_stale = src->upper_stale;
     s->symv_seg = src->symv_seg;
     rc = alloc_common(s);
+    if (!rc) {
+        s->stable_persist = src->stable_persist;
+        s->stable_pair = src->stable_pair;
+    }
     if (rc) {
         ellhip_destroy(s);
         return rc;

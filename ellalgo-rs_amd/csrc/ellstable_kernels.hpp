@@ -61,9 +61,11 @@ __device__ __forceinline__ double lane_bcast(double v, int j) {
 }
 
 // piece rows r = (tid >> 5) + 8k, column pair cp = tid & 31
+// (`tid`: the thread's index inside the group of 256 threads that shares the block -- threadIdx.x everywhere except in
+// the paired persistent solves, where a workgroup of 512 threads holds two such groups)
 __device__ __forceinline__ void st_load_piece(const double* __restrict__ M, long long ld, long long n,
-                                              long long r0, long long c0, double2_t (&v)[8]) {
-    const int tr = threadIdx.x >> 5, cp = threadIdx.x & 31;
+                                              long long r0, long long c0, double2_t (&v)[8], int tid) {
+    const int tr = tid >> 5, cp = tid & 31;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
         long long r = r0 + tr + 8 * k, c = c0 + 2 * cp;
@@ -72,8 +74,8 @@ __device__ __forceinline__ void st_load_piece(const double* __restrict__ M, long
         v[k] = *reinterpret_cast<const double2_t*>(M + r * ld + c);
     }
 }
-__device__ __forceinline__ void st_park_piece(double* __restrict__ lds, const double2_t (&v)[8]) {
-    const int tr = threadIdx.x >> 5, cp = threadIdx.x & 31;
+__device__ __forceinline__ void st_park_piece(double* __restrict__ lds, const double2_t (&v)[8], int tid) {
+    const int tr = tid >> 5, cp = tid & 31;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {  // two 8-byte writes: rows are not 16-byte aligned with the odd pitch
         lds[(tr + 8 * k) * BLK_PITCH + 2 * cp] = v[k].x;
@@ -117,8 +119,8 @@ __device__ __forceinline__ double st_fwd_mini_regs(double (&u)[SH], const double
 // the strict lower triangle of the piece belongs to S (the rest is factor / diagonal, never touched).
 __device__ __forceinline__ void st_store_piece(double* __restrict__ M, long long ld, long long n,
                                                long long R0, long long C0, const double* __restrict__ piece,
-                                               bool lower_only) {
-    const int tr = threadIdx.x >> 5, cp = threadIdx.x & 31;
+                                               bool lower_only, int tid) {
+    const int tr = tid >> 5, cp = tid & 31;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
         const int r = tr + 8 * k;
@@ -197,20 +199,23 @@ __device__ __forceinline__ void st_fwd_diag_block(double* __restrict__ M, long l
                                                   double* __restrict__ dlds, const double* __restrict__ wpart,
                                                   double* __restrict__ w, double* __restrict__ z,
                                                   double* __restrict__ gg, int* flag = nullptr, int epoch = 0,
-                                                  bool parked = false) {
+                                                  bool parked = false, int tid = threadIdx.x,
+                                                  double* __restrict__ wout = nullptr) {
+    // tid: index inside the 256-thread group that runs this block (all of them call; nobody else may).
+    // wout (LDS, 128 doubles): the block's final w for a consumer in the same workgroup, complete at the last barrier.
     __shared__ double wab[2][SH];  // [0]: final w of half A; [1]: partial w of half B after the mini panel
     double* pAA = lds;
     double* pAB = lds + SH * BLK_PITCH;
     double* pBB = lds + 2 * SH * BLK_PITCH;
     if (!parked) {  // (the persistent solve parks while it waits for the previous block: st_fwd_park)
-        st_park_piece(pAA, blk.aa);
-        st_park_piece(pAB, blk.ab);
-        st_park_piece(pBB, blk.bb);
-        if (threadIdx.x < SB) dlds[threadIdx.x] = dreg;
+        st_park_piece(pAA, blk.aa, tid);
+        st_park_piece(pAB, blk.ab, tid);
+        st_park_piece(pBB, blk.bb, tid);
+        if (tid < SB) dlds[tid] = dreg;
         __syncthreads();
     }
     const bool has_b = J0 + SH < n;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wave = tid >> 6, lane = tid & 63;
     double* mine = wave == 0 ? pAA : (wave == 1 ? pAB : pBB);
     const bool busy = wave == 0 || (has_b && wave <= 2);
     double u[SH];
@@ -222,6 +227,7 @@ __device__ __forceinline__ void st_fwd_diag_block(double* __restrict__ M, long l
     __syncthreads();
     if (wave == 0) {
         const double wA = wab[0][lane];
+        if (wout) wout[lane] = wA;
         const long long c = J0 + lane;
         if (c < n) {
             const double zi = wA * dlds[lane];  // :74
@@ -237,6 +243,7 @@ __device__ __forceinline__ void st_fwd_diag_block(double* __restrict__ M, long l
     __syncthreads();
     if (wave == 2 && has_b) {
         const double wB = st_fwd_chain_regs(u, wab[1][lane]);
+        if (wout) wout[SH + lane] = wB;
         const long long c = J0 + SH + lane;
         if (PUBLISH) {  // all 128 values by this wave, then its flag store (half A always lies inside the matrix here)
             st_publish_store(w + J0 + lane, wab[0][lane]);
@@ -256,32 +263,54 @@ __device__ __forceinline__ void st_fwd_diag_block(double* __restrict__ M, long l
         for (int j = 0; j < SH; ++j) mine[lane * BLK_PITCH + j] = u[j];
     }
     __syncthreads();
-    st_store_piece(M, ld, n, J0, J0, pAA, true);                       // S[A][A], strict lower
+    st_store_piece(M, ld, n, J0, J0, pAA, true, tid);                  // S[A][A], strict lower
     if (has_b) {
-        st_store_piece(M, ld, n, J0 + SH, J0, pAB, false);             // S[B][A], full
-        st_store_piece(M, ld, n, J0 + SH, J0 + SH, pBB, true);         // S[B][B], strict lower
+        st_store_piece(M, ld, n, J0 + SH, J0, pAB, false, tid);        // S[B][A], full
+        st_store_piece(M, ld, n, J0 + SH, J0 + SH, pBB, true, tid);    // S[B][B], strict lower
     }
 }
 
 __device__ __forceinline__ void st_fwd_park(const Blk3& blk, double dreg, double* __restrict__ lds,
-                                            double* __restrict__ dlds) {
-    st_park_piece(lds, blk.aa);
-    st_park_piece(lds + SH * BLK_PITCH, blk.ab);
-    st_park_piece(lds + 2 * SH * BLK_PITCH, blk.bb);
-    if (threadIdx.x < SB) dlds[threadIdx.x] = dreg;
+                                            double* __restrict__ dlds, int tid = threadIdx.x) {
+    st_park_piece(lds, blk.aa, tid);
+    st_park_piece(lds + SH * BLK_PITCH, blk.ab, tid);
+    st_park_piece(lds + 2 * SH * BLK_PITCH, blk.bb, tid);
+    if (tid < SB) dlds[tid] = dreg;
 }
 
 __device__ __forceinline__ void st_prefetch_block(const double* __restrict__ M, long long ld, long long n,
-                                                  long long J0, Blk3& blk, double& dreg) {
-    st_load_piece(M, ld, n, J0, J0, blk.aa);
-    st_load_piece(M, ld, n, J0, J0 + SH, blk.ab);
-    st_load_piece(M, ld, n, J0 + SH, J0 + SH, blk.bb);
-    long long dj = J0 + (threadIdx.x & (SB - 1));
+                                                  long long J0, Blk3& blk, double& dreg, int tid = threadIdx.x) {
+    st_load_piece(M, ld, n, J0, J0, blk.aa, tid);
+    st_load_piece(M, ld, n, J0, J0 + SH, blk.ab, tid);
+    st_load_piece(M, ld, n, J0 + SH, J0 + SH, blk.bb, tid);
+    long long dj = J0 + (tid & (SB - 1));
     if (dj > n - 1) dj = n - 1;
     dreg = M[dj * ld + dj];
 }
 
 constexpr int ST_LDS_DOUBLES = 3 * SH * BLK_PITCH;  // 96 KiB: the three parked pieces (the panel tile aliases it)
+
+// Workgroup barrier WITHOUT the wait for the wave's outstanding memory operations that __syncthreads() puts in front of
+// it: for the side of a paired solve that only keeps the other side's barrier count (its prefetches stay in flight
+// across the barrier; s_barrier itself waits for no counter).  The asm's memory clobber keeps the compiler from moving
+// LDS accesses across it.
+__device__ __forceinline__ void st_barrier_only() { asm volatile("s_barrier" ::: "memory"); }
+
+// Bring the three 64 x 64 pieces of the diagonal block at J0 (second / first / third piece at the given offsets) into
+// L2 without holding them: one 8-byte load per 128-byte line, three per thread.  The paired solves use it for the
+// block whose registers they cannot afford yet (VGPR budget of a 512-thread workgroup).  Returns a value the caller
+// must keep alive.
+__device__ __forceinline__ double st_touch_block(const double* __restrict__ M, long long ld, long long n, long long J0,
+                                                 int tid) {
+    const long long row = tid >> 2, off = 16 * (tid & 3);
+    auto at = [&](long long r, long long c) {
+        if (r > n - 1) r = n - 1;
+        if (c > n - 1) c = 0;
+        return M[r * ld + c];
+    };
+    return at(J0 + row, J0 + off) + at(J0 + row, J0 + SH + off) + at(J0 + SH + row, J0 + SH + off) +
+           at(J0 + SH + row, J0 + off);
+}
 
 __global__ __launch_bounds__(256) void k_st_fwd_first(double* __restrict__ M, long long ld, long long n,
                                                       const double* __restrict__ g, double* __restrict__ w,
@@ -527,6 +556,259 @@ __global__ __launch_bounds__(256) void k_st_fwd_persist(double* __restrict__ M, 
     }
 }
 
+// Paired persistent forward solve: workgroup t (512 threads) owns TWO consecutive 128-blocks, A = 2t and B = 2t + 1.
+// Threads 0..255 ("group 0") do for block A exactly what a workgroup of k_st_fwd_persist does for its block, threads
+// 256..511 ("group 1") the same for block B; the row blocks above the pair are applied by both groups side by side
+// (each to its own 128 columns) as their w arrives from the workgroups before.  What changes is the hand-off INSIDE the
+// pair: block A's result reaches group 1 through LDS (no store / poll round trip through memory, ~3 us under load), so
+// the chain pays one inter-workgroup hand-off per 256 columns instead of one per 128, and block A is published while
+// block B is still being solved (the next workgroup applies it meanwhile).  Same arithmetic in the same order per
+// column as k_st_fwd_persist / k_st_fwd_step: identical bits.
+//   The two groups run different code between the same barriers (the branch is on a scalar, so a wave executes the
+//   s_barrier of its own side only): while group 0 runs A's chain, group 1 fetches B's diagonal block and the rows of
+//   the inner panel; group 1's registers are not live on group 0's side, which keeps the chain's 128 VGPRs free.
+//   LDS: ONE diagonal block is parked at a time (A's, then B's, in the same 97.5 KB); the transpose tiles of both
+//   groups' write-backs alias it (144 KB in all).
+constexpr int ST_LDS2_DOUBLES = 2 * 4 * SPANEL * SLDS_PAD;  // 18432 doubles; the parked pieces (12480) alias its start
+
+// ONE copy of the diagonal-block code for both groups of a paired solve (a real call): inlined at both call sites the
+// kernels grew to ~100 KB of straight-line code, more than the instruction cache holds, and every block's chain was
+// fetched from L2 again (forward solve 4.1 ms instead of 0.95).
+__device__ __noinline__ void st_fwd_diag_block_call(double* __restrict__ M, long long ld, long long n, long long J0,
+                                                    double* __restrict__ lds, double* __restrict__ dlds,
+                                                    const double* __restrict__ wpart, double* __restrict__ w,
+                                                    double* __restrict__ z, double* __restrict__ gg, int* flag, int epoch,
+                                                    int tid, double* __restrict__ wout) {
+    Blk3 none;   // the block is parked in LDS already (a register block by reference would travel through scratch)
+    st_fwd_diag_block<true>(M, ld, n, J0, none, 0.0, lds, dlds, wpart, w, z, gg, flag, epoch, true, tid, wout);
+}
+
+__global__ __launch_bounds__(512) void k_st_fwd_persist2(double* __restrict__ M, long long ld, long long n,
+                                                         const double* __restrict__ g, double* __restrict__ w,
+                                                         double* __restrict__ z, double* __restrict__ gg,
+                                                         int* __restrict__ flags, int* __restrict__ err, int epoch,
+                                                         const DevState* __restrict__ st) {
+    if (st->halted) return;
+    __shared__ __attribute__((aligned(16))) double lds[ST_LDS2_DOUBLES];
+    __shared__ double part[2][4][SPANEL];
+    __shared__ double wstrip[2][SPANEL];
+    __shared__ double wblk[SB];   // w of the row block being applied (from another workgroup)
+    __shared__ double wA[SB];     // w of this pair's block A, for group 1's inner panel
+    __shared__ double dlds[SB];
+    __shared__ int ok;
+    const int grp = __builtin_amdgcn_readfirstlane(threadIdx.x >> 8);  // scalar: the two sides below branch uniformly
+    const int lt = threadIdx.x & 255;
+    const int lane = lt & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(lt >> 6);
+    const long long nblk = (n + SB - 1) / SB;
+    const long long blkA = 2 * (long long)blockIdx.x;
+    const bool hasB = blkA + 1 < nblk;
+    const bool act = grp == 0 || hasB;  // an odd block count leaves the last workgroup's group 1 without a block
+    const long long c0 = (blkA + grp) * SB;
+    const long long c = c0 + 2 * lane;
+    const long long cl = (act && c < n) ? c : 0;
+    const int piece = lane & 7;
+
+    Blk3 blk;
+    double dreg = 0.0;
+    if (act && lt < SPANEL) wstrip[grp][lt] = (c0 + lt < n) ? g[c0 + lt] : 0.0;
+    double* t = lds + (grp * 4 + wv) * (SPANEL * SLDS_PAD);
+    double2_t u[2][16];
+    // products S[col][row] = U[row][col] * w[row] of a row block, transposed through LDS into full 128-byte lines of S
+    // (the barriers are met by every thread; `doit`: this thread's group has something to write)
+    auto write_back = [&](long long J0, bool recompute, const double* wsrc, bool doit) {
+        if (recompute && doit) {
+            const double* rp = M + (J0 + 32 * wv) * ld + cl;   // one running pointer (32 row addresses would be 64 VGPRs)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const double2_t f = *reinterpret_cast<const double2_t*>(rp);
+                    rp += ld;
+                    const double wj = wsrc[32 * wv + 16 * h + r];
+                    u[h][r].x = f.x * wj;
+                    u[h][r].y = f.y * wj;
+                }
+            }
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const long long r0 = J0 + 32 * wv + 16 * h;
+            if (h) __syncthreads();  // the tile of the previous pass has been drained
+            if (doit) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    t[(2 * lane) * SLDS_PAD + r] = u[h][r].x;
+                    t[(2 * lane + 1) * SLDS_PAD + r] = u[h][r].y;
+                }
+            }
+            __syncthreads();
+            if (doit) {
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    const int col_local = 8 * k + (lane >> 3);
+                    const long long col = c0 + col_local;
+                    if (col < n) {
+                        const double2_t v = *reinterpret_cast<const double2_t*>(&t[col_local * SLDS_PAD + 2 * piece]);
+                        *reinterpret_cast<double2_t*>(M + col * ld + r0 + 2 * piece) = v;
+                    }
+                }
+            }
+        }
+    };
+    // rows of the inner panel (block A's rows, block B's columns): group 1 only, fetched while group 0 solves A.  B's
+    // diagonal block is only brought into L2 then (st_touch_block) and fetched for real once the panel's registers are
+    // free: 128 + 96 VGPRs at once do not fit the 256 a wave of a 512-thread workgroup has.
+    double2_t u2[2][16];
+    Blk3 blkB;
+    double dregB = 0.0;
+    auto fetch_inner = [&]() -> double {
+        const double* rp = M + (blkA * SB + 32 * wv) * ld + cl;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                u2[h][r] = *reinterpret_cast<const double2_t*>(rp);
+                rp += ld;
+            }
+        }
+        return st_touch_block(M, ld, n, c0, lt);
+    };
+
+    for (long long kb = 0; kb < blkA; ++kb) {
+        const long long J0 = kb * SB;  // all 128 rows exist: J0 + 128 <= 128 blkA < n
+        if (kb == blkA - 1 && grp == 0) {
+            // block A's diagonal block: fetched AND parked while the block before is still being solved (`lds` is free:
+            // the last row block's products are written back at the very end); before the row loads below, so that the
+            // two never hold registers at the same time
+            st_prefetch_block(M, ld, n, c0, blk, dreg, lt);
+            st_fwd_park(blk, dreg, lds, dlds, lt);
+        }
+        if (act) {
+            const double* rp = M + (J0 + 32 * wv) * ld + cl;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    u[h][r] = *reinterpret_cast<const double2_t*>(rp);
+                    rp += ld;
+                }
+            }
+        }
+        if (kb >= blkA - 2) {
+            // the two blocks of the workgroup right before this one: next in the chain, poll the values themselves
+            // (the buffer is all-sentinel when the launch starts); one workgroup per block does, see k_st_fwd_persist
+            if (threadIdx.x == 0) ok = 1;
+            __syncthreads();
+            if (threadIdx.x < SB) {
+                double v = 0.0;
+                if (!st_poll_value(w + J0 + threadIdx.x, v)) ok = 0;
+                wblk[threadIdx.x] = v;
+            }
+            __syncthreads();
+        } else {
+            if (threadIdx.x == 0) ok = st_wait_flag(flags + kb, epoch) ? 1 : 0;
+            __syncthreads();
+            if (ok && threadIdx.x < SB) wblk[threadIdx.x] = st_published_load(w + J0 + threadIdx.x);
+            __syncthreads();
+        }
+        if (!ok) {
+            if (threadIdx.x == 0) atomicExch(err, 1);
+            return;
+        }
+        if (act) {
+            double p0 = 0.0, p1 = 0.0;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const double wj = wblk[32 * wv + 16 * h + r];
+                    const double v0 = u[h][r].x * wj;
+                    const double v1 = u[h][r].y * wj;
+                    p0 += v0;
+                    p1 += v1;
+                    u[h][r].x = v0;  // the product replaces the factor entry (src/ell_stable.rs:66)
+                    u[h][r].y = v1;
+                }
+            }
+            part[grp][wv][2 * lane] = p0;
+            part[grp][wv][2 * lane + 1] = p1;
+        }
+        __syncthreads();
+        if (act && lt < SPANEL) {
+            const double s4 = ((part[grp][0][lt] + part[grp][1][lt]) + part[grp][2][lt]) + part[grp][3][lt];
+            wstrip[grp][lt] = wstrip[grp][lt] - s4;
+        }
+        if (kb + 1 < blkA) {
+            write_back(J0, false, wblk, act);
+            __syncthreads();  // tiles drained, part / wblk reusable
+        }
+    }
+    __syncthreads();
+    const long long cA = blkA * SB;
+    // ---- block A (group 0) | group 1 fetches what it needs next; barriers: [park, first workgroup only] + 3
+    if (grp == 0) {
+        if (blkA == 0) {  // no panel work before the first block: nothing parked yet
+            st_prefetch_block(M, ld, n, cA, blk, dreg, lt);
+            st_fwd_park(blk, dreg, lds, dlds, lt);
+            __syncthreads();
+        }
+        st_fwd_diag_block_call(M, ld, n, cA, lds, dlds, wstrip[0], w, z, gg, flags + blkA, epoch, lt, wA);
+    } else {
+        const double keep = hasB ? fetch_inner() : 0.0;
+        if (blkA == 0) st_barrier_only();
+        st_barrier_only();
+        st_barrier_only();
+        st_barrier_only();
+        if (keep == 1.2345e300 && threadIdx.x == 999) atomicExch(err, 9);  // (keeps the touching loads alive; never true)
+    }
+    if (!hasB) {  // (uniform over the workgroup) odd block count: only the deferred write-back is left
+        __syncthreads();
+        if (blkA > 0) write_back((blkA - 1) * SB, true, wblk, grp == 0);
+        return;
+    }
+    // ---- inner panel: rows of block A applied to block B's columns, w_A straight from LDS
+    if (grp == 1) {
+        double p0 = 0.0, p1 = 0.0;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const double wj = wA[32 * wv + 16 * h + r];
+                p0 += u2[h][r].x * wj;   // (the products themselves are recomputed for the write-back at the end)
+                p1 += u2[h][r].y * wj;
+            }
+        }
+        part[1][wv][2 * lane] = p0;
+        part[1][wv][2 * lane + 1] = p1;
+        st_prefetch_block(M, ld, n, c0, blkB, dregB, lt);   // (from L2: touched while block A was being solved)
+    }
+    __syncthreads();  // (group 0 has also finished reading A's parked products: the pieces are free)
+    if (grp == 1) {
+        if (lt < SPANEL) {
+            const double s4 = ((part[1][0][lt] + part[1][1][lt]) + part[1][2][lt]) + part[1][3][lt];
+            wstrip[1][lt] = wstrip[1][lt] - s4;
+        }
+        st_fwd_park(blkB, dregB, lds, dlds, lt);
+    }
+    __syncthreads();
+    // ---- block B (group 1); 3 barriers
+    if (grp == 1) {
+        st_fwd_diag_block_call(M, ld, n, c0, lds, dlds, wstrip[1], w, z, gg, flags + blkA + 1, epoch, lt, nullptr);
+    } else {
+        st_barrier_only();
+        st_barrier_only();
+        st_barrier_only();
+    }
+    __syncthreads();  // B's parked products have been written back: `lds` is free for the transposes
+    // ---- deferred write-backs: the row block right above the pair (both groups), then block A's rows (group 1)
+    if (blkA > 0) {
+        write_back((blkA - 1) * SB, true, wblk, true);
+        __syncthreads();
+    }
+    write_back(cA, true, wA, grp == 1);
+}
+
 // ---------------------------------------------------------------------------------- mid -------
 // omega, tsq, EllCalc, kappa; prefix sums t_j; beta2_j; diagonal rescale; q <- z.
 // src/ell_stable.rs:78-90,107-113,120-122.  Two launches:
@@ -644,10 +926,10 @@ struct Blk3b {
     double2_t bb[8], ba[8], aa[8];
 };
 __device__ __forceinline__ void st_prefetch_block_bwd(const double* __restrict__ M, long long ld, long long n,
-                                                      long long J0, Blk3b& blk) {
-    st_load_piece(M, ld, n, J0 + SH, J0 + SH, blk.bb);
-    st_load_piece(M, ld, n, J0 + SH, J0, blk.ba);
-    st_load_piece(M, ld, n, J0, J0, blk.aa);
+                                                      long long J0, Blk3b& blk, int tid = threadIdx.x) {
+    st_load_piece(M, ld, n, J0 + SH, J0 + SH, blk.bb, tid);
+    st_load_piece(M, ld, n, J0 + SH, J0, blk.ba, tid);
+    st_load_piece(M, ld, n, J0, J0, blk.aa, tid);
 }
 
 // Register forms (sv[j] = piece[j][lane] already loaded).  nvalid = rows of the half that exist (64 except in the
@@ -700,18 +982,21 @@ template <bool PUBLISH>
 __device__ __forceinline__ void st_bwd_diag_block(long long n, long long J0, const Blk3b& blk,
                                                   double* __restrict__ lds, const double* __restrict__ qpart,
                                                   double* __restrict__ q, double* __restrict__ qpub = nullptr,
-                                                  bool parked = false) {
+                                                  bool parked = false, int tid = threadIdx.x,
+                                                  double* __restrict__ qout = nullptr) {
+    // tid: index inside the 256-thread group that runs this block; qout (LDS, 128 doubles): the block's final q for a
+    // consumer in the same workgroup, complete once every wave of the group has left this function and met a barrier.
     __shared__ double qab[2][SH];  // [0]: final q of half B; [1]: partial q of half A after the mini panel
     double* pBB = lds;
     double* pBA = lds + SH * BLK_PITCH;
     double* pAA = lds + 2 * SH * BLK_PITCH;
     if (!parked) {  // (the persistent solve parks while it waits for the previous block's values)
-        st_park_piece(pBB, blk.bb);
-        st_park_piece(pBA, blk.ba);
-        st_park_piece(pAA, blk.aa);
+        st_park_piece(pBB, blk.bb, tid);
+        st_park_piece(pBA, blk.ba, tid);
+        st_park_piece(pAA, blk.aa, tid);
         __syncthreads();
     }
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wave = tid >> 6, lane = tid & 63;
     const bool has_b = J0 + SH < n;
     if (!has_b) {  // ragged last block with one half only: one wave, one chain
         if (wave != 0) return;
@@ -720,6 +1005,7 @@ __device__ __forceinline__ void st_bwd_diag_block(long long n, long long J0, con
         for (int j = 0; j < SH; ++j) sv[j] = pAA[j * BLK_PITCH + lane];
         const int nvalid = (n - J0 < SH) ? (int)(n - J0) : SH;
         const double qA = st_bwd_chain_regs(sv, nvalid, qpart[lane]);
+        if (qout) qout[lane] = qA;
         if (J0 + lane < n) {
             q[J0 + lane] = qA;
             if (PUBLISH) st_publish_store(qpub + J0 + lane, qA);
@@ -736,6 +1022,7 @@ __device__ __forceinline__ void st_bwd_diag_block(long long n, long long J0, con
     if (wave == 0) qab[0][lane] = st_bwd_chain_regs(sv, nvalid_b, qpart[lane + SH]);
     __syncthreads();
     if (wave == 0) {
+        if (qout) qout[SH + lane] = qab[0][lane];
         if (J0 + SH + lane < n) {
             const double qB = qab[0][lane];
             q[J0 + SH + lane] = qB;
@@ -747,6 +1034,7 @@ __device__ __forceinline__ void st_bwd_diag_block(long long n, long long J0, con
     __syncthreads();
     if (wave == 2) {
         const double qA = st_bwd_chain_regs(sv, SH, qab[1][lane]);  // half A is complete whenever half B exists
+        if (qout) qout[lane] = qA;
         q[J0 + lane] = qA;
         if (PUBLISH) st_publish_store(qpub + J0 + lane, qA);
     }
@@ -865,9 +1153,9 @@ __global__ __launch_bounds__(256) void k_st_bwd_persist(const double* __restrict
         }
         if (kb == sblk + 1) {  // own diagonal block: fetched and parked in LDS while the values it waits for are computed
             st_prefetch_block_bwd(M, ld, n, c0, blk);
-            st_park_piece(lds, blk.bb);
-            st_park_piece(lds + SH * BLK_PITCH, blk.ba);
-            st_park_piece(lds + 2 * SH * BLK_PITCH, blk.aa);
+            st_park_piece(lds, blk.bb, threadIdx.x);
+            st_park_piece(lds + SH * BLK_PITCH, blk.ba, threadIdx.x);
+            st_park_piece(lds + 2 * SH * BLK_PITCH, blk.aa, threadIdx.x);
         }
         if (threadIdx.x < SB) {
             double v = 0.0;
@@ -901,6 +1189,174 @@ __global__ __launch_bounds__(256) void k_st_bwd_persist(const double* __restrict
     }
     __syncthreads();
     st_bwd_diag_block<true>(n, c0, blk, lds, qstrip, q, qpub, sblk < nblk - 1);
+}
+
+__device__ __noinline__ void st_bwd_diag_block_call(long long n, long long J0, double* __restrict__ lds,
+                                                    const double* __restrict__ qpart, double* __restrict__ q,
+                                                    double* __restrict__ qpub, int tid, double* __restrict__ qout) {
+    Blk3b none;  // parked already
+    st_bwd_diag_block<true>(n, J0, none, lds, qpart, q, qpub, true, tid, qout);
+}
+
+// Paired persistent backward solve (see k_st_fwd_persist2): workgroup t (512 threads) owns the blocks H = nblk - 1 - 2t
+// (group 0, solved first) and L = H - 1 (group 1); block H's q reaches group 1 through LDS.  Nothing is stored but q, so
+// only one diagonal block is ever parked and there are no transposes.  Identical bits to k_st_bwd_persist / _step.
+__global__ __launch_bounds__(512) void k_st_bwd_persist2(const double* __restrict__ M, long long ld, long long n,
+                                                         double* __restrict__ q, double* __restrict__ qpub,
+                                                         int* __restrict__ err, const DevState* __restrict__ st) {
+    if (!st->apply) return;
+    __shared__ double lds[ST_LDS_DOUBLES_B];
+    __shared__ double part[2][4][SPANEL];
+    __shared__ double qstrip[2][SPANEL];
+    __shared__ double qblk[SB];   // q of the row block being applied (from another workgroup)
+    __shared__ double qH[SB];     // q of this pair's block H, for group 1's inner panel
+    __shared__ int ok;
+    const int grp = __builtin_amdgcn_readfirstlane(threadIdx.x >> 8);
+    const int lt = threadIdx.x & 255;
+    const int lane = lt & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(lt >> 6);
+    const long long nblk = (n + SB - 1) / SB;
+    const long long blkH = nblk - 1 - 2 * (long long)blockIdx.x;
+    const bool hasL = blkH >= 1;
+    const bool act = grp == 0 || hasL;
+    const long long myblk = blkH - grp;
+    const long long c0 = (act ? myblk : 0) * SB;
+    const long long c = c0 + 2 * lane;  // columns c, c + 1 < c0 + 128 <= J0 of every row block applied here: inside the matrix
+
+    Blk3b blk;
+    if (act && lt < SPANEL) qstrip[grp][lt] = (c0 + lt < n) ? q[c0 + lt] : 0.0;
+    if (threadIdx.x == 0) ok = 1;
+    __syncthreads();
+
+    for (long long kb = nblk - 1; kb > blkH; --kb) {
+        const long long J0 = kb * SB;
+        if (kb == blkH + 1 && grp == 0) {  // block H's diagonal block: fetched and parked while the values it waits for
+            st_prefetch_block_bwd(M, ld, n, c0, blk, lt);   // are computed; before the row loads (registers)
+            st_park_piece(lds, blk.bb, lt);
+            st_park_piece(lds + SH * BLK_PITCH, blk.ba, lt);
+            st_park_piece(lds + 2 * SH * BLK_PITCH, blk.aa, lt);
+        }
+        // A wave of a 512-thread workgroup has 256 VGPRs (half of what k_st_bwd_persist's waves have), and ANY spill is
+        // ruinous here: scratch memory limits how many workgroups the device keeps resident, and a chain whose
+        // workgroups are not all resident serialises (measured: 1.55 ms instead of 0.92).  So the wave's 32 rows are held
+        // 16 at a time: the first 16 are requested before the wait, the other 16 once those have been consumed.
+        double2_t sv[16];
+        const long long rfirst = J0 + 32 * wv;
+        const double* rp = M + (rfirst > n - 1 ? n - 1 : rfirst) * ld + c;
+        auto load16 = [&](int h) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                sv[r] = *reinterpret_cast<const double2_t*>(rp);
+                if (rfirst + 16 * h + r < n - 1) rp += ld;
+            }
+        };
+        if (act) load16(0);
+        if (threadIdx.x < SB) {
+            double v = 0.0;
+            if (J0 + threadIdx.x < n && !st_poll_value(qpub + J0 + threadIdx.x, v)) ok = 0;
+            qblk[threadIdx.x] = v;
+        }
+        __syncthreads();
+        if (!ok) {
+            if (threadIdx.x == 0) atomicExch(err, 2);
+            return;
+        }
+        if (act) {
+            double p0 = 0.0, p1 = 0.0;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                if (h) load16(1);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const double qj = qblk[32 * wv + 16 * h + r];  // 0 for rows beyond n
+                    p0 += sv[r].x * qj;
+                    p1 += sv[r].y * qj;
+                }
+            }
+            part[grp][wv][2 * lane] = p0;
+            part[grp][wv][2 * lane + 1] = p1;
+        }
+        __syncthreads();
+        if (act && lt < SPANEL) {
+            const double s4 = ((part[grp][0][lt] + part[grp][1][lt]) + part[grp][2][lt]) + part[grp][3][lt];
+            qstrip[grp][lt] = qstrip[grp][lt] - s4;
+        }
+        __syncthreads();
+    }
+    __syncthreads();
+    const long long cH = blkH * SB;
+    const bool first = blockIdx.x == 0;          // block H is the matrix' last block: nothing above it, nothing parked yet
+    const bool h_two_halves = cH + SH < n;       // st_bwd_diag_block meets 2 barriers then, none for a one-half ragged block
+    // ---- block H (group 0) | group 1 fetches the inner panel's rows and block L's diagonal block
+    double2_t s2[16];   // the first 16 of the wave's 32 rows of the inner panel; the other 16 follow when these are consumed
+    Blk3b blkL;
+    double keepL = 0.0;
+    const long long rfirst2 = cH + 32 * wv;
+    const double* rp2 = M + (rfirst2 > n - 1 ? n - 1 : rfirst2) * ld + c;
+    auto load16_inner = [&](int h) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            s2[r] = *reinterpret_cast<const double2_t*>(rp2);
+            if (rfirst2 + 16 * h + r < n - 1) rp2 += ld;
+        }
+    };
+    if (grp == 0) {
+        if (first) {
+            st_prefetch_block_bwd(M, ld, n, cH, blk, lt);
+            st_park_piece(lds, blk.bb, lt);
+            st_park_piece(lds + SH * BLK_PITCH, blk.ba, lt);
+            st_park_piece(lds + 2 * SH * BLK_PITCH, blk.aa, lt);
+            __syncthreads();
+        }
+        st_bwd_diag_block<true>(n, cH, blk, lds, qstrip[0], q, qpub, true, lt, qH);
+    } else {
+        if (hasL) {
+            load16_inner(0);
+            keepL = st_touch_block(M, ld, n, c0, lt);   // block L's diagonal block and the panel's other rows: into L2 only for now
+        }
+        if (first) st_barrier_only();
+        if (h_two_halves) {
+            st_barrier_only();
+            st_barrier_only();
+        }
+        if (keepL == 1.2345e300 && threadIdx.x == 999) atomicExch(err, 9);  // (keeps the loads alive; never true)
+    }
+    if (!hasL) return;   // (uniform) odd block count: block 0 was this workgroup's only block
+    __syncthreads();     // q_H complete in LDS; block H's parked pieces are no longer read
+    // ---- inner panel: rows of block H (scratch triangle) applied to block L's columns, q_H straight from LDS
+    if (grp == 1) {
+        double p0 = 0.0, p1 = 0.0;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            if (h) load16_inner(1);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const long long row = cH + 32 * wv + 16 * h + r;
+                const double qj = (row < n) ? qH[32 * wv + 16 * h + r] : 0.0;  // rows beyond n count nothing
+                p0 += s2[r].x * qj;
+                p1 += s2[r].y * qj;
+            }
+        }
+        part[1][wv][2 * lane] = p0;
+        part[1][wv][2 * lane + 1] = p1;
+        st_prefetch_block_bwd(M, ld, n, c0, blkL, lt);   // (from L2)
+        st_park_piece(lds, blkL.bb, lt);
+        st_park_piece(lds + SH * BLK_PITCH, blkL.ba, lt);
+        st_park_piece(lds + 2 * SH * BLK_PITCH, blkL.aa, lt);
+    }
+    __syncthreads();
+    if (grp == 1 && lt < SPANEL) {
+        const double s4 = ((part[1][0][lt] + part[1][1][lt]) + part[1][2][lt]) + part[1][3][lt];
+        qstrip[1][lt] = qstrip[1][lt] - s4;
+    }
+    __syncthreads();
+    // ---- block L (group 1): a full block (two halves): 2 barriers
+    if (grp == 1) {
+        st_bwd_diag_block<true>(n, c0, blkL, lds, qstrip[1], q, qpub, true, lt);
+    } else {
+        st_barrier_only();
+        st_barrier_only();
+    }
 }
 
 // xc -= (rho/omega) q   (src/ell_stable.rs:101-104)

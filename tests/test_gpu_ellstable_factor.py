@@ -90,6 +90,29 @@ def test_persistent_equals_per_block_launches_on_random_factor(gpu, monkeypatch,
     assert _offdiag_nonzeros(a.mq) > 0
 
 
+@pytest.mark.parametrize("n", [129, 300, 1000, 2048, 2048 + 128])
+def test_paired_persistent_solves_equal_per_block_launches(gpu, monkeypatch, n):
+    """ELLHIP_STABLE_PAIR=3: the experimental persistent solves with TWO 128-blocks per workgroup (512 threads, block A's
+    result handed to block B's half of the workgroup through LDS; off by default -- slower) must give
+    the bits of the one-launch-per-block path too: even and odd block counts, ragged last blocks, a failing cut."""
+    f = random_factor(n, 177 + n)
+    monkeypatch.setenv("ELLHIP_STABLE_PAIR", "3")
+    a = gpu.EllStable.new_with_matrix(1.0, f, np.zeros(n))
+    monkeypatch.setenv("ELLHIP_STABLE_PAIR", "0")
+    monkeypatch.setenv("ELLHIP_STABLE_PERSIST", "0")
+    b = gpu.EllStable.new_with_matrix(1.0, f, np.zeros(n))
+    monkeypatch.delenv("ELLHIP_STABLE_PERSIST")
+    rng = np.random.default_rng(7 * n)
+    for i in range(8):
+        gr = rng.standard_normal(n)
+        gr /= np.linalg.norm(gr)
+        beta = 5.0 if i == 5 else 0.05 * rng.random()
+        sa, sb = int(a.update_bias_cut((gr, beta))), int(b.update_bias_cut((gr, beta)))
+        assert sa == sb == (1 if i == 5 else 0)
+        assert a.tsq() == b.tsq() and a.kappa == b.kappa
+    assert np.array_equal(a.xc(), b.xc()) and np.array_equal(a.mq, b.mq)
+
+
 def test_failed_cut_in_the_middle_of_a_sequence(gpu, orc):
     n = 200
     g, o, f = _pair(gpu, orc, n, 4242)
