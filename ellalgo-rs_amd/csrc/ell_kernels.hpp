@@ -308,26 +308,36 @@ constexpr int SYMV_SEG_SMALL = 512;
 
 // SEG: segment width (2048 by default; 512 where a shard's trapezoid would give fewer tiles than the GPU has
 // room for -- at P = 8 a rank has ~130 tiles of 64 x 2048 but ~520 of 64 x 512).
-template <int RW, bool NT, int ABL = 0, int SEG = SYMV_SEG>  // ABL: timing-only ablations for tools/tune_ell.hip
-__global__ __launch_bounds__(256) void k_symv(const double* __restrict__ Q, long long ld, long long n,
-                                              long long row0, long long nrows,
-                                              const double* __restrict__ g, double* __restrict__ rowpart,
-                                              double* __restrict__ colpart, const DevState* __restrict__ st) {
+// Agent-scope relaxed (sc1) accesses for partial sums that are consumed INSIDE the launch that produced them
+// (k_symv_tail): write-through stores, loads that are never served from the reading CU's L1 (cdna_hip_programming.md
+// Guideline 16).
+__device__ __forceinline__ void ho_store(double* p, double v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double ho_load(const double* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// 16-byte write-through store (sc1).  Two 8-byte atomic stores per pair (64 lanes x 8 bytes at a 16-byte stride, twice)
+// made a tile's 16 KiB of column sums cost more than the tile itself: k_symv_tail 0.32 ms against 0.19 + 0.012 ms.
+__device__ __forceinline__ void ho_store2(double* p, double2_t v) {
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+}
+
+// One tile (strip I, segment J) of the lower-triangle GEMV; returns false when the tile lies wholly above the diagonal
+// or outside the local rows (nothing done).  HANDOFF: the partial sums are read by another workgroup of the same launch.
+template <int RW, bool NT, int ABL, int SEG, bool HANDOFF>
+__device__ __forceinline__ bool symv_tile(const double* __restrict__ Q, long long ld, long long n, long long row0,
+                                          long long nrows, const double* __restrict__ g, double* __restrict__ rowpart,
+                                          double* __restrict__ colpart, long long I, long long J, double (*red)[SYMV_H]) {
     constexpr int SYMV_NCH = SEG / 512;  // 16-byte column chunks per thread
-    __shared__ double red[4][SYMV_H];
-    if (st->halted) return;
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    // grid = (strips, segments), strips in descending order (the widest first).  Measured alternative: making
-    // the segment index the fast one (row-major traversal) is 19 % slower (profiles/r01/tune_symv.txt).
     // Row shard (symmetric multi-GPU mode): Q holds the rows [row0, row0 + nrows) only; I counts local strips,
     // every row / column index below is global.  Unsharded: row0 = 0, nrows = n.
-    const long long I = (long long)gridDim.x - 1 - blockIdx.x;
-    const long long J = blockIdx.y;
     const long long r0 = row0 + I * SYMV_H;
     const long long c0 = J * SEG;
     const long long rend = row0 + nrows;  // one past the last local row
-    if (r0 >= rend || c0 > r0 + SYMV_H - 1) return;  // nothing at or left of the diagonal in this segment
+    if (r0 >= rend || c0 > r0 + SYMV_H - 1) return false;  // nothing at or left of the diagonal in this segment
     const long long rlast = (r0 + SYMV_H - 1 < rend - 1) ? r0 + SYMV_H - 1 : rend - 1;
     Q -= row0 * ld;  // so that Q + r * ld addresses global row r
     const bool full = c0 + SEG - 1 < r0;  // every column of the segment is strictly left of every row
@@ -389,11 +399,32 @@ __global__ __launch_bounds__(256) void k_symv(const double* __restrict__ Q, long
     __syncthreads();
     if (threadIdx.x < SYMV_H && r0 + threadIdx.x < rend) {
         const int r = threadIdx.x;
-        rowpart[J * n + r0 + r] = ((red[0][r] + red[1][r]) + red[2][r]) + red[3][r];
+        const double v = ((red[0][r] + red[1][r]) + red[2][r]) + red[3][r];
+        if (HANDOFF) ho_store(rowpart + J * n + r0 + r, v); else rowpart[J * n + r0 + r] = v;
     }
 #pragma unroll
     for (int k = 0; k < SYMV_NCH; ++k)
-        if (ck[k] <= rlast) *reinterpret_cast<double2_t*>(colpart + I * n + ck[k]) = accc[k];
+        if (ck[k] <= rlast) {
+            if (HANDOFF) {
+                ho_store2(colpart + I * n + ck[k], accc[k]);
+            } else {
+                *reinterpret_cast<double2_t*>(colpart + I * n + ck[k]) = accc[k];
+            }
+        }
+    return true;
+}
+
+template <int RW, bool NT, int ABL = 0, int SEG = SYMV_SEG>  // ABL: timing-only ablations for tools/tune_ell.hip
+__global__ __launch_bounds__(256) void k_symv(const double* __restrict__ Q, long long ld, long long n,
+                                              long long row0, long long nrows,
+                                              const double* __restrict__ g, double* __restrict__ rowpart,
+                                              double* __restrict__ colpart, const DevState* __restrict__ st) {
+    __shared__ double red[4][SYMV_H];
+    if (st->halted) return;
+    // grid = (strips, segments), strips in descending order (the widest first).  Measured alternative: making
+    // the segment index the fast one (row-major traversal) is 19 % slower (profiles/r01/tune_symv.txt).
+    symv_tile<RW, NT, ABL, SEG, false>(Q, ld, n, row0, nrows, g, rowpart, colpart, (long long)gridDim.x - 1 - blockIdx.x,
+                                       (long long)blockIdx.y, red);
 }
 
 // y[i] = sum_{J <= i/SEG} rowpart[J][i] + sum_{I >= i/H} colpart[I][i]   (fixed order)
@@ -406,23 +437,21 @@ __global__ __launch_bounds__(256) void k_symv(const double* __restrict__ Q, long
 //     partial[b][1 + j] = sum over the same columns of pend[j][i] * g[i]          (v_j . g, j < NP)
 // (per lane x-then-y, xor butterfly over the wave; k_scalar_apply_def adds the workgroups' values in index order)
 // and workgroup 0 takes the halted / kappa snapshots k_scalar_dot_def would have taken.
-template <int NP>
-__global__ __launch_bounds__(256) void k_symv_reduce(long long n, long long row0, long long nrows, long long seg,
-                                                     const double* __restrict__ rowpart,
-                                                     const double* __restrict__ colpart,
-                                                     double* __restrict__ y, DevState* __restrict__ st,
-                                                     const double* __restrict__ g, const double* __restrict__ pend,
-                                                     double* __restrict__ partial) {
-    __shared__ double2_t part[4][64];
-    const int halted = st->halted;
-    if (NP > 0 && blockIdx.x == 0 && threadIdx.x == 0) {
-        st->halted_in = halted;
-        st->kappa_in = st->kappa;
-    }
-    if (halted) return;
+// The reduction of one block of 128 columns (blk) -- the body of k_symv_reduce.  HANDOFF: the partial sums were written
+// by other workgroups of THIS launch (k_symv_tail): they are read with agent-scope loads.
+template <int NP, bool HANDOFF>
+__device__ __forceinline__ void symv_reduce_block(long long blk, long long n, long long row0, long long nrows,
+                                                  long long seg, const double* __restrict__ rowpart,
+                                                  const double* __restrict__ colpart, double* __restrict__ y,
+                                                  const double* __restrict__ g, const double* __restrict__ pend,
+                                                  double* __restrict__ partial, double2_t (*part)[64]) {
+    auto ldp = [](const double* p) -> double2_t {
+        if constexpr (HANDOFF) return double2_t{ho_load(p), ho_load(p + 1)};
+        else return *reinterpret_cast<const double2_t*>(p);
+    };
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    const long long i = (long long)blockIdx.x * 128 + 2 * lane;  // columns i, i+1 (n is even)
+    const long long i = blk * 128 + 2 * lane;  // columns i, i+1 (n is even)
     const long long nstrips = (nrows + SYMV_H - 1) / SYMV_H;     // local strips
     // operands of the dot products: requested first, so their latency hides behind the strip loop
     constexpr int NPW = (NP + 3) / 4;  // pending vectors per wave (wave w takes j = w, w + 4, ...)
@@ -444,20 +473,22 @@ __global__ __launch_bounds__(256) void k_symv_reduce(long long n, long long row0
         // loads are independent of the running sums: keep 16 (then 8) of them in flight, add in strip order (the
         // first columns have n / 64 strips to add, 64 per wave: with 8 in flight the kernel took 8 round trips)
         long long I = (i < row0 ? 0 : (i - row0) / SYMV_H) + wave;
-        for (; I + 60 < nstrips; I += 64) {
-            double2_t v[16];
+        if constexpr (!HANDOFF) {  // (inside k_symv_tail the tile phase's 96 VGPRs bound the kernel: 8 in flight there)
+            for (; I + 60 < nstrips; I += 64) {
+                double2_t v[16];
 #pragma unroll
-            for (int u = 0; u < 16; ++u) v[u] = *reinterpret_cast<const double2_t*>(colpart + (I + 4 * u) * n + i);
+                for (int u = 0; u < 16; ++u) v[u] = ldp(colpart + (I + 4 * u) * n + i);
 #pragma unroll
-            for (int u = 0; u < 16; ++u) {
-                s.x += v[u].x;
-                s.y += v[u].y;
+                for (int u = 0; u < 16; ++u) {
+                    s.x += v[u].x;
+                    s.y += v[u].y;
+                }
             }
         }
         for (; I + 28 < nstrips; I += 32) {
             double2_t v[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const double2_t*>(colpart + (I + 4 * u) * n + i);
+            for (int u = 0; u < 8; ++u) v[u] = ldp(colpart + (I + 4 * u) * n + i);
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 s.x += v[u].x;
@@ -465,7 +496,7 @@ __global__ __launch_bounds__(256) void k_symv_reduce(long long n, long long row0
             }
         }
         for (; I < nstrips; I += 4) {
-            const double2_t v = *reinterpret_cast<const double2_t*>(colpart + I * n + i);
+            const double2_t v = ldp(colpart + I * n + i);
             s.x += v.x;
             s.y += v.y;
         }
@@ -480,7 +511,7 @@ __global__ __launch_bounds__(256) void k_symv_reduce(long long n, long long row0
 #pragma unroll
             for (int u = 0; u < 8; ++u) {  // unconditional loads (clamped), masked afterwards: adding +0.0 changes nothing
                 const long long Ju = (J + u < nJ) ? J + u : nJ - 1;
-                v[u] = *reinterpret_cast<const double2_t*>(rowpart + Ju * n + i);
+                v[u] = ldp(rowpart + Ju * n + i);
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
@@ -500,7 +531,7 @@ __global__ __launch_bounds__(256) void k_symv_reduce(long long n, long long row0
         if (NP > 0) yv = r;
     }
     if (NP > 0) {
-        double* out = partial + (long long)blockIdx.x * (NP + 1);
+        double* out = partial + blk * (NP + 1);
         if (wave == 0) {
             double sgy = gi.x * yv.x;
             sgy += gi.y * yv.y;
@@ -514,6 +545,112 @@ __global__ __launch_bounds__(256) void k_symv_reduce(long long n, long long row0
             sv += pv[k].y * gi.y;
             sv = wave_allreduce_sum(sv);
             if (lane == 0 && j < NP) out[1 + j] = sv;
+        }
+    }
+}
+
+template <int NP>
+__global__ __launch_bounds__(256) void k_symv_reduce(long long n, long long row0, long long nrows, long long seg,
+                                                     const double* __restrict__ rowpart,
+                                                     const double* __restrict__ colpart,
+                                                     double* __restrict__ y, DevState* __restrict__ st,
+                                                     const double* __restrict__ g, const double* __restrict__ pend,
+                                                     double* __restrict__ partial) {
+    __shared__ double2_t part[4][64];
+    const int halted = st->halted;
+    if (NP > 0 && blockIdx.x == 0 && threadIdx.x == 0) {
+        st->halted_in = halted;
+        st->kappa_in = st->kappa;
+    }
+    if (halted) return;
+    symv_reduce_block<NP, false>((long long)blockIdx.x, n, row0, nrows, seg, rowpart, colpart, y, g, pend, partial, part);
+}
+
+// ------------------------------------------------------------------------------- k_symv_tail ---
+// k_symv and k_symv_reduce<NP> in ONE launch (unsharded handle): a workgroup that has finished its tile counts it done
+// for its segment and -- if it belongs to the last workgroups the device was given -- pulls reduce tasks (128 columns
+// each, symv_reduce_block) from a queue: a task waits, bounded, until every tile of the segments 0 .. J(task) is counted
+// (segment-major dispatch order makes that a prefix condition; a task needs row sums from the segments left of its own
+// and column sums from its own).  One launch and one kernel boundary fewer on every update's dependency chain, and the
+// reductions of the early segments run in the tile phase's tail.  Same arithmetic in the same order as the two-launch
+// form: identical bits.  Hand-off as in cdna_hip_programming.md Guideline 16 (write-through stores, storing waves drain,
+// barrier, one lane adds to the counter; one lane polls, barrier, agent-scope loads).  Workgroups that wait hold their
+// slots and poll: only the last `npull` workgroups to FINISH their tile pull tasks (a finishing ticket tells), so the
+// waits are short and cannot starve tiles that still wait for a slot.  The last workgroup out re-arms the counters.
+constexpr int SYMV_MAXSEGS = 64;
+struct SymvTailCtl {
+    unsigned next, exited, finished, pad1;
+    unsigned seg_done[SYMV_MAXSEGS];
+};
+__device__ __forceinline__ bool symv_wait_ge(const unsigned* ctr, unsigned want) {  // ONE lane; bounded (~0.5 s)
+    for (int spin = 0; spin < (1 << 19); ++spin) {
+        if (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= want) return true;
+        __builtin_amdgcn_s_sleep(32);   // ~1 us between polls: a hundred pollers at 60 ns slowed the tiles still streaming
+    }
+    return false;
+}
+
+template <int RW, bool NT, int NP>
+__global__ __launch_bounds__(256, RW == 2 ? 5 : 4) /* RW = 2: 96 VGPRs, the residency of k_symv's tile phase */ void k_symv_tail(const double* __restrict__ Q, long long ld, long long n,
+                                                   const double* __restrict__ g, double* __restrict__ rowpart,
+                                                   double* __restrict__ colpart, double* __restrict__ y,
+                                                   const double* __restrict__ pend, double* __restrict__ partial,
+                                                   DevState* __restrict__ st, SymvTailCtl* __restrict__ ctl,
+                                                   unsigned nactive, unsigned npull) {
+    __shared__ double red[4][SYMV_H];
+    __shared__ double2_t part[4][64];
+    __shared__ int sh_task, sh_ok;
+    __shared__ unsigned sh_ticket;
+    const int halted = st->halted;
+    if (NP > 0 && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+        st->halted_in = halted;   // snapshots for k_scalar_apply_def (as k_symv_reduce<NP> takes them)
+        st->kappa_in = st->kappa;
+    }
+    if (halted) return;
+    const long long I = (long long)gridDim.x - 1 - blockIdx.x, J = blockIdx.y;
+    if (!symv_tile<RW, NT, 0, SYMV_SEG, true>(Q, ld, n, 0, n, g, rowpart, colpart, I, J, red)) return;  // (not counted)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains its write-through stores
+    __syncthreads();
+    const int tid = threadIdx.x;
+    if (tid == 0) {
+        atomicAdd(&ctl->seg_done[J], 1u);
+        sh_ticket = atomicAdd(&ctl->finished, 1u);   // this workgroup is the (ticket + 1)-th to finish its tile
+    }
+    __syncthreads();
+    // Only the LAST npull workgroups to finish pull tasks: whoever finishes early would poll the counters for most of
+    // the launch (128 early finishers polling made the whole launch 1.7x slower: 0.32 ms against 0.19 + 0.012 ms), the
+    // last ones wait microseconds; and however many rounds the grid needs, they belong to its last one.
+    if (sh_ticket + npull >= nactive) {
+        const int nblock = (int)((n + 127) / 128);
+        const long long nstrips = (n + SYMV_H - 1) / SYMV_H;
+        for (;;) {
+            if (tid == 0) sh_task = (int)atomicAdd(&ctl->next, 1u);
+            __syncthreads();
+            const int t = sh_task;
+            if (t >= nblock) break;
+            if (tid == 0) {
+                const long long Jt = ((long long)t * 128) / SYMV_SEG;
+                int ok = 1;
+                for (long long j = 0; j <= Jt && ok; ++j)   // tiles of segment j: the strips that reach its first column
+                    ok = symv_wait_ge(&ctl->seg_done[j], (unsigned)(nstrips - (j * SYMV_SEG) / SYMV_H)) ? 1 : 0;
+                sh_ok = ok;
+            }
+            __syncthreads();
+            if (sh_ok)
+                symv_reduce_block<NP, true>(t, n, 0, n, SYMV_SEG, rowpart, colpart, y, g, pend, partial, part);
+            else if (tid == 0)
+                atomicExch(&st->solve_err, 5);
+            __syncthreads();  // sh_task / sh_ok / part are rewritten by the next round
+        }
+    }
+    if (tid == 0) {
+        const unsigned e = atomicAdd(&ctl->exited, 1u);
+        if (e == nactive - 1) {  // last one out re-arms the counters for the next launch
+            const int nseg = (int)((n + SYMV_SEG - 1) / SYMV_SEG);
+            for (int j = 0; j < nseg; ++j) __hip_atomic_store(&ctl->seg_done[j], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&ctl->next, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&ctl->finished, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&ctl->exited, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
 }

@@ -92,6 +92,9 @@ struct ellhip_space {
     int symv_seg = SYMV_SEG;         // segment width of the lower-triangle GEMV's tiles (see symv_alloc)
     int apply_lower = 1;             // with symv: apply passes touch the lower triangle only (ELLHIP_APPLY_LOWER)
     int fuse_dots = 1;               // unsharded lower-triangle schedule: k_symv_reduce also yields the scalar stage's dot products (ELLHIP_FUSE_DOTS)
+    int symv_tail = 0;               // experimental: tiles and their reduction in ONE launch (k_symv_tail, ELLHIP_SYMV_TAIL=1)
+    SymvTailCtl* d_symv_ctl = nullptr;  // its queue head / completion counters
+    unsigned symv_tail_cap = 0;      // workgroups of k_symv_tail the device holds at once
     int dots_np = 0;                 // > 0: d_partial holds dot products of the primed gradient for this depth: [ceil(n/128)][dots_np + 1]
                                      // from k_symv_reduce, or [scalar_groups(n)][...] WITHOUT the g.y column from k_sweep_gemv_dots
     bool dots_need_gy = false;       // the latter: k_scalar_apply_def forms g.y itself
@@ -236,6 +239,7 @@ void pick_shape(ellhip_space* s) {
     s->apply_lower = env_int("ELLHIP_APPLY_LOWER", 1);
     s->apply_kernel = env_int("ELLHIP_APPLY_KERNEL", 1);
     s->fuse_dots = env_int("ELLHIP_FUSE_DOTS", 1);
+    s->symv_tail = env_int("ELLHIP_SYMV_TAIL", 0);   // measured slower than the two launches
     s->sh_apply = {4, 1, s->sh_fused.nt};  // 8 pending vectors per column step: more rows per workgroup amortise them
     s->sh_apply.rw = env_int("ELLHIP_APPLY_RW", s->sh_apply.rw);
     s->sh_apply.unr = env_int("ELLHIP_APPLY_UNR", s->sh_apply.unr);
@@ -535,6 +539,16 @@ int symv_alloc(ellhip_space* s) {
     // rows of rowpart outside this shard are never written but are read by nobody either; zero them anyway
     HIPCHK(hipMemsetAsync(s->d_rowpart, 0, nsegs * (size_t)s->n * sizeof(double), s->stream));
     HIPCHK(hipMemsetAsync(s->d_colpart, 0, nstrips * (size_t)s->n * sizeof(double), s->stream));
+    if (!s->sharded && s->symv_tail && s->symv_seg == SYMV_SEG && (s->n + SYMV_SEG - 1) / SYMV_SEG <= SYMV_MAXSEGS) {
+        HIPCHK(hipMalloc(&s->d_symv_ctl, sizeof(SymvTailCtl)));
+        HIPCHK(hipMemsetAsync(s->d_symv_ctl, 0, sizeof(SymvTailCtl), s->stream));
+        hipDeviceProp_t prop;
+        HIPCHK(hipGetDeviceProperties(&prop, s->device));
+        int occ = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)k_symv_tail<2, true, 16>, 256, 0) != hipSuccess) occ = 0;
+        s->symv_tail_cap = (unsigned)std::max(0, occ * prop.multiProcessorCount);
+        if (s->symv_tail_cap < 512) s->symv_tail = 0;   // (a device this small: keep the two launches)
+    }
     return 0;
 }
 
@@ -548,8 +562,40 @@ void symv_go(ellhip_space* s, const double* g_dev, unsigned nstrips, unsigned ns
                            s->ld, s->n, s->row0, s->nrows, g_dev, s->d_rowpart, s->d_colpart, s->d_st);
 }
 
+template <int RW, int NPV>
+void symv_tail_go(ellhip_space* s, const double* g_dev, double* y_out, unsigned nstrips, unsigned nsegs, bool nt,
+                  unsigned nactive, unsigned pull_from) {
+    if (nt)
+        hipLaunchKernelGGL((k_symv_tail<RW, true, NPV>), dim3(nstrips, nsegs), dim3(256), 0, s->stream, (const double*)s->d_Q,
+                           s->ld, s->n, g_dev, s->d_rowpart, s->d_colpart, y_out, (const double*)s->d_pend, s->d_partial,
+                           s->d_st, s->d_symv_ctl, nactive, pull_from);
+    else
+        hipLaunchKernelGGL((k_symv_tail<RW, false, NPV>), dim3(nstrips, nsegs), dim3(256), 0, s->stream, (const double*)s->d_Q,
+                           s->ld, s->n, g_dev, s->d_rowpart, s->d_colpart, y_out, (const double*)s->d_pend, s->d_partial,
+                           s->d_st, s->d_symv_ctl, nactive, pull_from);
+}
+
 int launch_symv(ellhip_space* s, const double* g_dev, double* y_out) {
     const int seg = s->symv_seg;
+    if (!s->sharded && s->symv_tail && s->d_symv_ctl && seg == SYMV_SEG && (s->symv_rw == 2 || s->symv_rw == 4) &&
+        s->fuse_dots && (s->defer == 8 || s->defer == 16)) {
+        // tiles + reduction in one launch (k_symv_tail)
+        ProfScope ps(s, CLS_SYMV);
+        const unsigned nstrips = (unsigned)((s->n + SYMV_H - 1) / SYMV_H), nsegs = (unsigned)((s->n + seg - 1) / seg);
+        unsigned nactive = 0;
+        for (unsigned j = 0; j < nsegs; ++j) nactive += nstrips - (unsigned)(((long long)j * seg) / SYMV_H);
+        const unsigned pull_from = std::min(nactive, (unsigned)env_int("ELLHIP_SYMV_TAIL_NPULL", (int)((s->n + 127) / 128)));   // workgroups that pull: the last to finish
+        const bool nt = s->sh_gemv.nt != 0;
+        const int np = s->fuse_dots ? s->defer : 0;
+#define TAIL_GO(RWV)                                                                              \
+    if (np == 16) symv_tail_go<RWV, 16>(s, g_dev, y_out, nstrips, nsegs, nt, nactive, pull_from);  \
+    else symv_tail_go<RWV, 8>(s, g_dev, y_out, nstrips, nsegs, nt, nactive, pull_from)
+        if (s->symv_rw == 2) { TAIL_GO(2); } else { TAIL_GO(4); }
+#undef TAIL_GO
+        HIPCHK(hipGetLastError());
+        s->dots_np = np;
+        return 0;
+    }
     {
         ProfScope ps(s, CLS_SYMV);
         const unsigned nstrips = (unsigned)((s->nrows + SYMV_H - 1) / SYMV_H);  // local strips
@@ -702,7 +748,9 @@ int read_back(ellhip_space* s) {
         (void)hipMemsetAsync(reinterpret_cast<char*>(s->d_st) + offsetof(DevState, solve_err), 0, sizeof(int), s->stream);
         (void)hipStreamSynchronize(s->stream);
         s->stable_persist = 0;
-        return fail(ELLHIP_E_HIP, "EllStable persistent solve: a bounded wait timed out; this handle now uses one launch per block");
+        s->symv_tail = 0;
+        return fail(ELLHIP_E_HIP, "a bounded in-launch wait timed out (EllStable persistent solve / k_symv_tail); this handle now "
+                                  "uses the forms without inter-workgroup waits");
     }
     return 0;
 }
@@ -1087,6 +1135,7 @@ void ellhip_destroy(ellhip_space* s) {
     if (s->d_cpend) (void)hipFree(s->d_cpend);
     if (s->d_rowpart) (void)hipFree(s->d_rowpart);
     if (s->d_colpart) (void)hipFree(s->d_colpart);
+    if (s->d_symv_ctl) (void)hipFree(s->d_symv_ctl);
     if (s->d_flags) (void)hipFree(s->d_flags);
     if (s->d_st) (void)hipFree(s->d_st);
     if (s->h_result) (void)hipHostFree(s->h_result);
@@ -1128,6 +1177,7 @@ int ellhip_clone(const ellhip_space* src_c, ellhip_space** out) {
     s->apply_lower = src->apply_lower;
     s->apply_kernel = src->apply_kernel;
     s->fuse_dots = src->fuse_dots;
+    s->symv_tail = src->symv_tail;
     s->shard_symmetric = src->shard_symmetric;
     s->upper_stale = src->upper_stale;
     s->symv_seg = src->symv_seg;
