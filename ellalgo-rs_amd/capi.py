@@ -88,6 +88,33 @@ def _one_hip_runtime_per_process() -> None:
             pass  # not loadable here: fall back to the system runtime
 
 
+def mapped_runtimes() -> dict:
+    """{'libamdhip64': [paths], 'libhsa-runtime64': [paths]} of this process, from /proc/self/maps."""
+    found = {"libamdhip64": set(), "libhsa-runtime64": set()}
+    try:
+        with open("/proc/self/maps") as f:
+            for line in f:
+                for key in found:
+                    if key + ".so" in line:
+                        found[key].add(os.path.realpath(line.split()[-1]))
+    except OSError:
+        pass
+    return {k: sorted(v) for k, v in found.items()}
+
+
+def _assert_one_runtime_mapped() -> None:
+    """Fail loudly if libellhip.so ended up beside a SECOND HIP or HSA runtime (see _one_hip_runtime_per_process): the
+    binding to PyTorch-ROCm's bundled runtime rests on a SONAME match, and two runtimes driving one GPU is the state that
+    hung.  ELLHIP_SYSTEM_HIP=1 (the caller chose /opt/rocm's runtime knowingly) skips the check."""
+    if os.environ.get("ELLHIP_SYSTEM_HIP", "0") == "1":
+        return
+    m = mapped_runtimes()
+    dup = {k: v for k, v in m.items() if len(v) > 1}
+    if dup:
+        raise EllHipError(f"two copies of a GPU runtime are mapped in this process: {dup}; import order or a SONAME "
+                          "mismatch defeated the single-runtime rule (ellalgo-rs_amd/capi.py)")
+
+
 def load():
     """dlopen libellhip.so (built in-tree by ellalgo-rs_amd/build.py) and type its entry points."""
     global _lib
@@ -99,6 +126,7 @@ def load():
                           "(the ellipsoid engine has no CPU fallback)")
     _one_hip_runtime_per_process()
     L = C.CDLL(path, mode=C.RTLD_GLOBAL)
+    _assert_one_runtime_mapped()
     vp, dbl, i32, i64 = C.c_void_p, C.c_double, C.c_int, C.c_int64
     sig = {
         "ellhip_create": (i32, [C.POINTER(vp), i32, i64, dbl, vp, vp, vp, i32]),

@@ -45,12 +45,15 @@ int batch_shape(ellhip_batch* h) {
     if (h->epw < 1) h->epw = 1;
     h->lds_bytes = (size_t)h->epw * per_bytes;
     if (h->lds_bytes > 160 * 1024) return fail(ELLHIP_E_INVALID, "batched engine: n too large for LDS");
-    // more than the default 64 KiB of dynamic LDS needs an opt-in per kernel.  The attribute belongs to the kernel,
-    // not to this handle: it is only ever RAISED, so that a handle with a larger footprint created earlier keeps
-    // launching after a smaller one has been set up.
-    static std::atomic<int> granted[3] = {{0}, {0}, {0}};
+    // more than the default 64 KiB of dynamic LDS needs an opt-in per kernel AND per device (a function attribute
+    // belongs to the device's copy of the code object).  It is only ever RAISED, so that a handle with a larger
+    // footprint created earlier keeps launching after a smaller one has been set up; the high-water marks are kept
+    // per (device, block size).
+    constexpr int MAXDEV = 64;
+    static std::atomic<int> granted[MAXDEV][3];
     const int slot = h->T == 64 ? 0 : (h->T == 128 ? 1 : 2);
-    if ((int)h->lds_bytes > granted[slot].load()) {
+    const int dev = (h->device >= 0 && h->device < MAXDEV) ? h->device : -1;
+    if (dev < 0 || (int)h->lds_bytes > granted[dev][slot].load()) {   // (a device beyond the table: set it every time)
 #define BATCH_ATTR(TT)                                                                         \
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_batch_update<TT>),             \
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes))
@@ -58,8 +61,10 @@ int batch_shape(ellhip_batch* h) {
         else if (h->T == 128) BATCH_ATTR(128);
         else BATCH_ATTR(256);
 #undef BATCH_ATTR
-        int seen = granted[slot].load();
-        while (seen < (int)h->lds_bytes && !granted[slot].compare_exchange_weak(seen, (int)h->lds_bytes)) {}
+        if (dev >= 0) {
+            int seen = granted[dev][slot].load();
+            while (seen < (int)h->lds_bytes && !granted[dev][slot].compare_exchange_weak(seen, (int)h->lds_bytes)) {}
+        }
     }
     return 0;
 }

@@ -885,8 +885,11 @@ __global__ __launch_bounds__(256) void k_pend_reset(double* __restrict__ pend, d
 // The reduction shape is fixed by n alone (slice length, 256 sequential-per-thread lanes, xor
 // butterfly, ((w0+w1)+w2)+w3, then the partials in index order), so omega has the same bits on every
 // rank of a row-partitioned run and in every schedule.
+#ifndef ELLHIP_SCALAR_SLICE
+#define ELLHIP_SCALAR_SLICE 1024
+#endif
 __host__ __device__ inline int scalar_groups(long long n) {
-    long long g = n / 1024;  // >= 1024 elements per workgroup (64 groups of 256 measured slower: 22.7 vs 17.8 us)
+    long long g = n / ELLHIP_SCALAR_SLICE;  // elements per workgroup of the scalar stage (tuning builds: -DELLHIP_SCALAR_SLICE=)
     if (g < 1) g = 1;
     if (g > 64) g = 64;
     return (int)g;
@@ -1085,16 +1088,34 @@ __global__ __launch_bounds__(256) void k_scalar_apply_def(long long n, const dou
             for (int j = 0; j < NP; ++j) pp[e][j] = in ? pend[(long long)j * n + i] : 0.0;
         }
     }
-    if (GY) {  // (npart = scalar_groups(n) <= 64 in this mode)
+    if (GY) {  // (npart = scalar_groups(n) <= 64 in this mode; <= 8 wherever the host selects it: n <= 8192)
         const long long m = scalar_slice(n);
-        for (int b = 0; b < npart; ++b) {
-            const long long lo = (long long)b * m;
-            const long long hi = (lo + m < n) ? lo + m : n;
-            double sgy = 0.0;
+        if (npart <= 8) {
+            // all slices in one sweep: 8 independent running sums per thread (slice b: i = b m + tid, + 256, ... as
+            // k_scalar_dot_def sums it), their wave reductions back to back -- not npart rounds of load / reduce / store
+            double sgy[8];
+#pragma unroll
+            for (int b = 0; b < 8; ++b) {
+                sgy[b] = 0.0;
+                const long long lo = (long long)b * m;
+                const long long hi = (b < npart) ? ((lo + m < n) ? lo + m : n) : lo;
+                for (long long i = lo + tid; i < hi; i += 256) sgy[b] += g_own[i] * y[i];
+            }
+#pragma unroll
+            for (int b = 0; b < 8; ++b) {
+                const double w = wave_allreduce_sum(sgy[b]);
+                if ((tid & 63) == 0 && b < npart) gy_w[b][tid >> 6] = w;
+            }
+        } else {
+            for (int b = 0; b < npart; ++b) {
+                const long long lo = (long long)b * m;
+                const long long hi = (lo + m < n) ? lo + m : n;
+                double sgy = 0.0;
 #pragma unroll 4
-            for (long long i = lo + tid; i < hi; i += 256) sgy += g_own[i] * y[i];
-            sgy = wave_allreduce_sum(sgy);
-            if ((tid & 63) == 0) gy_w[b][tid >> 6] = sgy;
+                for (long long i = lo + tid; i < hi; i += 256) sgy += g_own[i] * y[i];
+                sgy = wave_allreduce_sum(sgy);
+                if ((tid & 63) == 0) gy_w[b][tid >> 6] = sgy;
+            }
         }
         __syncthreads();
         if (tid < npart) gy_part[tid] = ((gy_w[tid][0] + gy_w[tid][1]) + gy_w[tid][2]) + gy_w[tid][3];

@@ -442,7 +442,7 @@ int ellstable_issue(ellhip_space* s, const double* g_dev, const CutParams* cp_de
     {
         ProfScope ps(s, CLS_ST_FWD);
         if (pair_fwd) {
-            hipLaunchKernelGGL(k_st_fwd_persist2, dim3((unsigned)npair), dim3(512), 0, st, s->d_Q, ld, n, g_dev, w, z, gg,
+            hipLaunchKernelGGL(k_st_fwd_persist2, dim3((unsigned)npair), dim3(256), 0, st, s->d_Q, ld, n, g_dev, w, z, gg,
                                s->d_flags, err, s->epoch, s->d_st);
         } else if (persist) {
             hipLaunchKernelGGL(k_st_fwd_persist, dim3((unsigned)nb), dim3(256), 0, st, s->d_Q, ld, n, g_dev, w, z, gg,
@@ -478,7 +478,7 @@ int ellstable_issue(ellhip_space* s, const double* g_dev, const CutParams* cp_de
     {
         ProfScope ps(s, CLS_ST_BWD);
         if (pair_bwd) {
-            hipLaunchKernelGGL(k_st_bwd_persist2, dim3((unsigned)npair), dim3(512), 0, st, s->d_Q, ld, n, q, qpub, err,
+            hipLaunchKernelGGL(k_st_bwd_persist2, dim3((unsigned)npair), dim3(256), 0, st, s->d_Q, ld, n, q, qpub, err,
                                s->d_st);
         } else if (persist) {
             hipLaunchKernelGGL(k_st_bwd_persist, dim3((unsigned)nb), dim3(256), 0, st, s->d_Q, ld, n, q, qpub, err,
@@ -872,7 +872,7 @@ int alloc_common(ellhip_space* s) {
                 return std::min(a, b) * prop.multiProcessorCount;
             };
             s->persist_cap1 = cap((const void*)k_st_fwd_persist, (const void*)k_st_bwd_persist, 256);
-            s->persist_cap2 = cap((const void*)k_st_fwd_persist2, (const void*)k_st_bwd_persist2, 512);
+            s->persist_cap2 = cap((const void*)k_st_fwd_persist2, (const void*)k_st_bwd_persist2, 256);
             // (the factor update runs beside the backward solve on the auxiliary stream, launched after it: the
             // solve's workgroups are placed first, and every wait in the solves is bounded)
             s->persist_cap1 = env_int("ELLHIP_STABLE_CAP", s->persist_cap1);

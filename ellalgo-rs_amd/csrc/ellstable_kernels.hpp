@@ -290,28 +290,6 @@ __device__ __forceinline__ void st_prefetch_block(const double* __restrict__ M, 
 
 constexpr int ST_LDS_DOUBLES = 3 * SH * BLK_PITCH;  // 96 KiB: the three parked pieces (the panel tile aliases it)
 
-// Workgroup barrier WITHOUT the wait for the wave's outstanding memory operations that __syncthreads() puts in front of
-// it: for the side of a paired solve that only keeps the other side's barrier count (its prefetches stay in flight
-// across the barrier; s_barrier itself waits for no counter).  The asm's memory clobber keeps the compiler from moving
-// LDS accesses across it.
-__device__ __forceinline__ void st_barrier_only() { asm volatile("s_barrier" ::: "memory"); }
-
-// Bring the three 64 x 64 pieces of the diagonal block at J0 (second / first / third piece at the given offsets) into
-// L2 without holding them: one 8-byte load per 128-byte line, three per thread.  The paired solves use it for the
-// block whose registers they cannot afford yet (VGPR budget of a 512-thread workgroup).  Returns a value the caller
-// must keep alive.
-__device__ __forceinline__ double st_touch_block(const double* __restrict__ M, long long ld, long long n, long long J0,
-                                                 int tid) {
-    const long long row = tid >> 2, off = 16 * (tid & 3);
-    auto at = [&](long long r, long long c) {
-        if (r > n - 1) r = n - 1;
-        if (c > n - 1) c = 0;
-        return M[r * ld + c];
-    };
-    return at(J0 + row, J0 + off) + at(J0 + row, J0 + SH + off) + at(J0 + SH + row, J0 + SH + off) +
-           at(J0 + SH + row, J0 + off);
-}
-
 __global__ __launch_bounds__(256) void k_st_fwd_first(double* __restrict__ M, long long ld, long long n,
                                                       const double* __restrict__ g, double* __restrict__ w,
                                                       double* __restrict__ z, double* __restrict__ gg,
@@ -556,34 +534,37 @@ __global__ __launch_bounds__(256) void k_st_fwd_persist(double* __restrict__ M, 
     }
 }
 
-// Paired persistent forward solve: workgroup t (512 threads) owns TWO consecutive 128-blocks, A = 2t and B = 2t + 1.
-// Threads 0..255 ("group 0") do for block A exactly what a workgroup of k_st_fwd_persist does for its block, threads
-// 256..511 ("group 1") the same for block B; the row blocks above the pair are applied by both groups side by side
-// (each to its own 128 columns) as their w arrives from the workgroups before.  What changes is the hand-off INSIDE the
-// pair: block A's result reaches group 1 through LDS (no store / poll round trip through memory, ~3 us under load), so
-// the chain pays one inter-workgroup hand-off per 256 columns instead of one per 128, and block A is published while
-// block B is still being solved (the next workgroup applies it meanwhile).  Same arithmetic in the same order per
-// column as k_st_fwd_persist / k_st_fwd_step: identical bits.
-//   The two groups run different code between the same barriers (the branch is on a scalar, so a wave executes the
-//   s_barrier of its own side only): while group 0 runs A's chain, group 1 fetches B's diagonal block and the rows of
-//   the inner panel; group 1's registers are not live on group 0's side, which keeps the chain's 128 VGPRs free.
-//   LDS: ONE diagonal block is parked at a time (A's, then B's, in the same 97.5 KB); the transpose tiles of both
-//   groups' write-backs alias it (144 KB in all).
+// Paired persistent forward solve: workgroup t owns TWO consecutive 128-blocks, A = 2t and B = 2t + 1 (256 columns; a
+// lane holds two columns of each).  The row blocks above the pair are applied to both column blocks as their w arrives
+// from the workgroups before; then block A is solved, its result is applied to block B's columns straight from LDS
+// (no store / poll round trip through memory, ~3 us under load), and block B is solved: the chain pays one
+// inter-workgroup hand-off per 256 columns instead of one per 128, and block A is published while block B is still
+// being solved (the next workgroup applies it meanwhile).  Same arithmetic in the same order per column as
+// k_st_fwd_persist / k_st_fwd_step: identical bits.
+//   256 threads, one workgroup per CU: the waves keep the 512-register budget the row panels (two column blocks: 256
+//   VGPRs) and the chains need.  (A first version with 512 threads -- one half of the workgroup per block, running
+//   side by side -- had 256 registers per wave, spilled, and scratch memory limits how many workgroups the device keeps
+//   resident: the chain serialised, 4.1 ms instead of 0.95.)
+//   LDS: ONE diagonal block is parked at a time (A's, then B's, in the same 97.5 KB); the transpose tiles of the two
+//   column blocks' write-backs alias it (144 KB in all).
 constexpr int ST_LDS2_DOUBLES = 2 * 4 * SPANEL * SLDS_PAD;  // 18432 doubles; the parked pieces (12480) alias its start
 
-// ONE copy of the diagonal-block code for both groups of a paired solve (a real call): inlined at both call sites the
-// kernels grew to ~100 KB of straight-line code, more than the instruction cache holds, and every block's chain was
-// fetched from L2 again (forward solve 4.1 ms instead of 0.95).
-__device__ __noinline__ void st_fwd_diag_block_call(double* __restrict__ M, long long ld, long long n, long long J0,
-                                                    double* __restrict__ lds, double* __restrict__ dlds,
-                                                    const double* __restrict__ wpart, double* __restrict__ w,
-                                                    double* __restrict__ z, double* __restrict__ gg, int* flag, int epoch,
-                                                    int tid, double* __restrict__ wout) {
-    Blk3 none;   // the block is parked in LDS already (a register block by reference would travel through scratch)
-    st_fwd_diag_block<true>(M, ld, n, J0, none, 0.0, lds, dlds, wpart, w, z, gg, flag, epoch, true, tid, wout);
+// Bring the 128 x 128 diagonal block at J0 into L2 without holding it: one 8-byte load per 128-byte line, four per
+// thread.  The paired solves fetch their SECOND block for real only when the first is solved (its 96 registers per
+// thread do not fit beside the chain and the inner panel's rows); this makes that fetch an L2 hit.  The caller keeps
+// the returned value alive.
+__device__ __forceinline__ double st_touch_block(const double* __restrict__ M, long long ld, long long n, long long J0) {
+    const long long row = threadIdx.x >> 2, off = 16 * (threadIdx.x & 3);
+    auto at = [&](long long r, long long c) {
+        if (r > n - 1) r = n - 1;
+        if (c > n - 1) c = 0;
+        return M[r * ld + c];
+    };
+    return at(J0 + row, J0 + off) + at(J0 + row, J0 + SH + off) + at(J0 + SH + row, J0 + SH + off) +
+           at(J0 + SH + row, J0 + off);
 }
 
-__global__ __launch_bounds__(512) void k_st_fwd_persist2(double* __restrict__ M, long long ld, long long n,
+__global__ __launch_bounds__(256) void k_st_fwd_persist2(double* __restrict__ M, long long ld, long long n,
                                                          const double* __restrict__ g, double* __restrict__ w,
                                                          double* __restrict__ z, double* __restrict__ gg,
                                                          int* __restrict__ flags, int* __restrict__ err, int epoch,
@@ -593,57 +574,69 @@ __global__ __launch_bounds__(512) void k_st_fwd_persist2(double* __restrict__ M,
     __shared__ double part[2][4][SPANEL];
     __shared__ double wstrip[2][SPANEL];
     __shared__ double wblk[SB];   // w of the row block being applied (from another workgroup)
-    __shared__ double wA[SB];     // w of this pair's block A, for group 1's inner panel
+    __shared__ double wA[SB];     // w of this pair's block A, for the inner panel
     __shared__ double dlds[SB];
     __shared__ int ok;
-    const int grp = __builtin_amdgcn_readfirstlane(threadIdx.x >> 8);  // scalar: the two sides below branch uniformly
-    const int lt = threadIdx.x & 255;
-    const int lane = lt & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(lt >> 6);
+    const int lane = threadIdx.x & 63;
+    const int wv = threadIdx.x >> 6;
     const long long nblk = (n + SB - 1) / SB;
     const long long blkA = 2 * (long long)blockIdx.x;
-    const bool hasB = blkA + 1 < nblk;
-    const bool act = grp == 0 || hasB;  // an odd block count leaves the last workgroup's group 1 without a block
-    const long long c0 = (blkA + grp) * SB;
-    const long long c = c0 + 2 * lane;
-    const long long cl = (act && c < n) ? c : 0;
+    const bool hasB = blkA + 1 < nblk;   // an odd block count leaves the last workgroup with block A only
+    const long long cA = blkA * SB, cB = cA + SB;
+    const long long clA = (cA + 2 * lane < n) ? cA + 2 * lane : 0;
+    const long long clB = (hasB && cB + 2 * lane < n) ? cB + 2 * lane : 0;
+    const long long dAB = clB - clA;   // (128, except for lanes beyond column n - 1 of a ragged last block)
     const int piece = lane & 7;
 
     Blk3 blk;
     double dreg = 0.0;
-    if (act && lt < SPANEL) wstrip[grp][lt] = (c0 + lt < n) ? g[c0 + lt] : 0.0;
-    double* t = lds + (grp * 4 + wv) * (SPANEL * SLDS_PAD);
-    double2_t u[2][16];
-    // products S[col][row] = U[row][col] * w[row] of a row block, transposed through LDS into full 128-byte lines of S
-    // (the barriers are met by every thread; `doit`: this thread's group has something to write)
-    auto write_back = [&](long long J0, bool recompute, const double* wsrc, bool doit) {
-        if (recompute && doit) {
-            const double* rp = M + (J0 + 32 * wv) * ld + cl;   // one running pointer (32 row addresses would be 64 VGPRs)
+    if (threadIdx.x < SPANEL) {
+        wstrip[0][threadIdx.x] = (cA + threadIdx.x < n) ? g[cA + threadIdx.x] : 0.0;
+        wstrip[1][threadIdx.x] = (hasB && cB + threadIdx.x < n) ? g[cB + threadIdx.x] : 0.0;
+    }
+    double2_t u[2][2][16];   // [column block][pass][row]
+    // products S[col][row] = U[row][col] * w[row] of a row block, transposed through LDS into full 128-byte lines of S;
+    // `which`: bit 0 = column block A, bit 1 = column block B; recompute: from the factor entries (L2) and wsrc
+    auto write_back = [&](long long J0, bool recompute, const double* wsrc, int which) {
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
+        for (int cb = 0; cb < 2; ++cb) {
+            if (!(which & (1 << cb))) continue;
+            const long long cl = cb ? clB : clA;
+            if (recompute) {
+                const double* rp = M + (J0 + 32 * wv) * ld + cl;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const double2_t f = *reinterpret_cast<const double2_t*>(rp);
-                    rp += ld;
-                    const double wj = wsrc[32 * wv + 16 * h + r];
-                    u[h][r].x = f.x * wj;
-                    u[h][r].y = f.y * wj;
+                for (int h = 0; h < 2; ++h) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const double2_t f = *reinterpret_cast<const double2_t*>(rp);
+                        rp += ld;
+                        const double wj = wsrc[32 * wv + 16 * h + r];
+                        u[cb][h][r].x = f.x * wj;
+                        u[cb][h][r].y = f.y * wj;
+                    }
                 }
             }
         }
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const long long r0 = J0 + 32 * wv + 16 * h;
-            if (h) __syncthreads();  // the tile of the previous pass has been drained
-            if (doit) {
+            if (h) __syncthreads();  // the tiles of the previous pass have been drained
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb) {
+                if (!(which & (1 << cb))) continue;
+                double* t = lds + (cb * 4 + wv) * (SPANEL * SLDS_PAD);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    t[(2 * lane) * SLDS_PAD + r] = u[h][r].x;
-                    t[(2 * lane + 1) * SLDS_PAD + r] = u[h][r].y;
+                    t[(2 * lane) * SLDS_PAD + r] = u[cb][h][r].x;
+                    t[(2 * lane + 1) * SLDS_PAD + r] = u[cb][h][r].y;
                 }
             }
             __syncthreads();
-            if (doit) {
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb) {
+                if (!(which & (1 << cb))) continue;
+                const double* t = lds + (cb * 4 + wv) * (SPANEL * SLDS_PAD);
+                const long long c0 = cb ? cB : cA;
 #pragma unroll
                 for (int k = 0; k < 16; ++k) {
                     const int col_local = 8 * k + (lane >> 3);
@@ -656,41 +649,24 @@ __global__ __launch_bounds__(512) void k_st_fwd_persist2(double* __restrict__ M,
             }
         }
     };
-    // rows of the inner panel (block A's rows, block B's columns): group 1 only, fetched while group 0 solves A.  B's
-    // diagonal block is only brought into L2 then (st_touch_block) and fetched for real once the panel's registers are
-    // free: 128 + 96 VGPRs at once do not fit the 256 a wave of a 512-thread workgroup has.
-    double2_t u2[2][16];
-    Blk3 blkB;
-    double dregB = 0.0;
-    auto fetch_inner = [&]() -> double {
-        const double* rp = M + (blkA * SB + 32 * wv) * ld + cl;
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                u2[h][r] = *reinterpret_cast<const double2_t*>(rp);
-                rp += ld;
-            }
-        }
-        return st_touch_block(M, ld, n, c0, lt);
-    };
+    const int both = hasB ? 3 : 1;
 
     for (long long kb = 0; kb < blkA; ++kb) {
         const long long J0 = kb * SB;  // all 128 rows exist: J0 + 128 <= 128 blkA < n
-        if (kb == blkA - 1 && grp == 0) {
+        if (kb == blkA - 1) {
             // block A's diagonal block: fetched AND parked while the block before is still being solved (`lds` is free:
-            // the last row block's products are written back at the very end); before the row loads below, so that the
-            // two never hold registers at the same time
-            st_prefetch_block(M, ld, n, c0, blk, dreg, lt);
-            st_fwd_park(blk, dreg, lds, dlds, lt);
+            // the last row block's products are written back at the very end)
+            st_prefetch_block(M, ld, n, cA, blk, dreg);
+            st_fwd_park(blk, dreg, lds, dlds);
         }
-        if (act) {
-            const double* rp = M + (J0 + 32 * wv) * ld + cl;
+        {   // ONE running row pointer; block B's pair sits `dAB` doubles to the right (64 row addresses would be 128 VGPRs)
+            const double* rp = M + (J0 + 32 * wv) * ld + clA;
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    u[h][r] = *reinterpret_cast<const double2_t*>(rp);
+                    u[0][h][r] = *reinterpret_cast<const double2_t*>(rp);
+                    if (hasB) u[1][h][r] = *reinterpret_cast<const double2_t*>(rp + dAB);
                     rp += ld;
                 }
             }
@@ -716,59 +692,68 @@ __global__ __launch_bounds__(512) void k_st_fwd_persist2(double* __restrict__ M,
             if (threadIdx.x == 0) atomicExch(err, 1);
             return;
         }
-        if (act) {
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) {
+            if (cb && !hasB) continue;
             double p0 = 0.0, p1 = 0.0;
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const double wj = wblk[32 * wv + 16 * h + r];
-                    const double v0 = u[h][r].x * wj;
-                    const double v1 = u[h][r].y * wj;
+                    const double v0 = u[cb][h][r].x * wj;
+                    const double v1 = u[cb][h][r].y * wj;
                     p0 += v0;
                     p1 += v1;
-                    u[h][r].x = v0;  // the product replaces the factor entry (src/ell_stable.rs:66)
-                    u[h][r].y = v1;
+                    u[cb][h][r].x = v0;  // the product replaces the factor entry (src/ell_stable.rs:66)
+                    u[cb][h][r].y = v1;
                 }
             }
-            part[grp][wv][2 * lane] = p0;
-            part[grp][wv][2 * lane + 1] = p1;
+            part[cb][wv][2 * lane] = p0;
+            part[cb][wv][2 * lane + 1] = p1;
         }
         __syncthreads();
-        if (act && lt < SPANEL) {
-            const double s4 = ((part[grp][0][lt] + part[grp][1][lt]) + part[grp][2][lt]) + part[grp][3][lt];
-            wstrip[grp][lt] = wstrip[grp][lt] - s4;
+        {
+            const int cb = threadIdx.x >> 7, c = threadIdx.x & (SPANEL - 1);   // 256 threads: both column blocks at once
+            if (!cb || hasB) {
+                const double s4 = ((part[cb][0][c] + part[cb][1][c]) + part[cb][2][c]) + part[cb][3][c];
+                wstrip[cb][c] = wstrip[cb][c] - s4;
+            }
         }
         if (kb + 1 < blkA) {
-            write_back(J0, false, wblk, act);
+            write_back(J0, false, wblk, both);
             __syncthreads();  // tiles drained, part / wblk reusable
         }
     }
     __syncthreads();
-    const long long cA = blkA * SB;
-    // ---- block A (group 0) | group 1 fetches what it needs next; barriers: [park, first workgroup only] + 3
-    if (grp == 0) {
-        if (blkA == 0) {  // no panel work before the first block: nothing parked yet
-            st_prefetch_block(M, ld, n, cA, blk, dreg, lt);
-            st_fwd_park(blk, dreg, lds, dlds, lt);
-            __syncthreads();
+    // ---- block A; the inner panel's rows (block A's rows, block B's columns) and B's diagonal block are requested first
+    double2_t u2[2][16];
+    Blk3 blkB;
+    double dregB = 0.0;
+    if (hasB) {
+        const double* rp = M + (cA + 32 * wv) * ld + clB;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                u2[h][r] = *reinterpret_cast<const double2_t*>(rp);
+                rp += ld;
+            }
         }
-        st_fwd_diag_block_call(M, ld, n, cA, lds, dlds, wstrip[0], w, z, gg, flags + blkA, epoch, lt, wA);
-    } else {
-        const double keep = hasB ? fetch_inner() : 0.0;
-        if (blkA == 0) st_barrier_only();
-        st_barrier_only();
-        st_barrier_only();
-        st_barrier_only();
-        if (keep == 1.2345e300 && threadIdx.x == 999) atomicExch(err, 9);  // (keeps the touching loads alive; never true)
+        const double keep = st_touch_block(M, ld, n, cB);   // B's diagonal block: into L2 for now
+        if (keep == 1.2345e300 && threadIdx.x == 999) atomicExch(err, 9);   // (keeps the loads alive; never true)
     }
-    if (!hasB) {  // (uniform over the workgroup) odd block count: only the deferred write-back is left
-        __syncthreads();
-        if (blkA > 0) write_back((blkA - 1) * SB, true, wblk, grp == 0);
+    if (blkA == 0) st_prefetch_block(M, ld, n, cA, blk, dreg);  // no panel work before the first block: nothing parked yet
+    st_fwd_diag_block<true>(M, ld, n, cA, blk, dreg, lds, dlds, wstrip[0], w, z, gg, flags + blkA, epoch, blkA > 0,
+                            threadIdx.x, wA);
+    if (!hasB) {
+        __syncthreads();  // A's parked products have been written back: `lds` is free for the transposes
+        if (blkA > 0) write_back((blkA - 1) * SB, true, wblk, 1);
         return;
     }
-    // ---- inner panel: rows of block A applied to block B's columns, w_A straight from LDS
-    if (grp == 1) {
+    // ---- inner panel: w_A straight from LDS (B's diagonal block is requested first: an L2 hit by now)
+    st_prefetch_block(M, ld, n, cB, blkB, dregB);
+    {
         double p0 = 0.0, p1 = 0.0;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
@@ -781,32 +766,24 @@ __global__ __launch_bounds__(512) void k_st_fwd_persist2(double* __restrict__ M,
         }
         part[1][wv][2 * lane] = p0;
         part[1][wv][2 * lane + 1] = p1;
-        st_prefetch_block(M, ld, n, c0, blkB, dregB, lt);   // (from L2: touched while block A was being solved)
     }
-    __syncthreads();  // (group 0 has also finished reading A's parked products: the pieces are free)
-    if (grp == 1) {
-        if (lt < SPANEL) {
-            const double s4 = ((part[1][0][lt] + part[1][1][lt]) + part[1][2][lt]) + part[1][3][lt];
-            wstrip[1][lt] = wstrip[1][lt] - s4;
-        }
-        st_fwd_park(blkB, dregB, lds, dlds, lt);
+    __syncthreads();  // (A's parked products have also been written back by now: the pieces are free)
+    if (threadIdx.x < SPANEL) {
+        const int c = threadIdx.x;
+        const double s4 = ((part[1][0][c] + part[1][1][c]) + part[1][2][c]) + part[1][3][c];
+        wstrip[1][c] = wstrip[1][c] - s4;
     }
+    st_fwd_park(blkB, dregB, lds, dlds);
     __syncthreads();
-    // ---- block B (group 1); 3 barriers
-    if (grp == 1) {
-        st_fwd_diag_block_call(M, ld, n, c0, lds, dlds, wstrip[1], w, z, gg, flags + blkA + 1, epoch, lt, nullptr);
-    } else {
-        st_barrier_only();
-        st_barrier_only();
-        st_barrier_only();
-    }
+    // ---- block B
+    st_fwd_diag_block<true>(M, ld, n, cB, blkB, dregB, lds, dlds, wstrip[1], w, z, gg, flags + blkA + 1, epoch, true);
     __syncthreads();  // B's parked products have been written back: `lds` is free for the transposes
-    // ---- deferred write-backs: the row block right above the pair (both groups), then block A's rows (group 1)
+    // ---- deferred write-backs: the row block right above the pair (both column blocks), then block A's rows (B's columns)
     if (blkA > 0) {
-        write_back((blkA - 1) * SB, true, wblk, true);
+        write_back((blkA - 1) * SB, true, wblk, 3);
         __syncthreads();
     }
-    write_back(cA, true, wA, grp == 1);
+    write_back(cA, true, wA, 2);
 }
 
 // ---------------------------------------------------------------------------------- mid -------
@@ -1191,17 +1168,11 @@ __global__ __launch_bounds__(256) void k_st_bwd_persist(const double* __restrict
     st_bwd_diag_block<true>(n, c0, blk, lds, qstrip, q, qpub, sblk < nblk - 1);
 }
 
-__device__ __noinline__ void st_bwd_diag_block_call(long long n, long long J0, double* __restrict__ lds,
-                                                    const double* __restrict__ qpart, double* __restrict__ q,
-                                                    double* __restrict__ qpub, int tid, double* __restrict__ qout) {
-    Blk3b none;  // parked already
-    st_bwd_diag_block<true>(n, J0, none, lds, qpart, q, qpub, true, tid, qout);
-}
-
-// Paired persistent backward solve (see k_st_fwd_persist2): workgroup t (512 threads) owns the blocks H = nblk - 1 - 2t
-// (group 0, solved first) and L = H - 1 (group 1); block H's q reaches group 1 through LDS.  Nothing is stored but q, so
-// only one diagonal block is ever parked and there are no transposes.  Identical bits to k_st_bwd_persist / _step.
-__global__ __launch_bounds__(512) void k_st_bwd_persist2(const double* __restrict__ M, long long ld, long long n,
+// Paired persistent backward solve (see k_st_fwd_persist2): workgroup t owns the blocks H = nblk - 1 - 2t (solved first)
+// and L = H - 1; block H's q reaches block L's inner panel through LDS.  Nothing is stored but q, so only one diagonal
+// block is ever parked and there are no transposes.  256 threads, a lane holds two columns of each block.  Identical bits
+// to k_st_bwd_persist / k_st_bwd_step.
+__global__ __launch_bounds__(256) void k_st_bwd_persist2(const double* __restrict__ M, long long ld, long long n,
                                                          double* __restrict__ q, double* __restrict__ qpub,
                                                          int* __restrict__ err, const DevState* __restrict__ st) {
     if (!st->apply) return;
@@ -1209,48 +1180,45 @@ __global__ __launch_bounds__(512) void k_st_bwd_persist2(const double* __restric
     __shared__ double part[2][4][SPANEL];
     __shared__ double qstrip[2][SPANEL];
     __shared__ double qblk[SB];   // q of the row block being applied (from another workgroup)
-    __shared__ double qH[SB];     // q of this pair's block H, for group 1's inner panel
+    __shared__ double qH[SB];     // q of this pair's block H, for the inner panel
     __shared__ int ok;
-    const int grp = __builtin_amdgcn_readfirstlane(threadIdx.x >> 8);
-    const int lt = threadIdx.x & 255;
-    const int lane = lt & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(lt >> 6);
+    const int lane = threadIdx.x & 63;
+    const int wv = threadIdx.x >> 6;
     const long long nblk = (n + SB - 1) / SB;
     const long long blkH = nblk - 1 - 2 * (long long)blockIdx.x;
-    const bool hasL = blkH >= 1;
-    const bool act = grp == 0 || hasL;
-    const long long myblk = blkH - grp;
-    const long long c0 = (act ? myblk : 0) * SB;
-    const long long c = c0 + 2 * lane;  // columns c, c + 1 < c0 + 128 <= J0 of every row block applied here: inside the matrix
+    const bool hasL = blkH >= 1;             // an odd block count leaves the last workgroup with block 0 only
+    const long long cH = blkH * SB, cL = hasL ? cH - SB : 0;
+    // columns c, c + 1 < c0 + 128 <= J0 of every row block applied here: inside the matrix
+    const long long clH = cH + 2 * lane, clL = cL + 2 * lane;
 
     Blk3b blk;
-    if (act && lt < SPANEL) qstrip[grp][lt] = (c0 + lt < n) ? q[c0 + lt] : 0.0;
+    if (threadIdx.x < SPANEL) {
+        qstrip[0][threadIdx.x] = (cH + threadIdx.x < n) ? q[cH + threadIdx.x] : 0.0;
+        qstrip[1][threadIdx.x] = hasL ? q[cL + threadIdx.x] : 0.0;
+    }
     if (threadIdx.x == 0) ok = 1;
     __syncthreads();
 
     for (long long kb = nblk - 1; kb > blkH; --kb) {
         const long long J0 = kb * SB;
-        if (kb == blkH + 1 && grp == 0) {  // block H's diagonal block: fetched and parked while the values it waits for
-            st_prefetch_block_bwd(M, ld, n, c0, blk, lt);   // are computed; before the row loads (registers)
-            st_park_piece(lds, blk.bb, lt);
-            st_park_piece(lds + SH * BLK_PITCH, blk.ba, lt);
-            st_park_piece(lds + 2 * SH * BLK_PITCH, blk.aa, lt);
+        if (kb == blkH + 1) {  // block H's diagonal block: fetched and parked while the values it waits for are computed
+            st_prefetch_block_bwd(M, ld, n, cH, blk);
+            st_park_piece(lds, blk.bb, threadIdx.x);
+            st_park_piece(lds + SH * BLK_PITCH, blk.ba, threadIdx.x);
+            st_park_piece(lds + 2 * SH * BLK_PITCH, blk.aa, threadIdx.x);
         }
-        // A wave of a 512-thread workgroup has 256 VGPRs (half of what k_st_bwd_persist's waves have), and ANY spill is
-        // ruinous here: scratch memory limits how many workgroups the device keeps resident, and a chain whose
-        // workgroups are not all resident serialises (measured: 1.55 ms instead of 0.92).  So the wave's 32 rows are held
-        // 16 at a time: the first 16 are requested before the wait, the other 16 once those have been consumed.
-        double2_t sv[16];
-        const long long rfirst = J0 + 32 * wv;
-        const double* rp = M + (rfirst > n - 1 ? n - 1 : rfirst) * ld + c;
-        auto load16 = [&](int h) {
+        double2_t sv[2][2][16];  // [column block][pass][row]: all rows requested before the wait
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const long long r0 = J0 + 32 * wv + 16 * h;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                sv[r] = *reinterpret_cast<const double2_t*>(rp);
-                if (rfirst + 16 * h + r < n - 1) rp += ld;
+                long long row = r0 + r;
+                if (row > n - 1) row = n - 1;
+                sv[0][h][r] = *reinterpret_cast<const double2_t*>(M + row * ld + clH);
+                if (hasL) sv[1][h][r] = *reinterpret_cast<const double2_t*>(M + row * ld + clL);
             }
-        };
-        if (act) load16(0);
+        }
         if (threadIdx.x < SB) {
             double v = 0.0;
             if (J0 + threadIdx.x < n && !st_poll_value(qpub + J0 + threadIdx.x, v)) ok = 0;
@@ -1261,102 +1229,83 @@ __global__ __launch_bounds__(512) void k_st_bwd_persist2(const double* __restric
             if (threadIdx.x == 0) atomicExch(err, 2);
             return;
         }
-        if (act) {
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) {
+            if (cb && !hasL) continue;
             double p0 = 0.0, p1 = 0.0;
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-                if (h) load16(1);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const double qj = qblk[32 * wv + 16 * h + r];  // 0 for rows beyond n
-                    p0 += sv[r].x * qj;
-                    p1 += sv[r].y * qj;
+                    p0 += sv[cb][h][r].x * qj;
+                    p1 += sv[cb][h][r].y * qj;
                 }
             }
-            part[grp][wv][2 * lane] = p0;
-            part[grp][wv][2 * lane + 1] = p1;
+            part[cb][wv][2 * lane] = p0;
+            part[cb][wv][2 * lane + 1] = p1;
         }
         __syncthreads();
-        if (act && lt < SPANEL) {
-            const double s4 = ((part[grp][0][lt] + part[grp][1][lt]) + part[grp][2][lt]) + part[grp][3][lt];
-            qstrip[grp][lt] = qstrip[grp][lt] - s4;
+        {
+            const int cb = threadIdx.x >> 7, c = threadIdx.x & (SPANEL - 1);
+            if (!cb || hasL) {
+                const double s4 = ((part[cb][0][c] + part[cb][1][c]) + part[cb][2][c]) + part[cb][3][c];
+                qstrip[cb][c] = qstrip[cb][c] - s4;
+            }
         }
         __syncthreads();
     }
     __syncthreads();
-    const long long cH = blkH * SB;
-    const bool first = blockIdx.x == 0;          // block H is the matrix' last block: nothing above it, nothing parked yet
-    const bool h_two_halves = cH + SH < n;       // st_bwd_diag_block meets 2 barriers then, none for a one-half ragged block
-    // ---- block H (group 0) | group 1 fetches the inner panel's rows and block L's diagonal block
-    double2_t s2[16];   // the first 16 of the wave's 32 rows of the inner panel; the other 16 follow when these are consumed
+    const bool first = blockIdx.x == 0;   // block H is the matrix' last block: nothing above it, nothing parked yet
+    // ---- the inner panel's rows (block H's rows of the scratch triangle, block L's columns) and block L's diagonal block
+    // are requested before block H is solved
+    double2_t s2[2][16];
     Blk3b blkL;
-    double keepL = 0.0;
-    const long long rfirst2 = cH + 32 * wv;
-    const double* rp2 = M + (rfirst2 > n - 1 ? n - 1 : rfirst2) * ld + c;
-    auto load16_inner = [&](int h) {
+    if (hasL) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            s2[r] = *reinterpret_cast<const double2_t*>(rp2);
-            if (rfirst2 + 16 * h + r < n - 1) rp2 += ld;
+        for (int h = 0; h < 2; ++h) {
+            const long long r0 = cH + 32 * wv + 16 * h;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                long long row = r0 + r;
+                if (row > n - 1) row = n - 1;
+                s2[h][r] = *reinterpret_cast<const double2_t*>(M + row * ld + clL);
+            }
         }
-    };
-    if (grp == 0) {
-        if (first) {
-            st_prefetch_block_bwd(M, ld, n, cH, blk, lt);
-            st_park_piece(lds, blk.bb, lt);
-            st_park_piece(lds + SH * BLK_PITCH, blk.ba, lt);
-            st_park_piece(lds + 2 * SH * BLK_PITCH, blk.aa, lt);
-            __syncthreads();
-        }
-        st_bwd_diag_block<true>(n, cH, blk, lds, qstrip[0], q, qpub, true, lt, qH);
-    } else {
-        if (hasL) {
-            load16_inner(0);
-            keepL = st_touch_block(M, ld, n, c0, lt);   // block L's diagonal block and the panel's other rows: into L2 only for now
-        }
-        if (first) st_barrier_only();
-        if (h_two_halves) {
-            st_barrier_only();
-            st_barrier_only();
-        }
-        if (keepL == 1.2345e300 && threadIdx.x == 999) atomicExch(err, 9);  // (keeps the loads alive; never true)
+        const double keep = st_touch_block(M, ld, n, cL);   // block L's diagonal block: into L2 for now
+        if (keep == 1.2345e300 && threadIdx.x == 999) atomicExch(err, 9);   // (keeps the loads alive; never true)
     }
-    if (!hasL) return;   // (uniform) odd block count: block 0 was this workgroup's only block
-    __syncthreads();     // q_H complete in LDS; block H's parked pieces are no longer read
-    // ---- inner panel: rows of block H (scratch triangle) applied to block L's columns, q_H straight from LDS
-    if (grp == 1) {
+    if (first) st_prefetch_block_bwd(M, ld, n, cH, blk);
+    st_bwd_diag_block<true>(n, cH, blk, lds, qstrip[0], q, qpub, !first, threadIdx.x, qH);
+    if (!hasL) return;
+    __syncthreads();   // q_H complete in LDS; block H's parked pieces are no longer read
+    st_prefetch_block_bwd(M, ld, n, cL, blkL);   // (an L2 hit by now)
+    {
         double p0 = 0.0, p1 = 0.0;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            if (h) load16_inner(1);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const long long row = cH + 32 * wv + 16 * h + r;
                 const double qj = (row < n) ? qH[32 * wv + 16 * h + r] : 0.0;  // rows beyond n count nothing
-                p0 += s2[r].x * qj;
-                p1 += s2[r].y * qj;
+                p0 += s2[h][r].x * qj;
+                p1 += s2[h][r].y * qj;
             }
         }
         part[1][wv][2 * lane] = p0;
         part[1][wv][2 * lane + 1] = p1;
-        st_prefetch_block_bwd(M, ld, n, c0, blkL, lt);   // (from L2)
-        st_park_piece(lds, blkL.bb, lt);
-        st_park_piece(lds + SH * BLK_PITCH, blkL.ba, lt);
-        st_park_piece(lds + 2 * SH * BLK_PITCH, blkL.aa, lt);
+    }
+    st_park_piece(lds, blkL.bb, threadIdx.x);
+    st_park_piece(lds + SH * BLK_PITCH, blkL.ba, threadIdx.x);
+    st_park_piece(lds + 2 * SH * BLK_PITCH, blkL.aa, threadIdx.x);
+    __syncthreads();
+    if (threadIdx.x < SPANEL) {
+        const int c = threadIdx.x;
+        const double s4 = ((part[1][0][c] + part[1][1][c]) + part[1][2][c]) + part[1][3][c];
+        qstrip[1][c] = qstrip[1][c] - s4;
     }
     __syncthreads();
-    if (grp == 1 && lt < SPANEL) {
-        const double s4 = ((part[1][0][lt] + part[1][1][lt]) + part[1][2][lt]) + part[1][3][lt];
-        qstrip[1][lt] = qstrip[1][lt] - s4;
-    }
-    __syncthreads();
-    // ---- block L (group 1): a full block (two halves): 2 barriers
-    if (grp == 1) {
-        st_bwd_diag_block<true>(n, c0, blkL, lds, qstrip[1], q, qpub, true, lt);
-    } else {
-        st_barrier_only();
-        st_barrier_only();
-    }
+    st_bwd_diag_block<true>(n, cL, blkL, lds, qstrip[1], q, qpub, true);
 }
 
 // xc -= (rho/omega) q   (src/ell_stable.rs:101-104)
