@@ -80,6 +80,10 @@ struct ellhip_space {
     double* d_gt_own[2] = {nullptr, nullptr};  // Q*g of slot 0 / 1 (n doubles)
     double* d_gt[2] = {nullptr, nullptr};      // buffers in use (own or caller's)
     double* d_work = nullptr;        // EllStable vectors: w, z, gg, q, beta2
+    double* d_hpart = nullptr;       // EllStable forward solve with helper workgroups: the helpers' hand-over buffer (n)
+    int stable_helpers = 1;          // k_st_fwd_helped when 2 * ceil(n/128) workgroups are resident at once
+    int stable_factor_rows = 1;      // factor update from U alone (k_st_factor_rows); 0: the tile kernel that reads the scratch
+    int persist_cap_h = 0;           // that limit (CU count x occupancy of k_st_fwd_helped)
     double* d_partial = nullptr;     // per-workgroup partial sums of omega (64)
     double* d_pend = nullptr;        // deferred mode: MAXPEND pending gt vectors (n each)
     double* d_cpend = nullptr;       // deferred mode: their coefficients sigma/omega
@@ -431,6 +435,8 @@ int ellstable_issue(ellhip_space* s, const double* g_dev, const CutParams* cp_de
     const bool pair_ok = s->stable_persist && npair <= s->persist_cap2;
     const bool pair_fwd = pair_ok && (s->stable_pair & 1), pair_bwd = pair_ok && (s->stable_pair & 2);
     const bool persist = pair_ok || (s->stable_persist && nb <= s->persist_cap1);
+    // forward solve with a helper workgroup per block (two workgroups per block, all resident): see k_st_fwd_helped
+    const bool helped = persist && !pair_fwd && s->stable_helpers && s->d_hpart && 2 * nb <= s->persist_cap_h;
     // Persistent forward solve: the workgroup that is next in the chain polls the VALUES of the block it waits for
     // (sentinel until stored, like the backward solve's qpub), everybody else the block's flag.  The published
     // vector therefore has to be all-sentinel when a solve starts: two buffers alternate by launch parity, and the
@@ -441,7 +447,10 @@ int ellstable_issue(ellhip_space* s, const double* g_dev, const CutParams* cp_de
     int* err = reinterpret_cast<int*>(reinterpret_cast<char*>(s->d_st) + offsetof(DevState, solve_err));
     {
         ProfScope ps(s, CLS_ST_FWD);
-        if (pair_fwd) {
+        if (helped) {
+            hipLaunchKernelGGL(k_st_fwd_helped, dim3((unsigned)(2 * nb)), dim3(256), 0, st, s->d_Q, ld, n, g_dev, w,
+                               s->d_hpart, z, gg, s->d_flags, err, s->epoch, s->d_st);
+        } else if (pair_fwd) {
             hipLaunchKernelGGL(k_st_fwd_persist2, dim3((unsigned)npair), dim3(256), 0, st, s->d_Q, ld, n, g_dev, w, z, gg,
                                s->d_flags, err, s->epoch, s->d_st);
         } else if (persist) {
@@ -466,7 +475,7 @@ int ellstable_issue(ellhip_space* s, const double* g_dev, const CutParams* cp_de
         hipLaunchKernelGGL(k_st_post, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, s->d_Q, ld, n,
                            (const double*)z, (const double*)gg, (const double*)cpre, q, beta2,
                            persist ? qpub : (double*)nullptr, persist ? w_next : (double*)nullptr,
-                           (const DevState*)s->d_st);
+                           (const DevState*)s->d_st, helped ? s->d_hpart : (double*)nullptr);
         HIPCHK(hipGetLastError());
     }
     // The factor update (reads S, rewrites U) and the backward solve (reads S, writes q) are independent.
@@ -499,8 +508,19 @@ int ellstable_issue(ellhip_space* s, const double* g_dev, const CutParams* cp_de
         if (overlap) HIPCHK(hipStreamWaitEvent(fs, s->ev_fork, 0));
         {
             ProfScope ps(s, CLS_ST_FACTOR, fs);
-            const unsigned nt64 = (unsigned)((n + 63) / 64);  // the factor update works on 64x64 tiles
-            hipLaunchKernelGGL(k_st_factor, dim3(nt64, nt64), dim3(256), 0, fs, s->d_Q, ld, n, beta2, s->d_st);
+            if (s->stable_factor_rows) {
+                // row-wise, from U alone (the scratch entry it would read IS fl(U * w): see k_st_factor_rows)
+                const unsigned gy = (unsigned)((n + FROW_H - 1) / FROW_H);
+                if (n >= 8192)
+                    hipLaunchKernelGGL((k_st_factor_rows<2048, 2>), dim3(gy, (unsigned)((n + 2047) / 2048)), dim3(256), 0,
+                                       fs, s->d_Q, ld, n, beta2, (const double*)w, s->d_st);
+                else
+                    hipLaunchKernelGGL((k_st_factor_rows<512, 4>), dim3(gy, (unsigned)((n + 511) / 512)), dim3(256), 0,
+                                       fs, s->d_Q, ld, n, beta2, (const double*)w, s->d_st);
+            } else {
+                const unsigned nt64 = (unsigned)((n + 63) / 64);  // 64x64 tiles, scratch triangle transposed through LDS
+                hipLaunchKernelGGL(k_st_factor, dim3(nt64, nt64), dim3(256), 0, fs, s->d_Q, ld, n, beta2, s->d_st);
+            }
             HIPCHK(hipGetLastError());
         }
         if (overlap) {
@@ -875,6 +895,13 @@ int alloc_common(ellhip_space* s) {
             s->persist_cap2 = cap((const void*)k_st_fwd_persist2, (const void*)k_st_bwd_persist2, 256);
             // (the factor update runs beside the backward solve on the auxiliary stream, launched after it: the
             // solve's workgroups are placed first, and every wait in the solves is bounded)
+            {
+                int a = 0;
+                if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, (const void*)k_st_fwd_helped, 256, 0) != hipSuccess) a = 0;
+                s->persist_cap_h = env_int("ELLHIP_STABLE_CAP_H", a * prop.multiProcessorCount);
+            }
+            s->stable_helpers = env_int("ELLHIP_STABLE_HELPERS", 1);
+            s->stable_factor_rows = env_int("ELLHIP_STABLE_FACTOR_ROWS", 1);
             s->persist_cap1 = env_int("ELLHIP_STABLE_CAP", s->persist_cap1);
             s->persist_cap2 = env_int("ELLHIP_STABLE_CAP2", s->persist_cap2);
         }
@@ -888,6 +915,8 @@ int alloc_common(ellhip_space* s) {
         // both publish buffers of the persistent forward solve start out all-sentinel
         hipLaunchKernelGGL(k_st_arm, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream, s->d_work, n);
         hipLaunchKernelGGL(k_st_arm, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream, s->d_work + 6 * n, n);
+        HIPCHK(hipMalloc(&s->d_hpart, vbytes));
+        hipLaunchKernelGGL(k_st_arm, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream, s->d_hpart, n);
         HIPCHK(hipGetLastError());
     }
     HIPCHK(hipHostMalloc(&s->h_result, sizeof(DevState), hipHostMallocDefault));
@@ -1130,6 +1159,7 @@ void ellhip_destroy(ellhip_space* s) {
         if (s->h_stage[k]) (void)hipHostFree(s->h_stage[k]);
     }
     if (s->d_work) (void)hipFree(s->d_work);
+    if (s->d_hpart) (void)hipFree(s->d_hpart);
     if (s->d_partial) (void)hipFree(s->d_partial);
     if (s->d_pend) (void)hipFree(s->d_pend);
     if (s->d_cpend) (void)hipFree(s->d_cpend);
@@ -1185,6 +1215,8 @@ int ellhip_clone(const ellhip_space* src_c, ellhip_space** out) {
     if (!rc) {
         s->stable_persist = src->stable_persist;
         s->stable_pair = src->stable_pair;
+        s->stable_helpers = src->stable_helpers;
+        s->stable_factor_rows = src->stable_factor_rows;
     }
     if (rc) {
         ellhip_destroy(s);

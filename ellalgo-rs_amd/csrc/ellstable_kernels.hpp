@@ -38,6 +38,16 @@ constexpr int SB = 128;       // block size of the triangular solves (two 64-wid
 constexpr int SH = 64;        // half block = one wave's register solve
 constexpr int SPANEL = 128;   // columns per panel workgroup (2 per lane)
 constexpr int SLDS_PAD = 18;  // doubles per LDS tile row (16 + 2: keeps 16-byte alignment)
+// Measurement builds only.  -DST_EXP_CHAIN_STEPS=k (results are then WRONG): the diagonal-block chains take k of their
+// 64 steps, which shows how much of a block's time is the chain arithmetic (profiles/r02/ellstable_chain_share.txt).
+// ST_STAMP(slot): tools/experiments/st_fwd_timeline.hip defines it to record wall-clock stamps per workgroup and step.
+#ifndef ST_EXP_CHAIN_STEPS
+#define ST_EXP_CHAIN_STEPS SH
+#endif
+#ifndef ST_STAMP
+#define ST_STAMP(kb, slot)        // thread 0 of the workgroup
+#define ST_STAMP_LANE0(kb, slot)  // lane 0 of the calling wave
+#endif
 
 // ------------------------------------------------------------------------------ forward ------
 // The diagonal-block solve is a length-128 dependency chain, so it is kept free of memory latency:
@@ -92,7 +102,7 @@ __device__ __forceinline__ double st_fwd_chain_regs(double (&u)[SH], double wi) 
     const int lane = threadIdx.x & 63;
     double t = wi;
 #pragma unroll
-    for (int j = 0; j < SH; ++j) {
+    for (int j = 0; j < ST_EXP_CHAIN_STEPS; ++j) {
         const double wj = lane_bcast(t, j);  // lane j's value is final after step j-1
         const double v = u[j] * wj;          // :65
         u[j] = v;                            // :66 (meaningful for j < lane only)
@@ -223,8 +233,13 @@ __device__ __forceinline__ void st_fwd_diag_block(double* __restrict__ M, long l
 #pragma unroll
         for (int j = 0; j < SH; ++j) u[j] = mine[j * BLK_PITCH + lane];
     }
-    if (wave == 0) wab[0][lane] = st_fwd_chain_regs(u, wpart[lane]);
+    if (wave == 0) {
+        ST_STAMP_LANE0(J0 / SB, 8);
+        wab[0][lane] = st_fwd_chain_regs(u, wpart[lane]);
+        ST_STAMP_LANE0(J0 / SB, 9);
+    }
     __syncthreads();
+    if (wave == 1) ST_STAMP_LANE0(J0 / SB, 10);
     if (wave == 0) {
         const double wA = wab[0][lane];
         if (wout) wout[lane] = wA;
@@ -239,15 +254,19 @@ __device__ __forceinline__ void st_fwd_diag_block(double* __restrict__ M, long l
         if (PUBLISH && !has_b) st_raise_flag(flag, epoch);
     } else if (wave == 1 && has_b) {
         wab[1][lane] = st_fwd_mini_regs(u, wab[0], wpart[lane + SH]);
+        ST_STAMP_LANE0(J0 / SB, 11);
     }
     __syncthreads();
     if (wave == 2 && has_b) {
+        ST_STAMP_LANE0(J0 / SB, 12);
         const double wB = st_fwd_chain_regs(u, wab[1][lane]);
+        ST_STAMP_LANE0(J0 / SB, 13);
         if (wout) wout[SH + lane] = wB;
         const long long c = J0 + SH + lane;
         if (PUBLISH) {  // all 128 values by this wave, then its flag store (half A always lies inside the matrix here)
             st_publish_store(w + J0 + lane, wab[0][lane]);
             if (c < n) st_publish_store(w + c, wB);
+            ST_STAMP_LANE0(J0 / SB, 7);
             st_raise_flag(flag, epoch);
         } else if (c < n) {
             w[c] = wB;
@@ -267,6 +286,104 @@ __device__ __forceinline__ void st_fwd_diag_block(double* __restrict__ M, long l
     if (has_b) {
         st_store_piece(M, ld, n, J0 + SH, J0, pAB, false, tid);        // S[B][A], full
         st_store_piece(M, ld, n, J0 + SH, J0 + SH, pBB, true, tid);    // S[B][B], strict lower
+    }
+}
+
+// The same block for a workgroup that has TIME before the values it waits for arrive (k_st_fwd_helped's chain
+// workgroups): the waves fetch their columns of the parked pieces into registers beforehand (st_fwd_diag_cols: 0.5 us
+// of LDS reads that otherwise sit between the arrival of the values and chain A, and compete with it), and the mini
+// panel A -> B is shared by waves 1 and 3 (interleaved partial sums a0, a1 in wave 1 and a2, a3 in wave 3, combined
+// as (a0 + a1) + (a2 + a3) exactly like st_fwd_mini_regs: 0.7 -> 0.35 us).  Same bits.  Always publishes.
+//   per block measured before: values seen 0.7 | sums 0.6 | columns 0.5 | chain A 1.26 | mini 0.69 | chain B 0.83 us
+// Half of the mini panel: the residues O, O + 1 of j mod 4 (O = 0: the partial sums a0, a1 of st_fwd_mini_regs; O = 2: a2, a3)
+template <int O>
+__device__ __forceinline__ double st_fwd_mini_half(double (&u)[SH], const double* __restrict__ wa) {
+    double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+    for (int j = O; j < SH; j += 4) {
+        const double v0 = u[j] * wa[j];
+        const double v1 = u[j + 1] * wa[j + 1];
+        u[j] = v0, u[j + 1] = v1;
+        a0 += v0, a1 += v1;
+    }
+    return a0 + a1;
+}
+__device__ __forceinline__ void st_fwd_diag_cols(const double* __restrict__ lds, bool has_b, double (&u)[SH]) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const double* mine = lds + (wave == 0 ? 0 : (wave == 2 ? 2 : 1)) * (SH * BLK_PITCH);  // waves 1 and 3: piece AB
+    if (wave == 0 || has_b) {
+#pragma unroll
+        for (int j = 0; j < SH; ++j) u[j] = mine[j * BLK_PITCH + lane];
+    }
+}
+__device__ __forceinline__ void st_fwd_diag_block_pre(double* __restrict__ M, long long ld, long long n, long long J0,
+                                                      double* __restrict__ lds, const double* __restrict__ dlds,
+                                                      const double* __restrict__ wpart, double* __restrict__ w,
+                                                      double* __restrict__ z, double* __restrict__ gg, int* flag,
+                                                      int epoch, double (&u)[SH]) {
+    __shared__ double wa[SH];        // final w of half A
+    __shared__ double mini[2][SH];   // (a0 + a1), (a2 + a3) of the mini panel
+    double* pAA = lds;
+    double* pAB = lds + SH * BLK_PITCH;
+    double* pBB = lds + 2 * SH * BLK_PITCH;
+    const bool has_b = J0 + SH < n;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (wave == 0) {
+        ST_STAMP_LANE0(J0 / SB, 8);
+        wa[lane] = st_fwd_chain_regs(u, wpart[lane]);
+        ST_STAMP_LANE0(J0 / SB, 9);
+    }
+    __syncthreads();
+    if (wave == 1) ST_STAMP_LANE0(J0 / SB, 10);
+    if (wave == 0) {
+        const double wA = wa[lane];
+        const long long c = J0 + lane;
+        if (c < n) {
+            const double zi = wA * dlds[lane];  // :74
+            if (!has_b) st_publish_store(w + c, wA);
+            z[c] = zi;
+            gg[c] = zi * wA;  // :81
+        }
+        if (!has_b) st_raise_flag(flag, epoch);
+    } else if (has_b && wave == 1) {
+        mini[0][lane] = st_fwd_mini_half<0>(u, wa);
+        ST_STAMP_LANE0(J0 / SB, 11);
+    } else if (has_b && wave == 3) {
+        mini[1][lane] = st_fwd_mini_half<2>(u, wa);
+    }
+    __syncthreads();
+    if (wave == 2 && has_b) {
+        ST_STAMP_LANE0(J0 / SB, 12);
+        const double wB = st_fwd_chain_regs(u, wpart[lane + SH] - (mini[0][lane] + mini[1][lane]));
+        ST_STAMP_LANE0(J0 / SB, 13);
+        const long long c = J0 + SH + lane;
+        st_publish_store(w + J0 + lane, wa[lane]);  // all 128 values by this wave, then its flag store
+        if (c < n) st_publish_store(w + c, wB);
+        ST_STAMP_LANE0(J0 / SB, 7);
+        st_raise_flag(flag, epoch);
+        if (c < n) {
+            const double zi = wB * dlds[lane + SH];
+            z[c] = zi;
+            gg[c] = zi * wB;
+        }
+    }
+    // parked products: piece[lane][j] (transposed in place; every lane read its whole column long ago)
+    if (wave == 0 || (has_b && wave == 2)) {
+        double* mine = wave == 0 ? pAA : pBB;
+#pragma unroll
+        for (int j = 0; j < SH; ++j) mine[lane * BLK_PITCH + j] = u[j];
+    } else if (has_b && wave == 1) {
+#pragma unroll
+        for (int j = 0; j < SH; j += 4) pAB[lane * BLK_PITCH + j] = u[j], pAB[lane * BLK_PITCH + j + 1] = u[j + 1];
+    } else if (has_b) {
+#pragma unroll
+        for (int j = 2; j < SH; j += 4) pAB[lane * BLK_PITCH + j] = u[j], pAB[lane * BLK_PITCH + j + 1] = u[j + 1];
+    }
+    __syncthreads();
+    st_store_piece(M, ld, n, J0, J0, pAA, true, threadIdx.x);                  // S[A][A], strict lower
+    if (has_b) {
+        st_store_piece(M, ld, n, J0 + SH, J0, pAB, false, threadIdx.x);        // S[B][A], full
+        st_store_piece(M, ld, n, J0 + SH, J0 + SH, pBB, true, threadIdx.x);    // S[B][B], strict lower
     }
 }
 
@@ -457,6 +574,7 @@ __global__ __launch_bounds__(256) void k_st_fwd_persist(double* __restrict__ M, 
     };
     for (long long kb = 0; kb < sblk; ++kb) {
         const long long J0 = kb * SB;  // all 128 rows exist: J0 + 128 <= c0 < n
+        ST_STAMP(kb, 0);
         // nothing below depends on the flag except w: request both passes' rows of U (and, in the last
         // iteration, the own diagonal block) before waiting, so their HBM latency is hidden behind the wait
 #pragma unroll
@@ -470,6 +588,7 @@ __global__ __launch_bounds__(256) void k_st_fwd_persist(double* __restrict__ M, 
             // (`lds` is free: the last row block's products are written back after the own solve)
             st_prefetch_block(M, ld, n, c0, blk, dreg);
             st_fwd_park(blk, dreg, lds, dlds);
+            ST_STAMP(kb, 4);
         }
         // (the data-as-flag hand-off of the backward solve was tried here too: 255 workgroups x 128 lanes polling the
         // values slowed the publishing wave down, forward solve 1.25 -> 1.34 ms; one polling lane per workgroup it is)
@@ -499,6 +618,7 @@ __global__ __launch_bounds__(256) void k_st_fwd_persist(double* __restrict__ M, 
             if (threadIdx.x < SB) wblk[threadIdx.x] = st_published_load(w + J0 + threadIdx.x);
             __syncthreads();
         }
+        ST_STAMP(kb, 1);
         double p0 = 0.0, p1 = 0.0;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
@@ -521,17 +641,245 @@ __global__ __launch_bounds__(256) void k_st_fwd_persist(double* __restrict__ M, 
                               part[3][threadIdx.x];
             wstrip[threadIdx.x] = wstrip[threadIdx.x] - s4;
         }
+        ST_STAMP(kb, 2);
         if (kb + 1 < sblk) {
             write_back(J0, false);
             __syncthreads();  // tiles drained, part reusable
         }
+        ST_STAMP(kb, 3);
     }
     __syncthreads();
     st_fwd_diag_block<true>(M, ld, n, c0, blk, dreg, lds, dlds, wstrip, w, z, gg, flags + sblk, epoch, sblk > 0);
+    ST_STAMP(sblk, 5);
     if (sblk > 0) {
         __syncthreads();  // the parked pieces have been written back: `lds` is free for the transposes
         write_back((sblk - 1) * SB, true);
     }
+    ST_STAMP(sblk, 6);
+}
+
+// Persistent forward solve with HELPER workgroups: two workgroups per 128-block s, on two CUs.
+//   helper s (dispatched first)  applies the row blocks kb = 0 .. s-2 to the strip's partial w as their w is published
+//                                (the rows of the next step are requested a step ahead, two register buffers) and hands
+//                                the 128 partial sums to
+//   chain s                      whose diagonal block is parked in LDS and whose rows of the one row block it still has
+//                                to apply (s-1) are in registers well before w of block s-1 comes out.  It takes the
+//                                helper's sums, applies block s-1, solves, publishes.
+// The products S[i][j] = U[j][i] w[j] (src/ell_stable.rs:66) are needed by nobody before the backward solve; writing
+// them (transposed through LDS, 2.3 us per row block) is shared so that neither workgroup sets the pace: the helper
+// writes the EVEN row blocks it has just applied, the chain workgroup recomputes and writes the ODD ones while it has
+// nothing else to do (it stops once block s-5 is solved) and, after its own hand-over, whatever is left plus row block
+// s-1.
+// Why: with one workgroup per block the chain period is (R + C) / 2, R = what the workgroup still has to do for row
+// block s-2 after that block's hand-over plus fetching and parking its own block (10.7 us at n = 16384: flag 1.7, sums
+// 0.6, write-back 2.2, 224 KB of rows + own block 6.2), C = 4.0 us from the arrival of block s-1's values to its own
+// hand-over (tools/experiments/st_fwd_timeline.hip, profiles/r02/ellstable_fwd_timeline.txt).  A workgroup moves
+// 128 KB in about 1 us at best (64 B / clock / CU): a helper that wrote every row block back (4.8 us per step) set the
+// pace itself (6.4 us per block); with every other one it averages 3.7 us per step, ahead of the chain.
+// Same arithmetic in the same order per column, same products: identical bits.  grid = 2 * ceil(n/128) <= the resident
+// limit (every workgroup waits only for workgroups dispatched before it); beyond that the handle uses k_st_fwd_persist.
+// hpart: n doubles, all-sentinel at launch (k_st_post re-arms it after every solve), the helpers' hand-over buffer.
+constexpr long long ST_DUTY_STOP = 5;  // the chain workgroup of block s stops writing once block s - 5 is solved
+__global__ __launch_bounds__(256) void k_st_fwd_helped(double* __restrict__ M, long long ld, long long n,
+                                                       const double* __restrict__ g, double* __restrict__ w,
+                                                       double* __restrict__ hpart, double* __restrict__ z,
+                                                       double* __restrict__ gg, int* __restrict__ flags,
+                                                       int* __restrict__ err, int epoch,
+                                                       const DevState* __restrict__ st) {
+    if (st->halted) return;
+    __shared__ __attribute__((aligned(16))) double lds[ST_LDS_DOUBLES];  // panel tiles / the parked pieces
+    __shared__ double part[4][SPANEL];
+    __shared__ double wstrip[SPANEL];
+    __shared__ double wblk[SB];
+    __shared__ double dlds[SB];
+    __shared__ int ok, duty_stop;
+    const int lane = threadIdx.x & 63;
+    const int wv = threadIdx.x >> 6;
+    const long long sblk = blockIdx.x >> 1;
+    const bool chain = (blockIdx.x & 1) != 0;
+    const long long c0 = sblk * SB;
+    const long long c = c0 + 2 * lane;
+    const long long cl = (c < n) ? c : 0;
+    const int piece = lane & 7;
+    double* t = lds + wv * (SPANEL * SLDS_PAD);
+
+    auto load_rows = [&](long long J0, double2_t (&u)[2][16]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const long long r0 = J0 + 32 * wv + 16 * h;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) u[h][r] = *reinterpret_cast<const double2_t*>(M + (r0 + r) * ld + cl);
+        }
+    };
+    // products (u <- u .* w of the row block in wblk); SUMS: also the strip's partial w (leaves with them applied)
+    auto apply_rows = [&](double2_t (&u)[2][16], auto sums_c) __attribute__((always_inline)) {
+        double p0 = 0.0, p1 = 0.0;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const double wj = wblk[32 * wv + 16 * h + r];
+                const double v0 = u[h][r].x * wj;
+                const double v1 = u[h][r].y * wj;
+                p0 += v0;
+                p1 += v1;
+                u[h][r].x = v0;  // the product replaces the factor entry (src/ell_stable.rs:66)
+                u[h][r].y = v1;
+            }
+        }
+        if constexpr (decltype(sums_c)::value) {
+            part[wv][2 * lane] = p0;
+            part[wv][2 * lane + 1] = p1;
+            __syncthreads();
+            if (threadIdx.x < SPANEL) {
+                const double s4 = ((part[0][threadIdx.x] + part[1][threadIdx.x]) + part[2][threadIdx.x]) +
+                                  part[3][threadIdx.x];
+                wstrip[threadIdx.x] = wstrip[threadIdx.x] - s4;
+            }
+        }
+    };
+    // S[col][J0 + ..] <- the products, transposed through LDS (as in k_st_fwd_persist); ends with the tiles drained
+    auto write_back = [&](long long J0, double2_t (&u)[2][16]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const long long r0 = J0 + 32 * wv + 16 * h;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                t[(2 * lane) * SLDS_PAD + r] = u[h][r].x;
+                t[(2 * lane + 1) * SLDS_PAD + r] = u[h][r].y;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const int col_local = 8 * k + (lane >> 3);
+                const long long col = c0 + col_local;
+                if (col < n) {
+                    const double2_t v = *reinterpret_cast<const double2_t*>(&t[col_local * SLDS_PAD + 2 * piece]);
+                    *reinterpret_cast<double2_t*>(M + col * ld + r0 + 2 * piece) = v;
+                }
+            }
+            __syncthreads();
+        }
+    };
+
+    if (threadIdx.x < SPANEL) wstrip[threadIdx.x] = (c0 + threadIdx.x < n) ? g[c0 + threadIdx.x] : 0.0;
+
+    if (!chain) {
+        // ------------------------------------------- helper: sums over the row blocks 0 .. sblk - 2, products of the even ones
+        const long long last = sblk - 2;
+        if (last < 0) return;
+        double2_t ua[2][16], ub[2][16];
+        // One step: wait for row block kb, request the rows of the step after it into the other buffer (AFTER the wait:
+        // loads return in order, a request in front of the poll would delay the poll's answer by its own latency), apply.
+        auto step = [&](long long kb, double2_t (&cur)[2][16], double2_t (&nxt)[2][16], auto even_c) __attribute__((always_inline)) -> bool {
+            ST_STAMP(kb, 0);
+            if (threadIdx.x == 0) ok = st_wait_flag(flags + kb, epoch) ? 1 : 0;
+            __syncthreads();
+            if (!ok) return false;
+            ST_STAMP(kb, 1);
+            if (threadIdx.x < SB) wblk[threadIdx.x] = st_published_load(w + kb * SB + threadIdx.x);
+            __syncthreads();
+            ST_STAMP(kb, 2);
+            apply_rows(cur, std::true_type{});
+            if (kb == last && threadIdx.x < SPANEL && c0 + threadIdx.x < n)
+                st_publish_store(hpart + c0 + threadIdx.x, wstrip[threadIdx.x]);  // the value is its own flag
+            // the rows of the next step: requested AFTER the wait (loads return in order, a request in front of the poll
+            // would delay the poll's answer by its own latency) and after the sums (issuing 128 KB of loads takes ~1 us)
+            load_rows(((kb + 1 <= last) ? kb + 1 : last) * SB, nxt);  // (past the end: row block `last` again, unused)
+            ST_STAMP(kb, 3);
+            if constexpr (decltype(even_c)::value) write_back(kb * SB, cur);
+            else __syncthreads();  // part / wblk are rewritten by the next step
+            ST_STAMP(kb, 4);
+            return true;
+        };
+        load_rows(0, ua);
+        bool fine = true;
+        for (long long kb = 0; fine && kb <= last; kb += 2) {
+            fine = step(kb, ua, ub, std::true_type{});
+            if (fine && kb + 1 <= last) fine = step(kb + 1, ub, ua, std::false_type{});
+        }
+        if (!fine && threadIdx.x == 0) atomicExch(err, 1);
+        return;
+    }
+
+    // -------------------------------------------------------------------- chain
+    double2_t u[2][16];
+    // (1) writing duty: the products of the odd row blocks up to sblk - 5, until block sblk - 5 is solved
+    long long odd_next = 1;  // the odd row blocks below this one have their products in S (uniform)
+    {
+        const long long dlast = sblk - ST_DUTY_STOP;
+        for (; odd_next <= dlast; odd_next += 2) {
+            const long long kb = odd_next;
+            if (threadIdx.x == 0) {
+                ok = st_wait_flag(flags + kb, epoch) ? 1 : 0;
+                duty_stop = (__hip_atomic_load(flags + dlast, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch) ? 1 : 0;
+            }
+            __syncthreads();
+            if (!ok) {
+                if (threadIdx.x == 0) atomicExch(err, 1);
+                return;
+            }
+            if (threadIdx.x < SB) wblk[threadIdx.x] = st_published_load(w + kb * SB + threadIdx.x);
+            const int stop = duty_stop;
+            load_rows(kb * SB, u);
+            __syncthreads();
+            apply_rows(u, std::false_type{});
+            write_back(kb * SB, u);
+            if (stop) {  // block sblk - 5 is solved: time to get ready for the own solve
+                odd_next += 2;
+                break;
+            }
+        }
+    }
+    // (2) the own solve
+    Blk3 blk;
+    double dreg = 0.0;
+    st_prefetch_block(M, ld, n, c0, blk, dreg);
+    if (sblk > 0) load_rows((sblk - 1) * SB, u);
+    st_fwd_park(blk, dreg, lds, dlds);
+    if (threadIdx.x == 0) ok = 1;
+    __syncthreads();
+    double ucol[SH];  // this wave's columns of the parked pieces, in registers before the values arrive
+    st_fwd_diag_cols(lds, c0 + SH < n, ucol);
+    ST_STAMP(sblk, 0);
+    if (sblk >= 2 && threadIdx.x < SPANEL && c0 + threadIdx.x < n) {  // the helper's sums over the row blocks 0 .. sblk - 2
+        double v = 0.0;
+        if (!st_poll_value(hpart + c0 + threadIdx.x, v)) ok = 0;
+        wstrip[threadIdx.x] = v;
+    }
+    ST_STAMP(sblk, 1);
+    if (sblk >= 1) {
+        // next in the chain: poll the 128 values themselves (all-sentinel when the launch starts)
+        if (threadIdx.x < SB) {
+            double v = 0.0;
+            if (!st_poll_value(w + (sblk - 1) * SB + threadIdx.x, v)) ok = 0;
+            wblk[threadIdx.x] = v;
+        }
+        __syncthreads();
+        if (!ok) {
+            if (threadIdx.x == 0) atomicExch(err, 1);
+            return;
+        }
+        ST_STAMP(sblk, 2);
+        apply_rows(u, std::true_type{});
+    }
+    __syncthreads();
+    ST_STAMP(sblk, 3);
+    st_fwd_diag_block_pre(M, ld, n, c0, lds, dlds, wstrip, w, z, gg, flags + sblk, epoch, ucol);
+    // (3) the products not written yet, off the chain (every w they need is published): the remaining odd row blocks and
+    // row block sblk - 1 (the helper stops at sblk - 2)
+    __syncthreads();  // the parked pieces have been written back: `lds` is free for the transposes
+    auto late = [&](long long kb) __attribute__((always_inline)) {
+        if (threadIdx.x < SB) wblk[threadIdx.x] = st_published_load(w + kb * SB + threadIdx.x);
+        load_rows(kb * SB, u);
+        __syncthreads();
+        apply_rows(u, std::false_type{});
+        write_back(kb * SB, u);
+    };
+    ST_STAMP(sblk, 5);
+    for (long long kb = odd_next; kb < sblk; kb += 2) late(kb);
+    if (sblk >= 1 && ((sblk - 1) & 1) == 0) late(sblk - 1);
+    ST_STAMP(sblk, 6);
 }
 
 // Paired persistent forward solve: workgroup t owns TWO consecutive 128-blocks, A = 2t and B = 2t + 1 (256 columns; a
@@ -876,9 +1224,11 @@ __global__ __launch_bounds__(256) void k_st_post(double* __restrict__ M, long lo
                                                  const double* __restrict__ z, const double* __restrict__ gg,
                                                  const double* __restrict__ cpre, double* __restrict__ q,
                                                  double* __restrict__ beta2, double* __restrict__ qpub_rearm,
-                                                 double* __restrict__ w_rearm, const DevState* __restrict__ st) {
+                                                 double* __restrict__ w_rearm, const DevState* __restrict__ st,
+                                                 double* __restrict__ hpart_rearm = nullptr) {
     const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n) return;
+    if (hpart_rearm) hpart_rearm[j] = st_sentinel();  // the helpers' hand-over buffer (k_st_fwd_helped), like w_rearm
     // the publish buffer of the NEXT persistent forward solve: armed whatever happened to this update (a failed cut and
     // a halted loop still alternate the buffers, see ellstable_issue)
     if (w_rearm) w_rearm[j] = st_sentinel();
@@ -917,7 +1267,7 @@ __device__ __forceinline__ double st_bwd_chain_regs(const double (&sv)[SH], int 
     if (nvalid == SH) {
         double t = qi;
 #pragma unroll
-        for (int j = SH - 1; j >= 1; --j) {
+        for (int j = SH - 1; j >= 1 + (SH - ST_EXP_CHAIN_STEPS); --j) {
             const double qj = lane_bcast(t, j);
             const double v = sv[j] * qj;
             t = qi - v;
@@ -1368,6 +1718,80 @@ __global__ __launch_bounds__(256) void k_st_factor(double* __restrict__ M, long 
                 *reinterpret_cast<double2_t*>(p) = uv;
             else
                 p[1] = uv.y;
+        }
+    }
+}
+
+// The same update WITHOUT reading the scratch triangle.  S[l][j] is, bit for bit, the product fl(U[j][l] * w[j]) the
+// forward solve of THIS update stored (src/ell_stable.rs:66; every path above writes exactly that product, and nothing
+// touches U or S between the solve and here), so
+//     U[j][l] <- U[j][l] + beta2[j] * fl(U[j][l] * w[j]),   l > j
+// is the reference's `+= beta2 * S[l][j]` (:114-117) with the factor of the product re-read from the element itself:
+// a row-wise read-modify-write of the strict upper triangle -- 8 n^2 bytes instead of 12 n^2, no transposes.
+// Tiles of FROW_H rows x SEG columns (one workgroup each; 2-D grid, tiles left of the diagonal leave at once); a thread
+// holds SEG / 512 column pairs of RW rows at a time.
+constexpr int FROW_H = 64;
+template <int SEG, int RW>
+__global__ __launch_bounds__(256) void k_st_factor_rows(double* __restrict__ M, long long ld, long long n,
+                                                        const double* __restrict__ beta2,
+                                                        const double* __restrict__ w,
+                                                        const DevState* __restrict__ st) {
+    if (!st->apply) return;
+    constexpr int NCH = SEG / 512;
+    const long long r0 = (long long)blockIdx.x * FROW_H, c0 = (long long)blockIdx.y * SEG;
+    if (r0 >= n || c0 >= n || c0 + SEG - 1 <= r0) return;  // no column of the segment right of the strip's first row
+    const long long rlast = (r0 + FROW_H - 1 < n - 1) ? r0 + FROW_H - 1 : n - 1;
+    // every element of the tile is right of the diagonal and every pair inside the matrix: no masks
+    const bool full = c0 > rlast && c0 + SEG <= n;
+    long long col[NCH];
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) col[k] = c0 + 512 * k + 2 * (long long)threadIdx.x;
+    for (long long j0 = r0; j0 <= rlast; j0 += RW) {
+        double2_t v[RW][NCH];
+        double b[RW], wj[RW];
+        if (full) {
+#pragma unroll
+            for (int r = 0; r < RW; ++r) {
+                const long long j = (j0 + r <= rlast) ? j0 + r : rlast;  // (past the strip: the last row again, not stored)
+                b[r] = beta2[j];
+                wj[r] = w[j];
+#pragma unroll
+                for (int k = 0; k < NCH; ++k) v[r][k] = ld_stream<true, double2_t>(M + j * ld + col[k]);
+            }
+#pragma unroll
+            for (int r = 0; r < RW; ++r) {
+                if (j0 + r > rlast) break;
+#pragma unroll
+                for (int k = 0; k < NCH; ++k) {
+                    double2_t o;
+                    o.x = v[r][k].x + b[r] * (v[r][k].x * wj[r]);
+                    o.y = v[r][k].y + b[r] * (v[r][k].y * wj[r]);
+                    *reinterpret_cast<double2_t*>(M + (j0 + r) * ld + col[k]) = o;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < RW; ++r) {
+                const long long j = j0 + r;
+                if (j > rlast) break;
+                const double bj = beta2[j], wv = w[j];
+#pragma unroll
+                for (int k = 0; k < NCH; ++k) {
+                    const long long l = col[k];
+                    if (l + 1 <= j || l >= n) continue;  // both left of / on the diagonal, or outside the matrix
+                    double* p = M + j * ld + l;
+                    if (l > j && l + 1 < n) {
+                        double2_t uv = *reinterpret_cast<double2_t*>(p);
+                        uv.x = uv.x + bj * (uv.x * wv);
+                        uv.y = uv.y + bj * (uv.y * wv);
+                        *reinterpret_cast<double2_t*>(p) = uv;
+                    } else if (l > j) {        // l == n - 1: the last column alone
+                        if (l < n) p[0] = p[0] + bj * (p[0] * wv);
+                    } else if (l + 1 < n) {    // l == j: only the second element of the pair is right of the diagonal
+                        p[1] = p[1] + bj * (p[1] * wv);
+                    }
+                }
+            }
         }
     }
 }

@@ -113,6 +113,33 @@ def test_paired_persistent_solves_equal_per_block_launches(gpu, monkeypatch, n):
     assert np.array_equal(a.xc(), b.xc()) and np.array_equal(a.mq, b.mq)
 
 
+@pytest.mark.parametrize("n", [2, 63, 64, 65, 129, 300, 513, 1000, 2048, 2048 + 128, 2049])
+def test_default_solves_and_factor_update_equal_the_plain_kernels(gpu, monkeypatch, n):
+    """The default EllStable path -- forward solve with a helper workgroup per block (k_st_fwd_helped) and the factor
+    update computed from U alone (k_st_factor_rows: the scratch entry it would read IS fl(U * w)) -- must give the bits
+    of the plain path: one launch per block, factor update reading the scratch triangle through LDS transposes.  Odd and
+    even n, ragged last blocks, one block, a failing cut in the middle."""
+    f = random_factor(n, 271 + n)
+    a = gpu.EllStable.new_with_matrix(1.0, f, np.zeros(n))
+    monkeypatch.setenv("ELLHIP_STABLE_HELPERS", "0")
+    monkeypatch.setenv("ELLHIP_STABLE_FACTOR_ROWS", "0")
+    monkeypatch.setenv("ELLHIP_STABLE_PERSIST", "0")
+    b = gpu.EllStable.new_with_matrix(1.0, f, np.zeros(n))
+    monkeypatch.delenv("ELLHIP_STABLE_PERSIST")
+    monkeypatch.setenv("ELLHIP_STABLE_FACTOR_ROWS", "1")
+    c = gpu.EllStable.new_with_matrix(1.0, f, np.zeros(n))   # persistent solves without helpers + the row-wise factor update
+    rng = np.random.default_rng(13 * n)
+    for i in range(8):
+        gr = rng.standard_normal(n)
+        gr /= np.linalg.norm(gr)
+        beta = 5.0 if i == 5 else 0.05 * rng.random()
+        sa, sb, sc = (int(x.update_bias_cut((gr, beta))) for x in (a, b, c))
+        assert sa == sb == sc == (1 if i == 5 else 0)
+        assert a.tsq() == b.tsq() == c.tsq() and a.kappa == b.kappa == c.kappa
+    assert np.array_equal(a.xc(), b.xc()) and np.array_equal(a.mq, b.mq)
+    assert np.array_equal(c.xc(), b.xc()) and np.array_equal(c.mq, b.mq)
+
+
 def test_failed_cut_in_the_middle_of_a_sequence(gpu, orc):
     n = 200
     g, o, f = _pair(gpu, orc, n, 4242)
