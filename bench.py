@@ -703,6 +703,14 @@ def main() -> None:
     alg = {"gemv": 8.0 * n2w, "rank1": 16.0 * n2w, "fused": 16.0 * n2w, "apply": (8.0 if lower_apply else 16.0) * n2w,
            "apply_gemv": 16.0 * n2w, "symv": 4.0 * n2w,
            "stable_fwd": 8.0 * n * n, "stable_bwd": 4.0 * n * n, "stable_factor": 12.0 * n * n}
+    if variant != "ell":
+        # EllStable: the factor update rewrites the strict upper triangle from itself (8*n^2; the scratch entry the
+        # reference adds IS fl(U*w)) unless the scratch-reading tile kernel is forced; and it runs
+        # inside the backward solve's launch (k_st_bwd_factor) when no separate factor launch shows up in the profile
+        rows = os.environ.get("ELLHIP_STABLE_FACTOR_ROWS", "1") != "0"
+        alg["stable_factor"] = (8.0 if rows else 12.0) * n * n
+        if prof and prof.get("stable_factor", (0.0, 0))[1] == 0:
+            alg["stable_bwd"] = 4.0 * n * n + alg["stable_factor"]
 
     def byte_model(sched, dep):
         """algorithmic bytes ONE update moves per GPU-share under a schedule / depth, and its description"""
@@ -741,7 +749,8 @@ def main() -> None:
     # bytes one update moves under the schedule that was timed (each schedule has its OWN byte model;
     # nothing is credited against the 24*n^2 two-pass model)
     if variant != "ell":
-        bytes_update, model = 24.0 * n * n, "24*n^2 B per update (EllStable: fwd 8 + bwd 4 + factor 12)"
+        fb = alg["stable_factor"] / (n * n)
+        bytes_update, model = (12.0 + fb) * n * n, f"{12.0 + fb:g}*n^2 B per update (EllStable: fwd 8 + bwd 4 + factor {fb:g})"
     else:
         bytes_update, model = byte_model("pipelined" if fused else "two-pass", depth)
     roofline = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None, "byte_model": model}

@@ -83,6 +83,10 @@ struct ellhip_space {
     double* d_hpart = nullptr;       // EllStable forward solve with helper workgroups: the helpers' hand-over buffer (n)
     int stable_helpers = 1;          // k_st_fwd_helped when 2 * ceil(n/128) workgroups are resident at once
     int stable_factor_rows = 1;      // factor update from U alone (k_st_factor_rows); 0: the tile kernel that reads the scratch
+    int stable_fused = 1;            // backward solve + factor update in one launch (k_st_bwd_factor)
+    int* d_ftiles = nullptr;         // its factor tiles (strip << 8 | segment), largest first
+    int* d_fnext = nullptr;          // ... and the queue position (reset by k_st_post before every launch)
+    int nftiles = 0, fused_workers = 0;
     int persist_cap_h = 0;           // that limit (CU count x occupancy of k_st_fwd_helped)
     double* d_partial = nullptr;     // per-workgroup partial sums of omega (64)
     double* d_pend = nullptr;        // deferred mode: MAXPEND pending gt vectors (n each)
@@ -475,18 +479,30 @@ int ellstable_issue(ellhip_space* s, const double* g_dev, const CutParams* cp_de
         hipLaunchKernelGGL(k_st_post, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, s->d_Q, ld, n,
                            (const double*)z, (const double*)gg, (const double*)cpre, q, beta2,
                            persist ? qpub : (double*)nullptr, persist ? w_next : (double*)nullptr,
-                           (const DevState*)s->d_st, helped ? s->d_hpart : (double*)nullptr);
+                           (const DevState*)s->d_st, helped ? s->d_hpart : (double*)nullptr, s->d_fnext);
         HIPCHK(hipGetLastError());
     }
     // The factor update (reads S, rewrites U) and the backward solve (reads S, writes q) are independent.
     // With the persistent backward solve (128 resident workgroups, latency-bound) the bandwidth-bound
     // factor update runs beside it on the auxiliary stream, launched AFTER it so the solve's workgroups
     // are placed first; the streams join before anything else touches the buffer.
-    const bool overlap = persist && s->stable_overlap;
+    const bool fused = persist && !pair_bwd && s->stable_fused && s->stable_factor_rows && s->d_ftiles && s->d_fnext &&
+                       s->fused_workers > 0 && nb + s->fused_workers <= s->persist_cap1;
+    const bool overlap = persist && s->stable_overlap && !fused;
     if (overlap) HIPCHK(hipEventRecord(s->ev_fork, st));
     {
         ProfScope ps(s, CLS_ST_BWD);
-        if (pair_bwd) {
+        if (fused) {
+            const unsigned grid = (unsigned)(nb + s->fused_workers);
+            if (n >= 8192)
+                hipLaunchKernelGGL((k_st_bwd_factor<2048, 8>), dim3(grid), dim3(256), 0, st, s->d_Q, ld, n, q, qpub, err,
+                                   (const DevState*)s->d_st, nb, (const double*)beta2, (const double*)w,
+                                   (const int*)s->d_ftiles, s->nftiles, s->d_fnext);
+            else
+                hipLaunchKernelGGL((k_st_bwd_factor<512, 16>), dim3(grid), dim3(256), 0, st, s->d_Q, ld, n, q, qpub, err,
+                                   (const DevState*)s->d_st, nb, (const double*)beta2, (const double*)w,
+                                   (const int*)s->d_ftiles, s->nftiles, s->d_fnext);
+        } else if (pair_bwd) {
             hipLaunchKernelGGL(k_st_bwd_persist2, dim3((unsigned)npair), dim3(256), 0, st, s->d_Q, ld, n, q, qpub, err,
                                s->d_st);
         } else if (persist) {
@@ -503,7 +519,7 @@ int ellstable_issue(ellhip_space* s, const double* g_dev, const CutParams* cp_de
         hipLaunchKernelGGL(k_st_xc, dim3(gx < 256 ? gx : 256), dim3(256), 0, st, n, q, s->d_xc, s->d_st);
         HIPCHK(hipGetLastError());
     }
-    {
+    if (!fused) {
         hipStream_t fs = overlap ? s->aux_stream : st;
         if (overlap) HIPCHK(hipStreamWaitEvent(fs, s->ev_fork, 0));
         {
@@ -906,6 +922,31 @@ int alloc_common(ellhip_space* s) {
             s->persist_cap2 = env_int("ELLHIP_STABLE_CAP2", s->persist_cap2);
         }
         s->stable_overlap = env_int("ELLHIP_STABLE_OVERLAP", 1);
+        s->stable_fused = env_int("ELLHIP_STABLE_FUSED", 1);
+        {   // the factor tiles of k_st_bwd_factor: the active tiles of k_st_factor_rows' grid, full ones first
+            const long long seg = (n >= 8192) ? 2048 : 512;
+            const long long nstrip = (n + FROW_H - 1) / FROW_H, nseg = (n + seg - 1) / seg;
+            std::vector<int> full, edge;
+            for (long long I = 0; I < nstrip && nseg <= 255; ++I)
+                for (long long J = 0; J < nseg; ++J) {
+                    const long long r0 = I * FROW_H, c0 = J * seg;
+                    if (c0 + seg - 1 <= r0) continue;
+                    const long long rlast = std::min(r0 + FROW_H - 1, n - 1);
+                    ((c0 > rlast && c0 + seg <= n) ? full : edge).push_back((int)((I << 8) | J));
+                }
+            full.insert(full.end(), edge.begin(), edge.end());
+            s->nftiles = (int)full.size();
+            const long long nbk = (n + SB - 1) / SB;
+            s->fused_workers = (int)std::max<long long>(0, std::min<long long>(s->persist_cap1 - nbk, s->nftiles));
+            s->fused_workers = env_int("ELLHIP_STABLE_WORKERS", s->fused_workers);
+            if (s->nftiles > 0) {
+                HIPCHK(hipMalloc(&s->d_fnext, sizeof(int)));
+                HIPCHK(hipMemsetAsync(s->d_fnext, 0, sizeof(int), s->stream));
+                HIPCHK(hipMalloc(&s->d_ftiles, full.size() * sizeof(int)));
+                HIPCHK(hipMemcpyAsync(s->d_ftiles, full.data(), full.size() * sizeof(int), hipMemcpyHostToDevice, s->stream));
+                HIPCHK(hipStreamSynchronize(s->stream));  // `full` goes out of scope
+            }
+        }
         HIPCHK(hipStreamCreateWithFlags(&s->aux_stream, hipStreamNonBlocking));
         HIPCHK(hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&s->ev_join, hipEventDisableTiming));
@@ -1160,6 +1201,8 @@ void ellhip_destroy(ellhip_space* s) {
     }
     if (s->d_work) (void)hipFree(s->d_work);
     if (s->d_hpart) (void)hipFree(s->d_hpart);
+    if (s->d_ftiles) (void)hipFree(s->d_ftiles);
+    if (s->d_fnext) (void)hipFree(s->d_fnext);
     if (s->d_partial) (void)hipFree(s->d_partial);
     if (s->d_pend) (void)hipFree(s->d_pend);
     if (s->d_cpend) (void)hipFree(s->d_cpend);
@@ -1217,6 +1260,7 @@ int ellhip_clone(const ellhip_space* src_c, ellhip_space** out) {
         s->stable_pair = src->stable_pair;
         s->stable_helpers = src->stable_helpers;
         s->stable_factor_rows = src->stable_factor_rows;
+        s->stable_fused = src->stable_fused;
     }
     if (rc) {
         ellhip_destroy(s);

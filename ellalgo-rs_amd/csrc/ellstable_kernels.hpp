@@ -1225,9 +1225,11 @@ __global__ __launch_bounds__(256) void k_st_post(double* __restrict__ M, long lo
                                                  const double* __restrict__ cpre, double* __restrict__ q,
                                                  double* __restrict__ beta2, double* __restrict__ qpub_rearm,
                                                  double* __restrict__ w_rearm, const DevState* __restrict__ st,
-                                                 double* __restrict__ hpart_rearm = nullptr) {
+                                                 double* __restrict__ hpart_rearm = nullptr,
+                                                 int* __restrict__ fnext_reset = nullptr) {
     const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n) return;
+    if (fnext_reset && j == 0) *fnext_reset = 0;  // the factor-tile queue of k_st_bwd_factor
     if (hpart_rearm) hpart_rearm[j] = st_sentinel();  // the helpers' hand-over buffer (k_st_fwd_helped), like w_rearm
     // the publish buffer of the NEXT persistent forward solve: armed whatever happened to this update (a failed cut and
     // a halted loop still alternate the buffers, see ellstable_issue)
@@ -1364,6 +1366,55 @@ __device__ __forceinline__ void st_bwd_diag_block(long long n, long long J0, con
         if (qout) qout[lane] = qA;
         q[J0 + lane] = qA;
         if (PUBLISH) st_publish_store(qpub + J0 + lane, qA);
+    }
+}
+
+// The same block for a workgroup that has time before the values it waits for arrive (k_st_bwd_factor): columns of the
+// parked pieces fetched into registers beforehand, mini panel B -> A shared by waves 1 and 3 -- see st_fwd_diag_block_pre.
+// Both halves exist (the caller takes st_bwd_diag_block for a ragged single half).  Always publishes.  Same bits.
+__device__ __forceinline__ void st_bwd_diag_cols(const double* __restrict__ lds, double (&sv)[SH]) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const double* mine = lds + (wave == 0 ? 0 : (wave == 2 ? 2 : 1)) * (SH * BLK_PITCH);  // BB | BA (waves 1, 3) | AA
+#pragma unroll
+    for (int j = 0; j < SH; ++j) sv[j] = mine[j * BLK_PITCH + lane];
+}
+template <int O>
+__device__ __forceinline__ double st_bwd_mini_half(const double (&sv)[SH], const double* __restrict__ qb, int nvalid) {
+    double a0 = 0.0, a1 = 0.0;  // the residues O, O + 1 of j mod 4 of st_bwd_mini_regs' four partial sums
+#pragma unroll
+    for (int j = O; j < SH; j += 4) {
+        const double v0 = sv[j] * qb[j];
+        const double v1 = sv[j + 1] * qb[j + 1];
+        a0 += (j < nvalid) ? v0 : 0.0;
+        a1 += (j + 1 < nvalid) ? v1 : 0.0;
+    }
+    return a0 + a1;
+}
+__device__ __forceinline__ void st_bwd_diag_block_pre(long long n, long long J0, const double* __restrict__ qpart,
+                                                      double* __restrict__ q, double* __restrict__ qpub,
+                                                      const double (&sv)[SH]) {
+    __shared__ double qb[SH];       // final q of half B
+    __shared__ double mini[2][SH];  // (a0 + a1), (a2 + a3) of the mini panel
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int nvalid_b = (n - (J0 + SH) < SH) ? (int)(n - (J0 + SH)) : SH;
+    if (wave == 0) qb[lane] = st_bwd_chain_regs(sv, nvalid_b, qpart[lane + SH]);
+    __syncthreads();
+    if (wave == 0) {
+        if (J0 + SH + lane < n) {
+            const double qB = qb[lane];
+            q[J0 + SH + lane] = qB;
+            st_publish_store(qpub + J0 + SH + lane, qB);  // the value is its own flag
+        }
+    } else if (wave == 1) {
+        mini[0][lane] = st_bwd_mini_half<0>(sv, qb, nvalid_b);
+    } else if (wave == 3) {
+        mini[1][lane] = st_bwd_mini_half<2>(sv, qb, nvalid_b);
+    }
+    __syncthreads();
+    if (wave == 2) {
+        const double qA = st_bwd_chain_regs(sv, SH, qpart[lane] - (mini[0][lane] + mini[1][lane]));
+        q[J0 + lane] = qA;
+        st_publish_store(qpub + J0 + lane, qA);
     }
 }
 
@@ -1731,14 +1782,15 @@ __global__ __launch_bounds__(256) void k_st_factor(double* __restrict__ M, long 
 // Tiles of FROW_H rows x SEG columns (one workgroup each; 2-D grid, tiles left of the diagonal leave at once); a thread
 // holds SEG / 512 column pairs of RW rows at a time.
 constexpr int FROW_H = 64;
-template <int SEG, int RW>
-__global__ __launch_bounds__(256) void k_st_factor_rows(double* __restrict__ M, long long ld, long long n,
-                                                        const double* __restrict__ beta2,
-                                                        const double* __restrict__ w,
-                                                        const DevState* __restrict__ st) {
-    if (!st->apply) return;
+// PIPE (the workers of k_st_bwd_factor: ONE workgroup per CU, so the loads in flight have to come from the thread
+// itself): full tiles with two register buffers of RW rows -- the next RW rows are requested before the current ones
+// are updated and stored (RW = 8, SEG = 2048: 2 x 128 KB per workgroup in flight).
+template <int SEG, int RW, bool PIPE = false>
+__device__ __forceinline__ void st_factor_tile(double* __restrict__ M, long long ld, long long n,
+                                               const double* __restrict__ beta2, const double* __restrict__ w,
+                                               long long I, long long J) {
     constexpr int NCH = SEG / 512;
-    const long long r0 = (long long)blockIdx.x * FROW_H, c0 = (long long)blockIdx.y * SEG;
+    const long long r0 = I * FROW_H, c0 = J * SEG;
     if (r0 >= n || c0 >= n || c0 + SEG - 1 <= r0) return;  // no column of the segment right of the strip's first row
     const long long rlast = (r0 + FROW_H - 1 < n - 1) ? r0 + FROW_H - 1 : n - 1;
     // every element of the tile is right of the diagonal and every pair inside the matrix: no masks
@@ -1746,6 +1798,42 @@ __global__ __launch_bounds__(256) void k_st_factor_rows(double* __restrict__ M, 
     long long col[NCH];
 #pragma unroll
     for (int k = 0; k < NCH; ++k) col[k] = c0 + 512 * k + 2 * (long long)threadIdx.x;
+    if constexpr (PIPE) {
+        if (full) {
+            double2_t va[RW][NCH], vb[RW][NCH];
+            auto fetch = [&](long long j0, double2_t (&v)[RW][NCH]) __attribute__((always_inline)) {
+#pragma unroll
+                for (int r = 0; r < RW; ++r) {
+                    const long long j = (j0 + r <= rlast) ? j0 + r : rlast;  // (past the strip: the last row again, not stored)
+#pragma unroll
+                    for (int k = 0; k < NCH; ++k) v[r][k] = ld_stream<true, double2_t>(M + j * ld + col[k]);
+                }
+            };
+            auto update = [&](long long j0, const double2_t (&v)[RW][NCH]) __attribute__((always_inline)) {
+#pragma unroll
+                for (int r = 0; r < RW; ++r) {
+                    if (j0 + r > rlast) break;
+                    const double bj = beta2[j0 + r], wv = w[j0 + r];
+#pragma unroll
+                    for (int k = 0; k < NCH; ++k) {
+                        double2_t o;
+                        o.x = v[r][k].x + bj * (v[r][k].x * wv);
+                        o.y = v[r][k].y + bj * (v[r][k].y * wv);
+                        *reinterpret_cast<double2_t*>(M + (j0 + r) * ld + col[k]) = o;
+                    }
+                }
+            };
+            fetch(r0, va);
+            for (long long j0 = r0; j0 <= rlast; j0 += 2 * RW) {
+                fetch(j0 + RW, vb);  // (clamped past the strip)
+                update(j0, va);
+                if (j0 + RW > rlast) break;
+                fetch(j0 + 2 * RW, va);
+                update(j0 + RW, vb);
+            }
+            return;
+        }
+    }
     for (long long j0 = r0; j0 <= rlast; j0 += RW) {
         double2_t v[RW][NCH];
         double b[RW], wj[RW];
@@ -1794,6 +1882,134 @@ __global__ __launch_bounds__(256) void k_st_factor_rows(double* __restrict__ M, 
             }
         }
     }
+}
+template <int SEG, int RW>
+__global__ __launch_bounds__(256) void k_st_factor_rows(double* __restrict__ M, long long ld, long long n,
+                                                        const double* __restrict__ beta2,
+                                                        const double* __restrict__ w,
+                                                        const DevState* __restrict__ st) {
+    if (!st->apply) return;
+    st_factor_tile<SEG, RW>(M, ld, n, beta2, w, (long long)blockIdx.x, (long long)blockIdx.y);
+}
+
+// Backward solve AND factor update in ONE launch (they are independent: the solve reads the scratch triangle and
+// writes q, the update rewrites the strict upper triangle from itself).  Workgroups [0, nblk) run the persistent
+// backward solve exactly as k_st_bwd_persist does (dispatch order = dependency order), with the diagonal block's
+// columns in registers before the values arrive (st_bwd_diag_block_pre); the workgroups after them are factor WORKERS:
+// worker k takes the tiles k, k + nworker, ... of the host-built list `ftiles` (strip << 8 | segment, the active tiles
+// of k_st_factor_rows<SEG, RW>'s grid, largest first).  One launch, so the overlap does not depend on the device
+// running two streams side by side (measured: on some boxes of the pool the two launches ran one after the other,
+// 0.68 + 0.47 ms instead of 0.93 together), and -- the static LDS of the solve limits every workgroup of this kernel to
+// one per CU -- the workers sit on OTHER CUs than the chain, which two separate kernels do not guarantee (the factor
+// kernel's waves then share the chain's SIMDs: backward solve 0.68 -> 0.92-0.96 ms).
+template <int SEG, int RW>
+__global__ __launch_bounds__(256) void k_st_bwd_factor(double* __restrict__ M, long long ld, long long n,
+                                                       double* __restrict__ q, double* __restrict__ qpub,
+                                                       int* __restrict__ err, const DevState* __restrict__ st,
+                                                       long long nblk, const double* __restrict__ beta2,
+                                                       const double* __restrict__ w, const int* __restrict__ ftiles,
+                                                       int nftiles, int* __restrict__ fnext) {
+    if (!st->apply) return;
+    // Factor tiles are PULLED (one atomic per 1 MiB tile): the workers start at once, and every chain workgroup joins
+    // them when its block is solved -- a CU streams ~30 GB/s at most (its outstanding misses x latency), so the 128
+    // worker CUs alone needed 0.85 ms for the 2.1 GB; the chain's CUs come free one by one, 5 us apart.
+    __shared__ int ftile;
+    auto work = [&]() __attribute__((always_inline)) {
+        for (;;) {
+            if (threadIdx.x == 0) ftile = atomicAdd(fnext, 1);
+            __syncthreads();
+            const int k = ftile;
+            __syncthreads();
+            if (k >= nftiles) break;
+            const int tl = ftiles[k];
+            st_factor_tile<SEG, RW, true>(M, ld, n, beta2, w, (long long)(tl >> 8), (long long)(tl & 0xff));
+        }
+    };
+    if ((long long)blockIdx.x >= nblk) {
+        work();
+        return;
+    }
+    __shared__ double lds[ST_LDS_DOUBLES_B];
+    __shared__ double part[4][SPANEL];
+    __shared__ double qstrip[SPANEL];
+    __shared__ double qblk[SB];
+    __shared__ int ok;
+    const int lane = threadIdx.x & 63;
+    const int wv = threadIdx.x >> 6;
+    const long long sblk = nblk - 1 - blockIdx.x;
+    const long long c0 = sblk * SB;
+    const long long c = c0 + 2 * lane;  // columns c, c+1 < c0 + 128 <= J0 of every row block applied here
+    const bool has_b = c0 + SH < n;
+
+    Blk3b blk;
+    double svc[SH];  // this wave's columns of the parked diagonal block
+    if (sblk == nblk - 1) {
+        st_prefetch_block_bwd(M, ld, n, c0, blk);
+        st_park_piece(lds, blk.bb, threadIdx.x);
+        st_park_piece(lds + SH * BLK_PITCH, blk.ba, threadIdx.x);
+        st_park_piece(lds + 2 * SH * BLK_PITCH, blk.aa, threadIdx.x);
+    }
+    if (threadIdx.x < SPANEL) qstrip[threadIdx.x] = (c0 + threadIdx.x < n) ? q[c0 + threadIdx.x] : 0.0;
+    if (threadIdx.x == 0) ok = 1;
+    __syncthreads();
+    if (sblk == nblk - 1 && has_b) st_bwd_diag_cols(lds, svc);
+
+    for (long long kb = nblk - 1; kb > sblk; --kb) {
+        const long long J0 = kb * SB;
+        double2_t sv[2][16];  // both passes' rows requested before the flag wait
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const long long r0 = J0 + 32 * wv + 16 * h;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                long long row = r0 + r;
+                if (row > n - 1) row = n - 1;
+                sv[h][r] = *reinterpret_cast<const double2_t*>(M + row * ld + c);
+            }
+        }
+        if (kb == sblk + 1) {  // own diagonal block: fetched, parked in LDS and its columns taken into registers while
+                               // the values it waits for are computed (sblk < nblk - 1: both halves exist)
+            st_prefetch_block_bwd(M, ld, n, c0, blk);
+            st_park_piece(lds, blk.bb, threadIdx.x);
+            st_park_piece(lds + SH * BLK_PITCH, blk.ba, threadIdx.x);
+            st_park_piece(lds + 2 * SH * BLK_PITCH, blk.aa, threadIdx.x);
+            __syncthreads();
+            st_bwd_diag_cols(lds, svc);
+        }
+        if (threadIdx.x < SB) {
+            double v = 0.0;
+            if (J0 + threadIdx.x < n && !st_poll_value(qpub + J0 + threadIdx.x, v)) ok = 0;
+            qblk[threadIdx.x] = v;
+        }
+        __syncthreads();
+        if (!ok) {
+            if (threadIdx.x == 0) atomicExch(err, 2);
+            return;
+        }
+        double p0 = 0.0, p1 = 0.0;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const double qj = qblk[32 * wv + 16 * h + r];  // 0 for rows beyond n
+                p0 += sv[h][r].x * qj;
+                p1 += sv[h][r].y * qj;
+            }
+        }
+        part[wv][2 * lane] = p0;
+        part[wv][2 * lane + 1] = p1;
+        __syncthreads();
+        if (threadIdx.x < SPANEL) {
+            const double s4 = ((part[0][threadIdx.x] + part[1][threadIdx.x]) + part[2][threadIdx.x]) +
+                              part[3][threadIdx.x];
+            qstrip[threadIdx.x] = qstrip[threadIdx.x] - s4;
+        }
+        __syncthreads();
+    }
+    __syncthreads();
+    if (has_b) st_bwd_diag_block_pre(n, c0, qstrip, q, qpub, svc);
+    else st_bwd_diag_block<true>(n, c0, blk, lds, qstrip, q, qpub, true);  // ragged last block, one half
+    work();  // this block is solved and handed over: the CU joins the factor workers
 }
 
 }  // namespace ellhip
