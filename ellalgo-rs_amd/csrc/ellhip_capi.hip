@@ -86,6 +86,10 @@ struct ellhip_space {
     int stable_fused = 1;            // backward solve + factor update in one launch (k_st_bwd_factor)
     int* d_ftiles = nullptr;         // its factor tiles (strip << 8 | segment), largest first
     int* d_fnext = nullptr;          // ... and the queue position (reset by k_st_post before every launch)
+    int* d_ftiles16 = nullptr;       // k_st_bwd_factor_helped: 16-row tiles (row group << 4 | segment)
+    int nftiles16 = 0;
+    double* d_qhpart = nullptr;      // ... and the backward helpers' hand-over buffer (n)
+    int stable_bwd_helpers = 1;
     int nftiles = 0, fused_workers = 0;
     int persist_cap_h = 0;           // that limit (CU count x occupancy of k_st_fwd_helped)
     double* d_partial = nullptr;     // per-workgroup partial sums of omega (64)
@@ -479,7 +483,8 @@ int ellstable_issue(ellhip_space* s, const double* g_dev, const CutParams* cp_de
         hipLaunchKernelGGL(k_st_post, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, s->d_Q, ld, n,
                            (const double*)z, (const double*)gg, (const double*)cpre, q, beta2,
                            persist ? qpub : (double*)nullptr, persist ? w_next : (double*)nullptr,
-                           (const DevState*)s->d_st, helped ? s->d_hpart : (double*)nullptr, s->d_fnext);
+                           (const DevState*)s->d_st, helped ? s->d_hpart : (double*)nullptr, s->d_fnext,
+                           (persist && s->stable_bwd_helpers) ? s->d_qhpart : (double*)nullptr);
         HIPCHK(hipGetLastError());
     }
     // The factor update (reads S, rewrites U) and the backward solve (reads S, writes q) are independent.
@@ -488,11 +493,30 @@ int ellstable_issue(ellhip_space* s, const double* g_dev, const CutParams* cp_de
     // are placed first; the streams join before anything else touches the buffer.
     const bool fused = persist && !pair_bwd && s->stable_fused && s->stable_factor_rows && s->d_ftiles && s->d_fnext &&
                        s->fused_workers > 0 && nb + s->fused_workers <= s->persist_cap1;
+    const bool fused_h = fused && s->stable_bwd_helpers && s->d_ftiles16 && s->d_qhpart && 2 * nb <= s->persist_cap1;
     const bool overlap = persist && s->stable_overlap && !fused;
     if (overlap) HIPCHK(hipEventRecord(s->ev_fork, st));
     {
         ProfScope ps(s, CLS_ST_BWD);
-        if (fused) {
+        if (fused_h) {
+            const unsigned grid = (unsigned)(2 * nb);
+            // (measurement only, results WRONG: ELLHIP_EXP_NO_FACTOR=1 leaves the factor tiles out to time the chain alone)
+            static const int no_factor = env_int("ELLHIP_EXP_NO_FACTOR", 0);
+            const int nft = no_factor > 0 ? s->nftiles16 - s->nftiles16 / no_factor : s->nftiles16;  // 1: none, 2: half, ...
+            // before their turn the chain workgroups pull factor tiles only when the matrix is on-die (n < 8192): from HBM
+            // it made them late for their own block (n = 16384: stop distance 6 / 12 / 24 / 48+ blocks: 785 / 731 / 710 /
+            // 685-695 us), on-die it pays (n = 4096: 139 us against 170 without)
+            static const int fq_env = env_int("ELLHIP_STABLE_FQ_STOP", 0);
+            const long long fq_stop = fq_env > 0 ? fq_env : (n >= 8192 ? nb + 1 : FQ_STOP);
+            if (n >= 8192)
+                hipLaunchKernelGGL((k_st_bwd_factor_helped<2048, 8>), dim3(grid), dim3(256), 0, st, s->d_Q, ld, n, q, qpub,
+                                   s->d_qhpart, err, (const DevState*)s->d_st, nb, (const double*)beta2, (const double*)w,
+                                   (const int*)s->d_ftiles16, nft, s->d_fnext, fq_stop);
+            else
+                hipLaunchKernelGGL((k_st_bwd_factor_helped<512, 8>), dim3(grid), dim3(256), 0, st, s->d_Q, ld, n, q, qpub,
+                                   s->d_qhpart, err, (const DevState*)s->d_st, nb, (const double*)beta2, (const double*)w,
+                                   (const int*)s->d_ftiles16, nft, s->d_fnext, fq_stop);
+        } else if (fused) {
             const unsigned grid = (unsigned)(nb + s->fused_workers);
             if (n >= 8192)
                 hipLaunchKernelGGL((k_st_bwd_factor<2048, 8>), dim3(grid), dim3(256), 0, st, s->d_Q, ld, n, q, qpub, err,
@@ -939,6 +963,27 @@ int alloc_common(ellhip_space* s) {
             const long long nbk = (n + SB - 1) / SB;
             s->fused_workers = (int)std::max<long long>(0, std::min<long long>(s->persist_cap1 - nbk, s->nftiles));
             s->fused_workers = env_int("ELLHIP_STABLE_WORKERS", s->fused_workers);
+            s->stable_bwd_helpers = env_int("ELLHIP_STABLE_BWD_HELPERS", 1);
+            {   // 16-row tiles of k_st_bwd_factor_helped
+                std::vector<int> f16, e16;
+                const long long ngrp = (n + FQ_H - 1) / FQ_H;
+                for (long long I = 0; I < ngrp && nseg <= 16; ++I)
+                    for (long long J = 0; J < nseg; ++J) {
+                        const long long r0 = I * FQ_H, c0 = J * seg;
+                        if (c0 + seg - 1 <= r0) continue;
+                        const long long rlast = std::min(r0 + FQ_H - 1, n - 1);
+                        ((c0 > rlast && c0 + seg <= n) ? f16 : e16).push_back((int)((I << 4) | J));
+                    }
+                f16.insert(f16.end(), e16.begin(), e16.end());
+                s->nftiles16 = (int)f16.size();
+                if (s->nftiles16 > 0) {
+                    HIPCHK(hipMalloc(&s->d_ftiles16, f16.size() * sizeof(int)));
+                    HIPCHK(hipMemcpyAsync(s->d_ftiles16, f16.data(), f16.size() * sizeof(int), hipMemcpyHostToDevice, s->stream));
+                    HIPCHK(hipStreamSynchronize(s->stream));
+                    HIPCHK(hipMalloc(&s->d_qhpart, vbytes));
+                    hipLaunchKernelGGL(k_st_arm, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream, s->d_qhpart, n);
+                }
+            }
             if (s->nftiles > 0) {
                 HIPCHK(hipMalloc(&s->d_fnext, sizeof(int)));
                 HIPCHK(hipMemsetAsync(s->d_fnext, 0, sizeof(int), s->stream));
@@ -1203,6 +1248,8 @@ void ellhip_destroy(ellhip_space* s) {
     if (s->d_hpart) (void)hipFree(s->d_hpart);
     if (s->d_ftiles) (void)hipFree(s->d_ftiles);
     if (s->d_fnext) (void)hipFree(s->d_fnext);
+    if (s->d_ftiles16) (void)hipFree(s->d_ftiles16);
+    if (s->d_qhpart) (void)hipFree(s->d_qhpart);
     if (s->d_partial) (void)hipFree(s->d_partial);
     if (s->d_pend) (void)hipFree(s->d_pend);
     if (s->d_cpend) (void)hipFree(s->d_cpend);
@@ -1261,6 +1308,7 @@ int ellhip_clone(const ellhip_space* src_c, ellhip_space** out) {
         s->stable_helpers = src->stable_helpers;
         s->stable_factor_rows = src->stable_factor_rows;
         s->stable_fused = src->stable_fused;
+        s->stable_bwd_helpers = src->stable_bwd_helpers;
     }
     if (rc) {
         ellhip_destroy(s);

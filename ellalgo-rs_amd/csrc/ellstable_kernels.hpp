@@ -667,9 +667,11 @@ __global__ __launch_bounds__(256) void k_st_fwd_persist(double* __restrict__ M, 
 //                                helper's sums, applies block s-1, solves, publishes.
 // The products S[i][j] = U[j][i] w[j] (src/ell_stable.rs:66) are needed by nobody before the backward solve; writing
 // them (transposed through LDS, 2.3 us per row block) is shared so that neither workgroup sets the pace: the helper
-// writes the EVEN row blocks it has just applied, the chain workgroup recomputes and writes the ODD ones while it has
-// nothing else to do (it stops once block s-5 is solved) and, after its own hand-over, whatever is left plus row block
-// s-1.
+// writes every 3rd row block it has just applied (ST_HELPER_WRITES), the chain workgroup recomputes and writes the others
+// while it has nothing else to do (it stops once block s-5 is solved) and, after its own hand-over, whatever is left plus
+// row block s-1.  A CU moves ~30 GB/s whatever its threads keep in flight, so the split is chosen by BYTES per step:
+// helper 128 KB of rows + 128/3 KB of products, chain workgroup 2/3 of (128 KB re-read + 128 KB written) -- 171 KB
+// each (every 2nd: 192 / 128 KB, 5.9 us per block; every 3rd or 4th: 5.7).
 // Why: with one workgroup per block the chain period is (R + C) / 2, R = what the workgroup still has to do for row
 // block s-2 after that block's hand-over plus fetching and parking its own block (10.7 us at n = 16384: flag 1.7, sums
 // 0.6, write-back 2.2, 224 KB of rows + own block 6.2), C = 4.0 us from the arrival of block s-1's values to its own
@@ -680,6 +682,9 @@ __global__ __launch_bounds__(256) void k_st_fwd_persist(double* __restrict__ M, 
 // limit (every workgroup waits only for workgroups dispatched before it); beyond that the handle uses k_st_fwd_persist.
 // hpart: n doubles, all-sentinel at launch (k_st_post re-arms it after every solve), the helpers' hand-over buffer.
 constexpr long long ST_DUTY_STOP = 5;  // the chain workgroup of block s stops writing once block s - 5 is solved
+#ifndef ST_HELPER_WRITES
+#define ST_HELPER_WRITES 3             // the helper writes every 3rd row block's products, the chain workgroup the others
+#endif
 __global__ __launch_bounds__(256) void k_st_fwd_helped(double* __restrict__ M, long long ld, long long n,
                                                        const double* __restrict__ g, double* __restrict__ w,
                                                        double* __restrict__ hpart, double* __restrict__ z,
@@ -771,7 +776,7 @@ __global__ __launch_bounds__(256) void k_st_fwd_helped(double* __restrict__ M, l
         double2_t ua[2][16], ub[2][16];
         // One step: wait for row block kb, request the rows of the step after it into the other buffer (AFTER the wait:
         // loads return in order, a request in front of the poll would delay the poll's answer by its own latency), apply.
-        auto step = [&](long long kb, double2_t (&cur)[2][16], double2_t (&nxt)[2][16], auto even_c) __attribute__((always_inline)) -> bool {
+        auto step = [&](long long kb, double2_t (&cur)[2][16], double2_t (&nxt)[2][16]) __attribute__((always_inline)) -> bool {
             ST_STAMP(kb, 0);
             if (threadIdx.x == 0) ok = st_wait_flag(flags + kb, epoch) ? 1 : 0;
             __syncthreads();
@@ -787,7 +792,7 @@ __global__ __launch_bounds__(256) void k_st_fwd_helped(double* __restrict__ M, l
             // would delay the poll's answer by its own latency) and after the sums (issuing 128 KB of loads takes ~1 us)
             load_rows(((kb + 1 <= last) ? kb + 1 : last) * SB, nxt);  // (past the end: row block `last` again, unused)
             ST_STAMP(kb, 3);
-            if constexpr (decltype(even_c)::value) write_back(kb * SB, cur);
+            if (kb % ST_HELPER_WRITES == 0) write_back(kb * SB, cur);
             else __syncthreads();  // part / wblk are rewritten by the next step
             ST_STAMP(kb, 4);
             return true;
@@ -795,8 +800,8 @@ __global__ __launch_bounds__(256) void k_st_fwd_helped(double* __restrict__ M, l
         load_rows(0, ua);
         bool fine = true;
         for (long long kb = 0; fine && kb <= last; kb += 2) {
-            fine = step(kb, ua, ub, std::true_type{});
-            if (fine && kb + 1 <= last) fine = step(kb + 1, ub, ua, std::false_type{});
+            fine = step(kb, ua, ub);
+            if (fine && kb + 1 <= last) fine = step(kb + 1, ub, ua);
         }
         if (!fine && threadIdx.x == 0) atomicExch(err, 1);
         return;
@@ -804,12 +809,13 @@ __global__ __launch_bounds__(256) void k_st_fwd_helped(double* __restrict__ M, l
 
     // -------------------------------------------------------------------- chain
     double2_t u[2][16];
-    // (1) writing duty: the products of the odd row blocks up to sblk - 5, until block sblk - 5 is solved
-    long long odd_next = 1;  // the odd row blocks below this one have their products in S (uniform)
+    // (1) writing duty: the products of the row blocks the helper leaves out, up to sblk - 5, until block sblk - 5 is solved
+    long long duty_next = 0;  // the chain workgroup's row blocks below this one have their products in S (uniform)
     {
         const long long dlast = sblk - ST_DUTY_STOP;
-        for (; odd_next <= dlast; odd_next += 2) {
-            const long long kb = odd_next;
+        for (; duty_next <= dlast; ++duty_next) {
+            const long long kb = duty_next;
+            if (kb % ST_HELPER_WRITES == 0) continue;  // the helper's
             if (threadIdx.x == 0) {
                 ok = st_wait_flag(flags + kb, epoch) ? 1 : 0;
                 duty_stop = (__hip_atomic_load(flags + dlast, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch) ? 1 : 0;
@@ -826,7 +832,7 @@ __global__ __launch_bounds__(256) void k_st_fwd_helped(double* __restrict__ M, l
             apply_rows(u, std::false_type{});
             write_back(kb * SB, u);
             if (stop) {  // block sblk - 5 is solved: time to get ready for the own solve
-                odd_next += 2;
+                ++duty_next;
                 break;
             }
         }
@@ -877,8 +883,8 @@ __global__ __launch_bounds__(256) void k_st_fwd_helped(double* __restrict__ M, l
         write_back(kb * SB, u);
     };
     ST_STAMP(sblk, 5);
-    for (long long kb = odd_next; kb < sblk; kb += 2) late(kb);
-    if (sblk >= 1 && ((sblk - 1) & 1) == 0) late(sblk - 1);
+    for (long long kb = duty_next; kb < sblk; ++kb)
+        if (kb % ST_HELPER_WRITES != 0 || kb == sblk - 1) late(kb);
     ST_STAMP(sblk, 6);
 }
 
@@ -1226,9 +1232,11 @@ __global__ __launch_bounds__(256) void k_st_post(double* __restrict__ M, long lo
                                                  double* __restrict__ beta2, double* __restrict__ qpub_rearm,
                                                  double* __restrict__ w_rearm, const DevState* __restrict__ st,
                                                  double* __restrict__ hpart_rearm = nullptr,
-                                                 int* __restrict__ fnext_reset = nullptr) {
+                                                 int* __restrict__ fnext_reset = nullptr,
+                                                 double* __restrict__ qhpart_rearm = nullptr) {
     const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n) return;
+    if (qhpart_rearm) qhpart_rearm[j] = st_sentinel();  // the backward helpers' hand-over buffer (k_st_bwd_factor_helped)
     if (fnext_reset && j == 0) *fnext_reset = 0;  // the factor-tile queue of k_st_bwd_factor
     if (hpart_rearm) hpart_rearm[j] = st_sentinel();  // the helpers' hand-over buffer (k_st_fwd_helped), like w_rearm
     // the publish buffer of the NEXT persistent forward solve: armed whatever happened to this update (a failed cut and
@@ -1785,14 +1793,14 @@ constexpr int FROW_H = 64;
 // PIPE (the workers of k_st_bwd_factor: ONE workgroup per CU, so the loads in flight have to come from the thread
 // itself): full tiles with two register buffers of RW rows -- the next RW rows are requested before the current ones
 // are updated and stored (RW = 8, SEG = 2048: 2 x 128 KB per workgroup in flight).
-template <int SEG, int RW, bool PIPE = false>
+template <int SEG, int RW, bool PIPE = false, int H = FROW_H>
 __device__ __forceinline__ void st_factor_tile(double* __restrict__ M, long long ld, long long n,
                                                const double* __restrict__ beta2, const double* __restrict__ w,
                                                long long I, long long J) {
     constexpr int NCH = SEG / 512;
-    const long long r0 = I * FROW_H, c0 = J * SEG;
+    const long long r0 = I * H, c0 = J * SEG;
     if (r0 >= n || c0 >= n || c0 + SEG - 1 <= r0) return;  // no column of the segment right of the strip's first row
-    const long long rlast = (r0 + FROW_H - 1 < n - 1) ? r0 + FROW_H - 1 : n - 1;
+    const long long rlast = (r0 + H - 1 < n - 1) ? r0 + H - 1 : n - 1;
     // every element of the tile is right of the diagonal and every pair inside the matrix: no masks
     const bool full = c0 > rlast && c0 + SEG <= n;
     long long col[NCH];
@@ -1824,12 +1832,15 @@ __device__ __forceinline__ void st_factor_tile(double* __restrict__ M, long long
                 }
             };
             fetch(r0, va);
-            for (long long j0 = r0; j0 <= rlast; j0 += 2 * RW) {
-                fetch(j0 + RW, vb);  // (clamped past the strip)
+            for (long long j0 = r0;; j0 += 2 * RW) {
+                const bool more1 = j0 + RW <= rlast;
+                if (more1) fetch(j0 + RW, vb);
                 update(j0, va);
-                if (j0 + RW > rlast) break;
-                fetch(j0 + 2 * RW, va);
+                if (!more1) break;
+                const bool more2 = j0 + 2 * RW <= rlast;
+                if (more2) fetch(j0 + 2 * RW, va);
                 update(j0 + RW, vb);
+                if (!more2) break;
             }
             return;
         }
@@ -2010,6 +2021,159 @@ __global__ __launch_bounds__(256) void k_st_bwd_factor(double* __restrict__ M, l
     if (has_b) st_bwd_diag_block_pre(n, c0, qstrip, q, qpub, svc);
     else st_bwd_diag_block<true>(n, c0, blk, lds, qstrip, q, qpub, true);  // ragged last block, one half
     work();  // this block is solved and handed over: the CU joins the factor workers
+}
+
+// The same launch with a HELPER workgroup per block (as in k_st_fwd_helped) and no dedicated factor workers: 2 * nblk
+// workgroups, one per CU.  helper s: the strip's partial sums over the row blocks nblk-1 .. s+2, handed to chain s
+// (qhpart, all-sentinel at launch); chain s: own block parked, columns and the rows of row block s+1 in registers before
+// block s+1's values come out.  Factor tiles are SMALL here (FQ_H = 16 rows x SEG columns, ~10 us of work) and every
+// workgroup pulls them whenever it has nothing else to do: a chain workgroup BEFORE its turn (it stops when block
+// s + FQ_STOP is solved -- one tile and the 6 us of fetching and parking fit in the remaining steps) and after it, a
+// helper after its last row block.  So nearly all of the chain workgroups' CU time goes to the factor update instead
+// of waiting, and the chain itself has nothing in front of it when its turn comes.
+constexpr int FQ_H = 16;
+constexpr long long FQ_STOP = 6;
+template <int SEG, int RW>
+__global__ __launch_bounds__(256) void k_st_bwd_factor_helped(double* __restrict__ M, long long ld, long long n,
+                                                              double* __restrict__ q, double* __restrict__ qpub,
+                                                              double* __restrict__ qhpart, int* __restrict__ err,
+                                                              const DevState* __restrict__ st, long long nblk,
+                                                              const double* __restrict__ beta2,
+                                                              const double* __restrict__ w,
+                                                              const int* __restrict__ ftiles, int nftiles,
+                                                              int* __restrict__ fnext, long long fq_stop) {
+    if (!st->apply) return;
+    __shared__ double lds[ST_LDS_DOUBLES_B];
+    __shared__ double part[4][SPANEL];
+    __shared__ double qstrip[SPANEL];
+    __shared__ double qblk[SB];
+    __shared__ int ok, ftile;
+    const int lane = threadIdx.x & 63;
+    const int wv = threadIdx.x >> 6;
+    const long long sblk = nblk - 1 - (long long)(blockIdx.x >> 1);
+    const bool chain = (blockIdx.x & 1) != 0;
+    const long long c0 = sblk * SB;
+    const long long c = c0 + 2 * lane;  // columns c, c+1 < c0 + 128 <= J0 of every row block applied here
+    const bool has_b = c0 + SH < n;
+
+    // factor tiles until the queue is empty or (deadline >= 0) block `deadline` has been solved
+    auto work = [&](long long deadline) __attribute__((always_inline)) {
+        for (;;) {
+            if (threadIdx.x == 0) {
+                int stop = 0;
+                if (deadline >= 0) {
+                    const double v = __hip_atomic_load(qpub + deadline * SB, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    stop = (unsigned long long)__double_as_longlong(v) != ST_SENTINEL_BITS;
+                }
+                ftile = stop ? nftiles : atomicAdd(fnext, 1);
+            }
+            __syncthreads();
+            const int k = ftile;
+            __syncthreads();
+            if (k >= nftiles) break;
+            const int tl = ftiles[k];
+            st_factor_tile<SEG, RW, true, FQ_H>(M, ld, n, beta2, w, (long long)(tl >> 4), (long long)(tl & 0xf));
+        }
+    };
+    auto load_rows = [&](long long J0, double2_t (&sv)[2][16]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const long long r0 = J0 + 32 * wv + 16 * h;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                long long row = r0 + r;
+                if (row > n - 1) row = n - 1;
+                sv[h][r] = *reinterpret_cast<const double2_t*>(M + row * ld + c);
+            }
+        }
+    };
+    // row block J0's q (in qblk) applied to the strip's partial sums
+    auto apply_rows = [&](const double2_t (&sv)[2][16]) __attribute__((always_inline)) {
+        double p0 = 0.0, p1 = 0.0;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const double qj = qblk[32 * wv + 16 * h + r];  // 0 for rows beyond n
+                p0 += sv[h][r].x * qj;
+                p1 += sv[h][r].y * qj;
+            }
+        }
+        part[wv][2 * lane] = p0;
+        part[wv][2 * lane + 1] = p1;
+        __syncthreads();
+        if (threadIdx.x < SPANEL) {
+            const double s4 = ((part[0][threadIdx.x] + part[1][threadIdx.x]) + part[2][threadIdx.x]) +
+                              part[3][threadIdx.x];
+            qstrip[threadIdx.x] = qstrip[threadIdx.x] - s4;
+        }
+        __syncthreads();
+    };
+    // the 128 values of row block kb, polled (data-as-flag); false on time-out
+    auto wait_block = [&](long long kb) __attribute__((always_inline)) -> bool {
+        if (threadIdx.x < SB) {
+            double v = 0.0;
+            if (kb * SB + threadIdx.x < n && !st_poll_value(qpub + kb * SB + threadIdx.x, v)) ok = 0;
+            qblk[threadIdx.x] = v;
+        }
+        __syncthreads();
+        return ok != 0;
+    };
+
+    if (threadIdx.x < SPANEL) qstrip[threadIdx.x] = (c0 + threadIdx.x < n) ? q[c0 + threadIdx.x] : 0.0;
+    if (threadIdx.x == 0) ok = 1;
+    __syncthreads();
+
+    if (!chain) {
+        // -------------------------------------------------------- helper: row blocks nblk-1 .. sblk+2, then factor tiles
+        double2_t sv[2][16];
+        for (long long kb = nblk - 1; kb >= sblk + 2; --kb) {
+            // Matrix on-die (n < 8192, SEG = 512): far from its hand-over the helper does not wait for a row block, it
+            // pulls factor tiles until the block is there (a tile in progress makes it late by a few us; it catches up at
+            // 1.6 us per step against the chain's 4-6): n = 4096 147.6 -> 139.5 us.  From HBM (n = 16384) the extra
+            // streaming slows the chain's hand-offs more than it helps: 783 -> 847 us (chain alone 515).
+            if (SEG == 512 && kb > sblk + 2 + fq_stop) work(kb);
+            load_rows(kb * SB, sv);
+            if (!wait_block(kb)) {
+                if (threadIdx.x == 0) atomicExch(err, 2);
+                return;
+            }
+            apply_rows(sv);
+        }
+        if (sblk + 2 <= nblk - 1 && threadIdx.x < SPANEL && c0 + threadIdx.x < n)
+            st_publish_store(qhpart + c0 + threadIdx.x, qstrip[threadIdx.x]);  // the value is its own flag
+        work(-1);
+        return;
+    }
+
+    // ------------------------------------------------------------ chain: factor tiles until block sblk + FQ_STOP is solved
+    if (sblk + fq_stop <= nblk - 1) work(sblk + fq_stop);
+    Blk3b blk;
+    double svc[SH];  // this wave's columns of the parked diagonal block
+    double2_t sv[2][16];
+    st_prefetch_block_bwd(M, ld, n, c0, blk);
+    if (sblk + 1 <= nblk - 1) load_rows((sblk + 1) * SB, sv);
+    st_park_piece(lds, blk.bb, threadIdx.x);
+    st_park_piece(lds + SH * BLK_PITCH, blk.ba, threadIdx.x);
+    st_park_piece(lds + 2 * SH * BLK_PITCH, blk.aa, threadIdx.x);
+    __syncthreads();
+    if (has_b) st_bwd_diag_cols(lds, svc);
+    if (sblk + 2 <= nblk - 1 && threadIdx.x < SPANEL && c0 + threadIdx.x < n) {  // the helper's sums
+        double v = 0.0;
+        if (!st_poll_value(qhpart + c0 + threadIdx.x, v)) ok = 0;
+        qstrip[threadIdx.x] = v;
+    }
+    if (sblk + 1 <= nblk - 1) {
+        if (!wait_block(sblk + 1)) {
+            if (threadIdx.x == 0) atomicExch(err, 2);
+            return;
+        }
+        apply_rows(sv);
+    }
+    __syncthreads();
+    if (has_b) st_bwd_diag_block_pre(n, c0, qstrip, q, qpub, svc);
+    else st_bwd_diag_block<true>(n, c0, blk, lds, qstrip, q, qpub, true);  // ragged last block, one half
+    work(-1);  // this block is solved and handed over: the CU goes back to the factor tiles
 }
 
 }  // namespace ellhip

@@ -127,7 +127,9 @@ def test_default_solves_and_factor_update_equal_the_plain_kernels(gpu, monkeypat
     b = gpu.EllStable.new_with_matrix(1.0, f, np.zeros(n))
     monkeypatch.delenv("ELLHIP_STABLE_PERSIST")
     monkeypatch.setenv("ELLHIP_STABLE_FACTOR_ROWS", "1")
-    c = gpu.EllStable.new_with_matrix(1.0, f, np.zeros(n))   # persistent solves without helpers + the row-wise factor update
+    monkeypatch.setenv("ELLHIP_STABLE_BWD_HELPERS", "0")
+    # persistent solves without helpers, backward solve + row-wise factor update in one launch with dedicated workers
+    c = gpu.EllStable.new_with_matrix(1.0, f, np.zeros(n))
     rng = np.random.default_rng(13 * n)
     for i in range(8):
         gr = rng.standard_normal(n)
