@@ -113,12 +113,13 @@ def test_paired_persistent_solves_equal_per_block_launches(gpu, monkeypatch, n):
     assert np.array_equal(a.xc(), b.xc()) and np.array_equal(a.mq, b.mq)
 
 
-@pytest.mark.parametrize("n", [2, 63, 64, 65, 129, 300, 513, 1000, 2048, 2048 + 128, 2049])
+@pytest.mark.parametrize("n", [2, 63, 64, 65, 129, 300, 513, 1000, 2048, 2048 + 128, 2049, 8192, 8200, 8191])
 def test_default_solves_and_factor_update_equal_the_plain_kernels(gpu, monkeypatch, n):
     """The default EllStable path -- forward solve with a helper workgroup per block (k_st_fwd_helped) and the factor
     update computed from U alone (k_st_factor_rows: the scratch entry it would read IS fl(U * w)) -- must give the bits
     of the plain path: one launch per block, factor update reading the scratch triangle through LDS transposes.  Odd and
-    even n, ragged last blocks, one block, a failing cut in the middle."""
+    even n, ragged last blocks, one block, a failing cut in the middle; 8191 / 8192 / 8200 straddle the size where the
+    factor tiles switch from 512- to 2048-column segments and the chain workgroups stop pulling tiles before their turn."""
     f = random_factor(n, 271 + n)
     a = gpu.EllStable.new_with_matrix(1.0, f, np.zeros(n))
     monkeypatch.setenv("ELLHIP_STABLE_HELPERS", "0")
