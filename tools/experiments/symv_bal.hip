@@ -22,13 +22,14 @@ struct BalCtl {
     int ncu;
     unsigned exited;
     int nlist;
-    int cnt[BAL_MAXL];          // next item of list c
+    int cnt[BAL_MAXL * 32];     // next item of list c, one 128-byte line each (c * 32): the start-up atomics of 1280
+                                // workgroups on 8 shared lines cost ~50 us
     int len[BAL_MAXL];
     int items[BAL_MAXL][BAL_MAXI];  // strip << 8 | segment
 };
 
-template <int RW, int SEG>
-__global__ __launch_bounds__(256) void k_symv_bal(const double* __restrict__ Q, long long ld, long long n,
+template <int RW, int SEG, bool STAMP = false>
+__global__ __launch_bounds__(256, RW == 2 ? 5 : 4) void k_symv_bal(const double* __restrict__ Q, long long ld, long long n,
                                                   const double* __restrict__ g, double* __restrict__ rowpart,
                                                   double* __restrict__ colpart, BalCtl* __restrict__ ctl,
                                                   unsigned long long* stamps) {
@@ -63,7 +64,7 @@ __global__ __launch_bounds__(256) void k_symv_bal(const double* __restrict__ Q, 
         if (threadIdx.x == 0) {
             int item = -1;
             if (victim < nlist) {
-                const int k = atomicAdd(&ctl->cnt[victim], 1);
+                const int k = atomicAdd(&ctl->cnt[victim * 32], 1);
                 if (k < ctl->len[victim]) item = ctl->items[victim][k];
             }
             s_item = item;
@@ -78,7 +79,7 @@ __global__ __launch_bounds__(256) void k_symv_bal(const double* __restrict__ Q, 
                 for (int base = 0; base < nlist && found < 0; base += 64) {
                     const int c = (((mine < nlist ? mine : 0) + 1 + base + (int)threadIdx.x) % nlist);
                     const bool has = (base + (int)threadIdx.x < nlist) &&
-                                     __hip_atomic_load(&ctl->cnt[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < ctl->len[c];
+                                     __hip_atomic_load(&ctl->cnt[c * 32], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < ctl->len[c];
                     const unsigned long long m = __ballot(has);
                     if (m) found = (((mine < nlist ? mine : 0) + 1 + base + (int)__builtin_ctzll(m)) % nlist);
                 }
@@ -91,9 +92,9 @@ __global__ __launch_bounds__(256) void k_symv_bal(const double* __restrict__ Q, 
             continue;
         }
         unsigned long long t0 = 0;
-        if (stamps && threadIdx.x == 0) t0 = wall_clock64();
+        if (STAMP && threadIdx.x == 0) t0 = wall_clock64();
         symv_tile<RW, true, 0, SEG, false>(Q, ld, n, 0, n, g, rowpart, colpart, (long long)(item >> 8), (long long)(item & 0xff), red);
-        if (stamps && threadIdx.x == 0) {
+        if (STAMP && threadIdx.x == 0) {
             const int slot = (item >> 8) * 16 + (item & 0xff);
             stamps[3 * slot] = t0; stamps[3 * slot + 1] = wall_clock64(); stamps[3 * slot + 2] = (unsigned long long)(mine < nlist ? mine : 999);
         }
@@ -102,7 +103,7 @@ __global__ __launch_bounds__(256) void k_symv_bal(const double* __restrict__ Q, 
     if (threadIdx.x == 0) {
         const unsigned e = atomicAdd(&ctl->exited, 1u);
         if (e == gridDim.x - 1) {  // last one out re-arms the lists
-            for (int c = 0; c < nlist; ++c) __hip_atomic_store(&ctl->cnt[c], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int c = 0; c < nlist; ++c) __hip_atomic_store(&ctl->cnt[c * 32], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(&ctl->exited, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
@@ -149,18 +150,37 @@ int main(int argc, char** argv) {
             for (long long r = r0; r < std::min<long long>(r0 + SYMV_H, n); ++r) el += (double)std::max<long long>(0, std::min<long long>(SEG, r - c0 + 2));
             tiles.push_back({(I << 8) | J, el / (64.0 * SEG) + fixed});
         }
-    std::sort(tiles.begin(), tiles.end(), [](const T& a, const T& b) { return a.cost > b.cost; });
+    const int listmode = argc > 3 ? atoi(argv[3]) : 0;
     static BalCtl h;
     memset(&h, 0, sizeof(h));
     for (auto& v : h.cu_of) v = -1;
     h.nlist = ncu;
     std::vector<double> load(ncu, 0.0);
-    for (auto& t : tiles) {
-        int best = 0;
-        for (int c = 1; c < ncu; ++c) if (load[c] < load[best]) best = c;
-        if (h.len[best] >= BAL_MAXI) { printf("list overflow\n"); return 1; }
-        h.items[best][h.len[best]++] = t.item;
-        load[best] += t.cost;
+    auto lpt = [&](std::vector<T> v) {
+        std::sort(v.begin(), v.end(), [](const T& a, const T& b) { return a.cost > b.cost; });
+        for (auto& t : v) {
+            int best = 0;
+            for (int c = 1; c < ncu; ++c) if (load[c] < load[best]) best = c;
+            if (h.len[best] >= BAL_MAXI) { printf("list overflow\n"); exit(1); }
+            h.items[best][h.len[best]++] = t.item;
+            load[best] += t.cost;
+        }
+    };
+    if (listmode == 0) {
+        lpt(tiles);
+    } else {
+        // locality first: the FULL tiles in (strip descending, segment ascending) order, dealt in runs -- a CU gets
+        // consecutive segments of one strip (the same 64 rows: the same pages) -- then the diagonal tiles by LPT
+        std::vector<T> full, diag;
+        for (auto& t : tiles) (t.cost >= 1.0 + fixed - 1e-9 ? full : diag).push_back(t);
+        std::sort(full.begin(), full.end(), [](const T& a, const T& b) { const int ia = a.item >> 8, ib = b.item >> 8; return ia != ib ? ia > ib : (a.item & 0xff) < (b.item & 0xff); });
+        const double per = (double)full.size() / ncu;
+        for (size_t k = 0; k < full.size(); ++k) {
+            const int c = std::min(ncu - 1, (int)(k / per));
+            h.items[c][h.len[c]++] = full[k].item;
+            load[c] += full[k].cost;
+        }
+        lpt(diag);
     }
     printf("%zu tiles; per-CU load min %.3f max %.3f full tiles, list lengths %d..%d\n", tiles.size(), *std::min_element(load.begin(), load.end()),
            *std::max_element(load.begin(), load.end()), *std::min_element(h.len, h.len + ncu), *std::max_element(h.len, h.len + ncu));
@@ -179,7 +199,7 @@ int main(int argc, char** argv) {
     };
     for (int rep = 0; rep < 1; ++rep) {
         timeit("k_symv static 2-D grid (production)", [&]() { hipLaunchKernelGGL((k_symv_plain<2, SEG>), dim3(nstrips, nsegs), dim3(256), 0, 0, Q, ld, n, g, rp, cp); });
-        for (int w : {occ, occ - 1, occ - 2})
+        for (int w : {occ + 1, occ, occ - 1, occ - 2})
             if (w >= 2) {
                 char name[96]; snprintf(name, sizeof(name), "k_symv_bal RW2, %d workgroups per CU", w);
                 timeit(name, [&]() { hipLaunchKernelGGL((k_symv_bal<2, SEG>), dim3(ncu * w), dim3(256), 0, 0, Q, ld, n, g, rp2, cp2, ctl, (unsigned long long*)nullptr); });
@@ -196,7 +216,7 @@ int main(int argc, char** argv) {
     }
     // same outputs?
     CK(hipMemset(rp2, 0, nrp * 8)); CK(hipMemset(cp2, 0, ncp * 8));
-    hipLaunchKernelGGL((k_symv_bal<2, SEG>), dim3(ncu * occ), dim3(256), 0, 0, Q, ld, n, g, rp2, cp2, ctl, stamps);
+    hipLaunchKernelGGL((k_symv_bal<2, SEG, true>), dim3(ncu * occ), dim3(256), 0, 0, Q, ld, n, g, rp2, cp2, ctl, stamps);
     CK(hipDeviceSynchronize());
     std::vector<double> a(nrp), b(nrp), c(ncp), d(ncp);
     CK(hipMemcpy(a.data(), rp, nrp * 8, hipMemcpyDeviceToHost)); CK(hipMemcpy(b.data(), rp2, nrp * 8, hipMemcpyDeviceToHost));
