@@ -577,8 +577,8 @@ def main() -> None:
                                                           nccl_id=ids[0], symmetric=shard_sym,
                                                           defer_depth=depth if shard_sym else 8)
                 sharded_via = "c-abi (RCCL inside libellhip.so)"
-            except pkg.capi.EllHipError as e:
-                log(f"[rank {rank}] C-ABI sharded space unavailable ({e}); falling back to torch.distributed")
+            except (pkg.capi.EllHipError, RuntimeError, OSError) as e:
+                log(f"[rank {rank}] C-ABI sharded space unavailable ({type(e).__name__}: {e}); falling back to torch.distributed")
                 space = None
         if space is None:
             from ellalgo_rs_amd.sharded import ShardedEll
