@@ -1034,16 +1034,17 @@ __global__ __launch_bounds__(256) void k_scalar_dot_def(long long n, const doubl
 // GY: the partial sums' column 0 (g . y) does not exist yet (k_sweep_gemv_dots produced the other columns beside the
 // GEMV that produced y): every workgroup forms the scalar_groups(n) slice sums itself, in k_scalar_dot_def's shape, and
 // they enter the reduction below exactly where the stored column would -- the same bits either way.
-template <int NP, bool GY = false>
-__global__ __launch_bounds__(256) void k_scalar_apply_def(long long n, const double* __restrict__ y,
-                                                          double* __restrict__ xc, double* __restrict__ pend,
-                                                          double* __restrict__ cpend,
-                                                          const double* __restrict__ partial,
-                                                          DevState* __restrict__ st, EllCalcDev calc,
-                                                          const CutParams* __restrict__ cp_dev, CutParams cp_val,
-                                                          int slot, int queue_mode, int* __restrict__ q_status,
-                                                          double* __restrict__ q_tsq, int npart,
-                                                          const double* __restrict__ g_own) {
+// (the body of the kernel, for workgroup `wg` of the stage: also run by the last workgroups of k_update_fused_def)
+template <int NP, bool GY>
+__device__ __forceinline__ void scalar_apply_def_body(const long long wg, long long n, const double* __restrict__ y,
+                                                      double* __restrict__ xc, double* __restrict__ pend,
+                                                      double* __restrict__ cpend,
+                                                      const double* __restrict__ partial,
+                                                      DevState* __restrict__ st, EllCalcDev calc,
+                                                      const CutParams* __restrict__ cp_dev, CutParams cp_val,
+                                                      int slot, int queue_mode, int* __restrict__ q_status,
+                                                      double* __restrict__ q_tsq, int npart,
+                                                      const double* __restrict__ g_own) {
     // npart = number of partial-sum rows: scalar_groups(n) after k_scalar_dot_def, ceil(n / 128) after k_symv_reduce<NP>
     // `slot` = number of updates already pending = index of the (all-zero) slot this cut records into.
     // The host passes it: it equals the device's count as long as the queue has not halted, and a halted
@@ -1052,7 +1053,7 @@ __global__ __launch_bounds__(256) void k_scalar_apply_def(long long n, const dou
     __shared__ double bc_cd[NP];
     __shared__ int bc_status;
     const int tid = threadIdx.x;
-    const bool lead = blockIdx.x == 0;
+    const bool lead = wg == 0;
     if (st->halted_in) {
         if (lead && tid == 0 && q_status) {
             *q_status = ST_UNKNOWN;
@@ -1073,7 +1074,7 @@ __global__ __launch_bounds__(256) void k_scalar_apply_def(long long n, const dou
     // the coefficient stage run (up to 4 elements per thread: slices are 1024 long up to n = 65536).
     constexpr int EPT = 4;
     const long long m_sl = scalar_slice(n);
-    const long long lo_sl = (long long)blockIdx.x * m_sl;
+    const long long lo_sl = wg * m_sl;
     const long long hi_sl = (lo_sl + m_sl < n) ? lo_sl + m_sl : n;
     const bool pre = m_sl <= 256 * EPT;
     double py[EPT], px[EPT], pp[EPT][NP];
@@ -1219,6 +1220,20 @@ __global__ __launch_bounds__(256) void k_scalar_apply_def(long long n, const dou
     }
 }
 
+template <int NP, bool GY = false>
+__global__ __launch_bounds__(256) void k_scalar_apply_def(long long n, const double* __restrict__ y,
+                                                          double* __restrict__ xc, double* __restrict__ pend,
+                                                          double* __restrict__ cpend,
+                                                          const double* __restrict__ partial,
+                                                          DevState* __restrict__ st, EllCalcDev calc,
+                                                          const CutParams* __restrict__ cp_dev, CutParams cp_val,
+                                                          int slot, int queue_mode, int* __restrict__ q_status,
+                                                          double* __restrict__ q_tsq, int npart,
+                                                          const double* __restrict__ g_own) {
+    scalar_apply_def_body<NP, GY>((long long)blockIdx.x, n, y, xc, pend, cpend, partial, st, calc, cp_dev, cp_val, slot,
+                                  queue_mode, q_status, q_tsq, npart, g_own);
+}
+
 // Full-row GEMV pass of the deferred schedule (handles without the lower-triangle schedule: n < 8192, odd n) with
 // the scalar stage's v_j . g dot products computed BESIDE it: the grid has scalar_groups(n) extra workgroups behind
 // the row tiles; extra workgroup b does for slice b exactly what k_scalar_dot_def does for columns 1..NP (same thread
@@ -1267,6 +1282,107 @@ __global__ __launch_bounds__(256) void k_sweep_gemv_dots(const double* Q, long l
     if (row_base >= nrows) return;
     sweep_rows<RW, UNR, VEC, NT, false, true, false>(Q, const_cast<double*>(Q), ld, n, nrows, row0, row_base, nullptr, gvec,
                                                      gv_out, 0.0, 1.0, reinterpret_cast<double(*)[RW]>(&red[0][0]));
+}
+
+// ONE launch per update on the recorded full-row schedule (unsharded handle, depth 8, n < 8192 or odd n): the GEMV
+// pass of k_sweep_gemv_dots AND the scalar stage k_scalar_apply_def<NP, true> -- `Ell::update_core` (src/ell.rs:97-137)
+// up to the recorded shrink in a single kernel, as SURVEY section 7's k_ell_fused asks.  The row tiles run first (lower
+// block indices); the last scalar_groups(n) workgroups form the v_j . g partial sums beside them exactly as before, then
+// wait until every workgroup of the launch has ARRIVED (one counter that only grows: `target` = launches so far x grid
+// size; arrival = barrier, agent-scope release fence by one thread, atomic add; the waiters poll with one lane, then an
+// acquire fence) and run the scalar stage's body on the fresh y.  Nobody else waits, so the grid need not be resident
+// (a workgroup waits only for workgroups dispatched before it), and the wait is bounded (DevState.solve_err = 7).
+// Same code on the same data in the same order as the two launches: identical bits.  What it saves is the second
+// launch's latency on the update's dependency chain: n = 4096 24.6 + 11.5 us -> see DESIGN.md section 5.1.
+constexpr int FUSED_WAIT_ERR = 7;
+template <int RW, int UNR, int VEC, bool NT, int NP>
+__global__ __launch_bounds__(256) void k_update_fused_def(const double* Q, long long ld, long long n, long long nrows,
+                                                          long long row0, const double* __restrict__ gvec,
+                                                          double* __restrict__ gv_out, DevState* __restrict__ st,
+                                                          int reverse, unsigned ntiles, double* __restrict__ pend,
+                                                          double* __restrict__ partial, double* __restrict__ xc,
+                                                          double* __restrict__ cpend, EllCalcDev calc,
+                                                          const CutParams* __restrict__ cp_dev, CutParams cp_val, int slot,
+                                                          int queue_mode, int* __restrict__ q_status,
+                                                          double* __restrict__ q_tsq, unsigned* __restrict__ arrived,
+                                                          unsigned target) {
+    __shared__ double red[4][RW > NP ? RW : NP];
+    __shared__ int wait_ok;
+    const int halted = st->halted;
+    const int tid = threadIdx.x;
+    if (blockIdx.x >= ntiles) {
+        const long long b = (long long)blockIdx.x - ntiles;
+        if (b == 0 && tid == 0) {  // (write-through, like everything a waiter reads after the arrivals)
+            __hip_atomic_store(&st->halted_in, halted, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&st->kappa_in, st->kappa, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (!halted) {
+            const long long m = scalar_slice(n);
+            const long long lo = b * m;
+            const long long hi = (lo + m < n) ? lo + m : n;
+            double sd[NP];
+#pragma unroll
+            for (int j = 0; j < NP; ++j) sd[j] = 0.0;
+            for (long long i = lo + tid; i < hi; i += 256) {
+                const double gi = gvec[i];
+#pragma unroll
+                for (int j = 0; j < NP; ++j) sd[j] += pend[(long long)j * n + i] * gi;
+            }
+#pragma unroll
+            for (int j = 0; j < NP; ++j) {
+                const double w = wave_allreduce_sum(sd[j]);
+                if ((tid & 63) == 0) red[tid >> 6][j] = w;
+            }
+            __syncthreads();
+            if (tid < NP)
+                __hip_atomic_store(&partial[b * (NP + 1) + 1 + tid], ((red[0][tid] + red[1][tid]) + red[2][tid]) + red[3][tid],
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the write-through stores above have landed
+        __syncthreads();
+        if (tid == 0) {
+            atomicAdd(arrived, 1u);
+            int ok = 0;
+            for (int spin = 0; spin < (1 << 22); ++spin) {
+                const unsigned a = __hip_atomic_load(arrived, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((int)(a - target) >= 0) {
+                    ok = 1;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(4);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // y and the partial sums of the others
+            if (!ok) atomicExch(&st->solve_err, FUSED_WAIT_ERR);
+            wait_ok = ok;
+        }
+        __syncthreads();
+        if (!wait_ok) return;
+        scalar_apply_def_body<NP, true>(b, n, gv_out - row0, xc, pend, cpend, partial, st, calc, cp_dev, cp_val, slot,
+                                        queue_mode, q_status, q_tsq, (int)scalar_groups(n), gvec);
+        return;
+    }
+    if (!halted) {
+        const long long tile = reverse ? (long long)ntiles - 1 - blockIdx.x : (long long)blockIdx.x;
+        const long long row_base = tile * RW;
+        if (row_base < nrows)
+            sweep_rows<RW, UNR, VEC, NT, false, true, false>(Q, const_cast<double*>(Q), ld, n, nrows, row0, row_base, nullptr,
+                                                             gvec, gv_out, 0.0, 1.0,
+                                                             reinterpret_cast<double(*)[RW]>(&red[0][0]));
+    }
+    // The tile's rows of y once more, WRITE-THROUGH (sweep_rows stored them with plain stores; its wave sums are still in
+    // `red`): a release fence here would write back the XCD's whole L2 in every one of the ~500 tile workgroups (measured:
+    // 69 us per launch instead of 25 + 12).
+    if (!halted && tid < RW) {
+        const long long tile = reverse ? (long long)ntiles - 1 - blockIdx.x : (long long)blockIdx.x;
+        const long long r = tile * RW + tid;
+        double(*rr)[RW] = reinterpret_cast<double(*)[RW]>(&red[0][0]);  // sweep_rows' view of the buffer
+        if (r < nrows)
+            __hip_atomic_store(&gv_out[r], ((rr[0][tid] + rr[1][tid]) + rr[2][tid]) + rr[3][tid], __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) atomicAdd(arrived, 1u);
 }
 
 constexpr long long SCALAR_SPLIT_N = 8192;

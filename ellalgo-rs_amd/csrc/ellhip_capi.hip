@@ -81,6 +81,15 @@ struct ellhip_space {
     double* d_gt[2] = {nullptr, nullptr};      // buffers in use (own or caller's)
     double* d_work = nullptr;        // EllStable vectors: w, z, gg, q, beta2
     double* d_hpart = nullptr;       // EllStable forward solve with helper workgroups: the helpers' hand-over buffer (n)
+    // one launch per update on the recorded full-row schedule (k_update_fused_def): a prime that is immediately followed
+    // by its cut is not launched by itself (lazy_prime), the cut launches GEMV + scalar stage together
+    int fused_update = 0;            // ELLHIP_FUSED_UPDATE (experimental, slower: see alloc_common)
+    bool allow_lazy = false;         // set by the callers that issue prime and cut back to back (queue runs, ellhip_update)
+    bool lazy_prime = false;         // the GEMV of lazy_g into slot lazy_slot has NOT been launched yet
+    const double* lazy_g = nullptr;
+    int lazy_slot = 0;
+    unsigned* d_arrived = nullptr;   // arrival counter of k_update_fused_def (only grows)
+    unsigned fused_target = 0;       // its value once every workgroup of the launches so far has arrived
     int stable_helpers = 1;          // k_st_fwd_helped when 2 * ceil(n/128) workgroups are resident at once
     int stable_factor_rows = 1;      // factor update from U alone (k_st_factor_rows); 0: the tile kernel that reads the scratch
     int stable_fused = 1;            // backward solve + factor update in one launch (k_st_bwd_factor)
@@ -339,6 +348,37 @@ int launch_gemv_dots(ellhip_space* s, const double* gvec, double* gv_out) {
     s->dots_np = 8;
     s->dots_need_gy = true;
     return 0;
+}
+
+// GEMV + dot products + scalar stage in ONE launch (k_update_fused_def): the cut's parameters are known at launch time.
+template <int VEC, bool NT>
+int launch_update_fused_t(ellhip_space* s, const Shape& sh, const double* gvec, double* gv_out, const CutParams* cp_dev,
+                          CutParams cp_val, int queue_mode, int* qst, double* qtsq) {
+    const long long nr = s->nrows;
+    const unsigned ntiles = (unsigned)((nr + sh.rw - 1) / sh.rw);
+    const unsigned grid = ntiles + (unsigned)scalar_groups(s->n);
+    EllCalcDev calc = EllCalcDev::make(s->n, s->use_parallel_cut);
+    s->fused_target += grid;
+#define FUSED_CASE(RW, UNR)                                                                                         \
+    if (sh.rw == RW && sh.unr == UNR) {                                                                             \
+        hipLaunchKernelGGL((k_update_fused_def<RW, UNR, VEC, NT, 8>), dim3(grid), dim3(256), 0, s->stream,           \
+                           (const double*)s->d_Q, s->ld, s->n, nr, s->row0, gvec, gv_out + s->row0, s->d_st, s->dir, \
+                           ntiles, s->d_pend, s->d_partial, s->d_xc, s->d_cpend, calc, cp_dev, cp_val, s->npend,     \
+                           queue_mode, qst, qtsq, s->d_arrived, s->fused_target);                                    \
+        return 0;                                                                                                   \
+    }
+    FUSED_CASE(1, 4) FUSED_CASE(1, 8) FUSED_CASE(2, 4) FUSED_CASE(2, 8) FUSED_CASE(4, 2) FUSED_CASE(4, 4)
+    FUSED_CASE(8, 1) FUSED_CASE(8, 2)
+#undef FUSED_CASE
+    s->fused_target -= grid;
+    return fail(ELLHIP_E_INVALID, "unsupported RW/UNR launch shape (supported: 1x4 1x8 2x4 2x8 4x2 4x4 8x1 8x2)");
+}
+
+bool deferring(const ellhip_space* s);
+// the schedule k_update_fused_def serves: what do_prime would hand to launch_gemv_dots
+bool fused_update_ok(const ellhip_space* s) {
+    return s->fused_update && s->d_arrived && deferring(s) && s->defer == 8 && !s->sharded && s->fuse_dots && s->n <= 8192 &&
+           s->d_pend && s->d_partial;
 }
 
 // Deferred mode is in force for Ell with depth > 1, except while the reference semantics need Q itself
@@ -701,6 +741,12 @@ int do_prime(ellhip_space* s, const double* g_dev, int slot) {
     if (symv_ok(s)) return launch_symv(s, g_dev, s->d_gt[slot]);
     if (s->shard_symmetric)
         return fail(ELLHIP_E_STATE, "symmetric row shard: only the deferred (depth 8) schedule is available");
+    if (s->allow_lazy && fused_update_ok(s)) {  // the caller cuts this very gradient next: one launch for both (do_cut)
+        s->lazy_prime = true;
+        s->lazy_g = g_dev;
+        s->lazy_slot = slot;
+        return 0;
+    }
     ProfScope ps(s, CLS_GEMV);
     // deferred depth 8 on full rows (no lower-triangle schedule at this size): the dot products ride along.  Up to
     // n = 8192 only: every workgroup of the scalar stage re-forms g.y from all of g and y, which stops paying beyond.
@@ -716,6 +762,30 @@ int do_cut(ellhip_space* s, const double* g_dev, const CutParams* cp_dev, CutPar
     // The dot products a prime left in d_partial belong to THIS cut only: whatever path the cut takes (also the
     // non-deferred one, after a depth switch between prime and cut) they are spent now, and a gradient primed later
     // by a fused pass (rank-1 + GEMV, apply + GEMV) has none.
+    if (s->lazy_prime) {
+        // the GEMV of this gradient was held back by do_prime: GEMV pass + scalar stage in one launch
+        s->lazy_prime = false;
+        if (g_dev != s->lazy_g || s->lazy_slot != s->cur || !fused_update_ok(s)) {
+            // (cannot happen with the callers that set allow_lazy; be safe: do what do_prime would have done)
+            int rc = launch_gemv_dots(s, s->lazy_g, s->d_gt[s->lazy_slot]);
+            if (rc) return rc;
+        } else {
+            ProfScope ps(s, CLS_GEMV);
+            const bool even = (s->n % 2) == 0;
+            const bool nt = even && s->sh_gemv.nt;
+            double* out = s->d_gt[s->cur];
+            int rc = !even ? launch_update_fused_t<1, false>(s, s->sh_gemv, g_dev, out, cp_dev, cp_val, queue_mode, qst, qtsq)
+                           : (nt ? launch_update_fused_t<2, true>(s, s->sh_gemv, g_dev, out, cp_dev, cp_val, queue_mode, qst, qtsq)
+                                 : launch_update_fused_t<2, false>(s, s->sh_gemv, g_dev, out, cp_dev, cp_val, queue_mode, qst, qtsq));
+            if (rc) return rc;
+            HIPCHK(hipGetLastError());
+            s->dir ^= 1;
+            s->dots_np = 0;
+            s->dots_need_gy = false;
+            s->npend += 1;
+            return 0;
+        }
+    }
     const int dots_np_now = s->dots_np;
     s->dots_np = 0;
     ProfScope ps(s, CLS_SCALAR);
@@ -809,6 +879,7 @@ int read_back(ellhip_space* s) {
         (void)hipStreamSynchronize(s->stream);
         s->stable_persist = 0;
         s->symv_tail = 0;
+        s->fused_update = 0;
         return fail(ELLHIP_E_HIP, "a bounded in-launch wait timed out (EllStable persistent solve / k_symv_tail); this handle now "
                                   "uses the forms without inter-workgroup waits");
     }
@@ -911,6 +982,13 @@ int alloc_common(ellhip_space* s) {
     // lower-triangle GEMV's reduction produces them
     HIPCHK(hipMalloc(&s->d_partial, (size_t)std::max<long long>(64, (n + 127) / 128) * (MAXPEND + 1) * sizeof(double)));
     if (s->variant == ELLHIP_SPACE_ELL) {
+        // off by default: measured at n = 4096, the launch takes 40.1 us against 25.0 + 14.1 us for the two it replaces
+        // (the scalar stage's own dependency chain, not the launch, is what costs), and the queue loses the apply + GEMV
+        // pass of every 8th cut: 22 800 against 25 400 updates/s
+        s->fused_update = env_int("ELLHIP_FUSED_UPDATE", 0);
+        HIPCHK(hipMalloc(&s->d_arrived, sizeof(unsigned)));
+        HIPCHK(hipMemsetAsync(s->d_arrived, 0, sizeof(unsigned), s->stream));
+        s->fused_target = 0;
         HIPCHK(hipMalloc(&s->d_pend, (size_t)MAXPEND * vbytes));
         HIPCHK(hipMalloc(&s->d_cpend, MAXPEND * sizeof(double)));
         HIPCHK(hipMemsetAsync(s->d_pend, 0, (size_t)MAXPEND * vbytes, s->stream));
@@ -1246,6 +1324,7 @@ void ellhip_destroy(ellhip_space* s) {
     }
     if (s->d_work) (void)hipFree(s->d_work);
     if (s->d_hpart) (void)hipFree(s->d_hpart);
+    if (s->d_arrived) (void)hipFree(s->d_arrived);
     if (s->d_ftiles) (void)hipFree(s->d_ftiles);
     if (s->d_fnext) (void)hipFree(s->d_fnext);
     if (s->d_ftiles16) (void)hipFree(s->d_ftiles16);
@@ -1457,9 +1536,12 @@ int ellhip_update_end(ellhip_space* s) {
 }
 
 int ellhip_update(ellhip_space* s, int kind, const double* grad, double beta0, int has_beta1, double beta1) {
+    if (s) s->allow_lazy = true;  // begin and end back to back: GEMV + scalar stage in one launch where there is one
     int rc = ellhip_update_begin(s, kind, grad, beta0, has_beta1, beta1);
-    if (rc) return rc;
-    return ellhip_update_end(s);
+    if (!rc) rc = ellhip_update_end(s);
+    else if (s) s->lazy_prime = false;
+    if (s) s->allow_lazy = false;
+    return rc;
 }
 
 namespace {
@@ -1694,8 +1776,11 @@ int ellhip_queue_run(ellhip_space* s, int64_t first, int64_t count) {
     if (!s || first < 0 || count < 0 || first + count > s->qk) return fail(ELLHIP_E_INVALID, "queue range");
     DeviceGuard guard(s->device);
     for (int64_t i = first; i < first + count; ++i) {
+        s->allow_lazy = true;  // prime and cut back to back: one launch where the schedule has one (k_update_fused_def)
         int rc = queue_prime_impl(s, i);
         if (!rc) rc = queue_cut_impl(s, i);
+        s->allow_lazy = false;
+        s->lazy_prime = false;
         if (!rc) rc = queue_commit_impl(s, i, -1);
         if (rc) return rc;
     }
@@ -1706,9 +1791,16 @@ int ellhip_queue_run_fused(ellhip_space* s, int64_t first, int64_t count) {
     if (!s || first < 0 || count < 0 || first + count > s->qk) return fail(ELLHIP_E_INVALID, "queue range");
     DeviceGuard guard(s->device);
     for (int64_t i = first; i < first + count; ++i) {
-        int rc = queue_prime_impl(s, i);  // only the first cut of a run pays a separate GEMV pass
+        // Where one launch does GEMV + scalar stage (k_update_fused_def: recorded full-row schedule) nothing is gained by
+        // priming the next gradient inside this cut's commit -- there is no rank-1 pass to share -- so the cut is issued
+        // as in ellhip_queue_run; elsewhere the commit carries the next GEMV.
+        const bool one_launch = fused_update_ok(s) && !(s->primed && s->primed_qindex == i);
+        s->allow_lazy = one_launch;
+        int rc = queue_prime_impl(s, i);  // (pipelined form: only the first cut of a run pays a separate GEMV pass)
         if (!rc) rc = queue_cut_impl(s, i);
-        if (!rc) rc = queue_commit_impl(s, i, (i + 1 < s->qk) ? i + 1 : -1);
+        s->allow_lazy = false;
+        s->lazy_prime = false;
+        if (!rc) rc = queue_commit_impl(s, i, (!one_launch && i + 1 < s->qk) ? i + 1 : -1);
         if (rc) return rc;
     }
     return 0;

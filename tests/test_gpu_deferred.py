@@ -428,3 +428,36 @@ def test_depth_switches_between_prime_and_cut_do_not_leak_dot_products(gpu, orc,
     assert int(e.cut(0, (0.01, None))) == o.update(0, gs[5], 0.01) == 0
     e.commit(None)
     assert_state_close(e, o, what=f"n={n} depth {depth}")
+
+
+@pytest.mark.parametrize("n", [5, 130, 257, 1000, 4096])
+def test_one_launch_update_equals_the_two_launches(gpu, monkeypatch, n):
+    """ELLHIP_FUSED_UPDATE=1 (off by default: slower): GEMV pass + dot products + scalar stage of a
+    cut in ONE launch (k_update_fused_def, the scalar stage's workgroups wait in-launch for the row tiles) must give
+    the bits of the two launches -- direct updates, the two-pass queue and the pipelined queue, with a failing cut."""
+    from ellalgo_rs_amd import synth
+    k = 21
+    kinds, grads, b0, b1 = synth.parallel_cuts(n, k)
+    b0 = b0.copy()
+    b0[13] = 1e6   # fails: NoSoln halts the queues there
+
+    def build(flag):
+        monkeypatch.setenv("ELLHIP_FUSED_UPDATE", flag)
+        s = gpu.Ell.new_with_scalar(1.0, np.linspace(-1.0, 1.0, n))
+        s.defer_depth = 8
+        return s
+
+    ref, direct, twopass, piped = build("0"), build("1"), build("1"), build("1")
+    monkeypatch.delenv("ELLHIP_FUSED_UPDATE")
+    for i in range(13):
+        cut = (grads[i], (b0[i], b1[i]))
+        assert int(ref._update(int(kinds[i]), cut)) == int(direct._update(int(kinds[i]), cut)) == 0
+        assert ref.tsq() == direct.tsq() and ref.kappa == direct.kappa
+    for s, fused in ((twopass, False), (piped, True)):
+        s.queue_upload(kinds, grads, b0, b1)
+        s.queue_run(0, k, fused=fused)
+        st, _ = s.queue_results()
+        assert list(st[:14]) == [0] * 13 + [1]
+    for s in (direct, twopass, piped):
+        assert np.array_equal(s.xc(), ref.xc()) and s.kappa == ref.kappa
+        assert np.array_equal(s.mq, ref.mq)
