@@ -439,7 +439,9 @@ __global__ __launch_bounds__(256) void k_symv(const double* __restrict__ Q, long
 // and workgroup 0 takes the halted / kappa snapshots k_scalar_dot_def would have taken.
 // The reduction of one block of 128 columns (blk) -- the body of k_symv_reduce.  HANDOFF: the partial sums were written
 // by other workgroups of THIS launch (k_symv_tail): they are read with agent-scope loads.
-template <int NP, bool HANDOFF>
+// WT: y and the partial dot products are stored write-through (agent scope): other workgroups of the SAME launch read
+// them after an in-launch wait (k_symv_reduce_scalar).
+template <int NP, bool HANDOFF, bool WT = false>
 __device__ __forceinline__ void symv_reduce_block(long long blk, long long n, long long row0, long long nrows,
                                                   long long seg, const double* __restrict__ rowpart,
                                                   const double* __restrict__ colpart, double* __restrict__ y,
@@ -527,7 +529,8 @@ __device__ __forceinline__ void symv_reduce_block(long long blk, long long n, lo
         const double2_t c0 = part[0][lane], c1 = part[1][lane], c2 = part[2][lane], c3 = part[3][lane];
         r.x += ((c0.x + c1.x) + c2.x) + c3.x;
         r.y += ((c0.y + c1.y) + c2.y) + c3.y;
-        *reinterpret_cast<double2_t*>(y + i) = r;
+        if constexpr (WT) ho_store2(y + i, r);
+        else *reinterpret_cast<double2_t*>(y + i) = r;
         if (NP > 0) yv = r;
     }
     if (NP > 0) {
@@ -536,7 +539,10 @@ __device__ __forceinline__ void symv_reduce_block(long long blk, long long n, lo
             double sgy = gi.x * yv.x;
             sgy += gi.y * yv.y;
             sgy = wave_allreduce_sum(sgy);
-            if (lane == 0) out[0] = sgy;
+            if (lane == 0) {
+                if constexpr (WT) ho_store(out, sgy);
+                else out[0] = sgy;
+            }
         }
 #pragma unroll
         for (int k = 0; k < NPW; ++k) {
@@ -544,7 +550,10 @@ __device__ __forceinline__ void symv_reduce_block(long long blk, long long n, lo
             double sv = pv[k].x * gi.x;
             sv += pv[k].y * gi.y;
             sv = wave_allreduce_sum(sv);
-            if (lane == 0 && j < NP) out[1 + j] = sv;
+            if (lane == 0 && j < NP) {
+                if constexpr (WT) ho_store(out + 1 + j, sv);
+                else out[1 + j] = sv;
+            }
         }
     }
 }
@@ -1036,7 +1045,8 @@ __global__ __launch_bounds__(256) void k_scalar_dot_def(long long n, const doubl
 // they enter the reduction below exactly where the stored column would -- the same bits either way.
 // (the body of the kernel, for workgroup `wg` of the stage: also run by the last workgroups of k_update_fused_def)
 template <int NP, bool GY>
-__device__ __forceinline__ void scalar_apply_def_body(const long long wg, long long n, const double* __restrict__ y,
+__device__ __forceinline__ void scalar_apply_def_body(const long long wg, const long long lo_sl, const long long hi_sl,
+                                                      long long n, const double* __restrict__ y,
                                                       double* __restrict__ xc, double* __restrict__ pend,
                                                       double* __restrict__ cpend,
                                                       const double* __restrict__ partial,
@@ -1073,10 +1083,8 @@ __device__ __forceinline__ void scalar_apply_def_body(const long long wg, long l
     // The slice's operands do not depend on the coefficients: request them now, so that they arrive while the sums and
     // the coefficient stage run (up to 4 elements per thread: slices are 1024 long up to n = 65536).
     constexpr int EPT = 4;
-    const long long m_sl = scalar_slice(n);
-    const long long lo_sl = wg * m_sl;
-    const long long hi_sl = (lo_sl + m_sl < n) ? lo_sl + m_sl : n;
-    const bool pre = m_sl <= 256 * EPT;
+    // [lo_sl, hi_sl): the elements this workgroup updates (its slice of scalar_slice(n) elements in the stand-alone stage)
+    const bool pre = hi_sl - lo_sl <= 256 * EPT;
     double py[EPT], px[EPT], pp[EPT][NP];
     if (pre) {
 #pragma unroll
@@ -1230,8 +1238,9 @@ __global__ __launch_bounds__(256) void k_scalar_apply_def(long long n, const dou
                                                           int slot, int queue_mode, int* __restrict__ q_status,
                                                           double* __restrict__ q_tsq, int npart,
                                                           const double* __restrict__ g_own) {
-    scalar_apply_def_body<NP, GY>((long long)blockIdx.x, n, y, xc, pend, cpend, partial, st, calc, cp_dev, cp_val, slot,
-                                  queue_mode, q_status, q_tsq, npart, g_own);
+    const long long m_sl = scalar_slice(n), lo_sl = (long long)blockIdx.x * m_sl;
+    scalar_apply_def_body<NP, GY>((long long)blockIdx.x, lo_sl, (lo_sl + m_sl < n) ? lo_sl + m_sl : n, n, y, xc, pend, cpend,
+                                  partial, st, calc, cp_dev, cp_val, slot, queue_mode, q_status, q_tsq, npart, g_own);
 }
 
 // Full-row GEMV pass of the deferred schedule (handles without the lower-triangle schedule: n < 8192, odd n) with
@@ -1357,8 +1366,10 @@ __global__ __launch_bounds__(256) void k_update_fused_def(const double* Q, long 
         }
         __syncthreads();
         if (!wait_ok) return;
-        scalar_apply_def_body<NP, true>(b, n, gv_out - row0, xc, pend, cpend, partial, st, calc, cp_dev, cp_val, slot,
-                                        queue_mode, q_status, q_tsq, (int)scalar_groups(n), gvec);
+        const long long m_sl = scalar_slice(n), lo_sl = b * m_sl;
+        scalar_apply_def_body<NP, true>(b, lo_sl, (lo_sl + m_sl < n) ? lo_sl + m_sl : n, n, gv_out - row0, xc, pend, cpend,
+                                        partial, st, calc, cp_dev, cp_val, slot, queue_mode, q_status, q_tsq,
+                                        (int)scalar_groups(n), gvec);
         return;
     }
     if (!halted) {
@@ -1383,6 +1394,56 @@ __global__ __launch_bounds__(256) void k_update_fused_def(const double* Q, long 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0) atomicAdd(arrived, 1u);
+}
+
+// k_symv_reduce<NP> AND the scalar stage in ONE launch (unsharded lower-triangle schedule): every workgroup reduces its
+// 128 columns of y and its share of the dot products (write-through), arrives, waits until all ceil(n/128) workgroups
+// have (they do the same amount of work and are all resident, so the wait is short; bounded), then forms omega / the
+// coefficients redundantly from the same partial sums in the same order as k_scalar_apply_def -- identical bits -- and
+// updates ITS OWN 128 elements (gt, the recorded vector, xc).  One launch and one kernel boundary fewer on the
+// update's dependency chain.
+template <int NP>
+__global__ __launch_bounds__(256) void k_symv_reduce_scalar(long long n, long long seg, const double* __restrict__ rowpart,
+                                                            const double* __restrict__ colpart, double* __restrict__ y,
+                                                            DevState* __restrict__ st, const double* __restrict__ g,
+                                                            double* __restrict__ pend, double* __restrict__ partial,
+                                                            double* __restrict__ xc, double* __restrict__ cpend,
+                                                            EllCalcDev calc, const CutParams* __restrict__ cp_dev,
+                                                            CutParams cp_val, int slot, int queue_mode,
+                                                            int* __restrict__ q_status, double* __restrict__ q_tsq,
+                                                            unsigned* __restrict__ arrived, unsigned target) {
+    __shared__ double2_t part[4][64];
+    __shared__ int wait_ok;
+    const int halted = st->halted;
+    const int tid = threadIdx.x;
+    if (blockIdx.x == 0 && tid == 0) {  // the snapshots the stage's body reads (its lead workgroup rewrites kappa / halted)
+        __hip_atomic_store(&st->halted_in, halted, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&st->kappa_in, st->kappa, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (!halted)
+        symv_reduce_block<NP, false, true>((long long)blockIdx.x, n, 0, n, seg, rowpart, colpart, y, g, pend, partial, part);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the write-through stores have landed
+    __syncthreads();
+    if (tid == 0) {
+        atomicAdd(arrived, 1u);
+        int ok = 0;
+        for (int spin = 0; spin < (1 << 22); ++spin) {
+            const unsigned a = __hip_atomic_load(arrived, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((int)(a - target) >= 0) {
+                ok = 1;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(2);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // the others' partial sums
+        if (!ok) atomicExch(&st->solve_err, FUSED_WAIT_ERR);
+        wait_ok = ok;
+    }
+    __syncthreads();
+    if (!wait_ok) return;
+    const long long lo = (long long)blockIdx.x * 128;
+    scalar_apply_def_body<NP, false>((long long)blockIdx.x, lo, (lo + 128 < n) ? lo + 128 : n, n, y, xc, pend, cpend, partial,
+                                     st, calc, cp_dev, cp_val, slot, queue_mode, q_status, q_tsq, (int)gridDim.x, nullptr);
 }
 
 constexpr long long SCALAR_SPLIT_N = 8192;

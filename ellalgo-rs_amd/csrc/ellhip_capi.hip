@@ -88,7 +88,13 @@ struct ellhip_space {
     bool lazy_prime = false;         // the GEMV of lazy_g into slot lazy_slot has NOT been launched yet
     const double* lazy_g = nullptr;
     int lazy_slot = 0;
-    unsigned* d_arrived = nullptr;   // arrival counter of k_update_fused_def (only grows)
+    // k_symv_reduce_scalar: the reduction of a lower-triangle GEMV is held back (lazy_reduce) when the gradient's cut
+    // follows at once, and launched together with the scalar stage by do_cut
+    int reduce_scalar = 0;           // ELLHIP_REDUCE_SCALAR (experimental, not faster: see alloc_common)
+    bool lazy_reduce = false;
+    const double* lazy_rg = nullptr; // the gradient whose tiles have run
+    double* lazy_ry = nullptr;       // where its y goes
+    unsigned* d_arrived = nullptr;   // arrival counter of k_update_fused_def / k_symv_reduce_scalar (only grows)
     unsigned fused_target = 0;       // its value once every workgroup of the launches so far has arrived
     int stable_helpers = 1;          // k_st_fwd_helped when 2 * ceil(n/128) workgroups are resident at once
     int stable_factor_rows = 1;      // factor update from U alone (k_st_factor_rows); 0: the tile kernel that reads the scratch
@@ -675,6 +681,20 @@ void symv_tail_go(ellhip_space* s, const double* g_dev, double* y_out, unsigned 
                            s->d_st, s->d_symv_ctl, nactive, pull_from);
 }
 
+int launch_symv_reduce(ellhip_space* s, const double* g_dev, double* y_out);
+bool deferring(const ellhip_space* s);
+// the schedule k_symv_reduce_scalar serves: unsharded lower-triangle GEMV whose reduction carries the dot products
+bool reduce_scalar_ok(const ellhip_space* s) {
+    return s->reduce_scalar && s->d_arrived && !s->sharded && s->fuse_dots && deferring(s) && (s->defer == 8 || s->defer == 16) &&
+           !s->symv_tail && (s->n + 127) / 128 <= 256;
+}
+// launch the reduction a lazy prime held back (somebody needs y, or the cut is not the one that was announced)
+int finish_lazy_reduce(ellhip_space* s) {
+    if (!s->lazy_reduce) return 0;
+    s->lazy_reduce = false;
+    return launch_symv_reduce(s, s->lazy_rg, s->lazy_ry);
+}
+
 int launch_symv(ellhip_space* s, const double* g_dev, double* y_out) {
     const int seg = s->symv_seg;
     if (!s->sharded && s->symv_tail && s->d_symv_ctl && seg == SYMV_SEG && (s->symv_rw == 2 || s->symv_rw == 4) &&
@@ -716,6 +736,19 @@ int launch_symv(ellhip_space* s, const double* g_dev, double* y_out) {
         }
         HIPCHK(hipGetLastError());
     }
+    if (s->allow_lazy && reduce_scalar_ok(s) && seg == s->symv_seg) {
+        // the caller cuts this gradient next: its reduction runs in the scalar stage's launch (do_cut)
+        s->lazy_reduce = true;
+        s->lazy_rg = g_dev;
+        s->lazy_ry = y_out;
+        return 0;
+    }
+    return launch_symv_reduce(s, g_dev, y_out);
+}
+
+// the reduction of the tiles launch_symv has issued (by itself: k_symv_reduce<NP>)
+int launch_symv_reduce(ellhip_space* s, const double* g_dev, double* y_out) {
+    const int seg = s->symv_seg;
     ProfScope ps(s, CLS_SYMV_REDUCE);
     // unsharded: the reduction also yields the scalar stage's dot products (a shard's y is partial until the owner's
     // all-reduce has run, so its dot products wait for k_scalar_dot_def)
@@ -762,6 +795,30 @@ int do_cut(ellhip_space* s, const double* g_dev, const CutParams* cp_dev, CutPar
     // The dot products a prime left in d_partial belong to THIS cut only: whatever path the cut takes (also the
     // non-deferred one, after a depth switch between prime and cut) they are spent now, and a gradient primed later
     // by a fused pass (rank-1 + GEMV, apply + GEMV) has none.
+    if (s->lazy_reduce) {
+        if (g_dev != s->lazy_rg || s->lazy_ry != s->d_gt[s->cur] || !reduce_scalar_ok(s)) {
+            int rc = finish_lazy_reduce(s);  // (cannot happen with the callers that set allow_lazy; be safe)
+            if (rc) return rc;
+        } else {
+            s->lazy_reduce = false;
+            ProfScope ps(s, CLS_SYMV_REDUCE);
+            EllCalcDev calc = EllCalcDev::make(s->n, s->use_parallel_cut);
+            const unsigned grid = (unsigned)((s->n + 127) / 128);
+            s->fused_target += grid;
+#define RS_GO(NPV)                                                                                                      \
+    hipLaunchKernelGGL(k_symv_reduce_scalar<NPV>, dim3(grid), dim3(256), 0, s->stream, s->n, (long long)s->symv_seg,      \
+                       (const double*)s->d_rowpart, (const double*)s->d_colpart, s->d_gt[s->cur], s->d_st, g_dev, s->d_pend, \
+                       s->d_partial, s->d_xc, s->d_cpend, calc, cp_dev, cp_val, s->npend, queue_mode, qst, qtsq,          \
+                       s->d_arrived, s->fused_target)
+            if (s->defer == 16) RS_GO(16); else RS_GO(8);
+#undef RS_GO
+            HIPCHK(hipGetLastError());
+            s->dots_np = 0;
+            s->dots_need_gy = false;
+            s->npend += 1;
+            return 0;
+        }
+    }
     if (s->lazy_prime) {
         // the GEMV of this gradient was held back by do_prime: GEMV pass + scalar stage in one launch
         s->lazy_prime = false;
@@ -880,6 +937,7 @@ int read_back(ellhip_space* s) {
         s->stable_persist = 0;
         s->symv_tail = 0;
         s->fused_update = 0;
+        s->reduce_scalar = 0;
         return fail(ELLHIP_E_HIP, "a bounded in-launch wait timed out (EllStable persistent solve / k_symv_tail); this handle now "
                                   "uses the forms without inter-workgroup waits");
     }
@@ -986,6 +1044,8 @@ int alloc_common(ellhip_space* s) {
         // (the scalar stage's own dependency chain, not the launch, is what costs), and the queue loses the apply + GEMV
         // pass of every 8th cut: 22 800 against 25 400 updates/s
         s->fused_update = env_int("ELLHIP_FUSED_UPDATE", 0);
+        // likewise off: k_symv_reduce_scalar takes 23.9 us against 11.4 + 12.3 us (n = 16384: 4190 against 4230 updates/s)
+        s->reduce_scalar = env_int("ELLHIP_REDUCE_SCALAR", 0);
         HIPCHK(hipMalloc(&s->d_arrived, sizeof(unsigned)));
         HIPCHK(hipMemsetAsync(s->d_arrived, 0, sizeof(unsigned), s->stream));
         s->fused_target = 0;
@@ -1540,7 +1600,13 @@ int ellhip_update(ellhip_space* s, int kind, const double* grad, double beta0, i
     int rc = ellhip_update_begin(s, kind, grad, beta0, has_beta1, beta1);
     if (!rc) rc = ellhip_update_end(s);
     else if (s) s->lazy_prime = false;
-    if (s) s->allow_lazy = false;
+    if (s) {
+        s->allow_lazy = false;
+        if (s->lazy_reduce) {
+            DeviceGuard guard(s->device);
+            (void)finish_lazy_reduce(s);
+        }
+    }
     return rc;
 }
 
@@ -1776,11 +1842,12 @@ int ellhip_queue_run(ellhip_space* s, int64_t first, int64_t count) {
     if (!s || first < 0 || count < 0 || first + count > s->qk) return fail(ELLHIP_E_INVALID, "queue range");
     DeviceGuard guard(s->device);
     for (int64_t i = first; i < first + count; ++i) {
-        s->allow_lazy = true;  // prime and cut back to back: one launch where the schedule has one (k_update_fused_def)
+        s->allow_lazy = true;  // prime and cut back to back: launches that can share one do (do_prime / launch_symv / do_cut)
         int rc = queue_prime_impl(s, i);
         if (!rc) rc = queue_cut_impl(s, i);
         s->allow_lazy = false;
         s->lazy_prime = false;
+        if (!rc) rc = finish_lazy_reduce(s);  // (only if the cut failed to take it)
         if (!rc) rc = queue_commit_impl(s, i, -1);
         if (rc) return rc;
     }
@@ -1795,15 +1862,20 @@ int ellhip_queue_run_fused(ellhip_space* s, int64_t first, int64_t count) {
         // priming the next gradient inside this cut's commit -- there is no rank-1 pass to share -- so the cut is issued
         // as in ellhip_queue_run; elsewhere the commit carries the next GEMV.
         const bool one_launch = fused_update_ok(s) && !(s->primed && s->primed_qindex == i);
-        s->allow_lazy = one_launch;
+        // (the lower-triangle GEMV the commit issues for the next cut leaves its reduction to that cut's scalar stage)
+        s->allow_lazy = one_launch || reduce_scalar_ok(s);
         int rc = queue_prime_impl(s, i);  // (pipelined form: only the first cut of a run pays a separate GEMV pass)
         if (!rc) rc = queue_cut_impl(s, i);
-        s->allow_lazy = false;
         s->lazy_prime = false;
+        if (!rc && i + 1 >= first + count) s->allow_lazy = false;  // the last commit of the run primes eagerly
         if (!rc) rc = queue_commit_impl(s, i, (!one_launch && i + 1 < s->qk) ? i + 1 : -1);
-        if (rc) return rc;
+        s->allow_lazy = false;
+        if (rc) {
+            (void)finish_lazy_reduce(s);
+            return rc;
+        }
     }
-    return 0;
+    return finish_lazy_reduce(s);
 }
 
 int ellhip_queue_results(ellhip_space* s, int32_t* status_out, double* tsq_out) {

@@ -461,3 +461,37 @@ def test_one_launch_update_equals_the_two_launches(gpu, monkeypatch, n):
     for s in (direct, twopass, piped):
         assert np.array_equal(s.xc(), ref.xc()) and s.kappa == ref.kappa
         assert np.array_equal(s.mq, ref.mq)
+
+
+@pytest.mark.parametrize("n,depth", [(1024, 8), (1024, 16), (2112, 16)])
+def test_reduction_inside_the_scalar_stage_launch_equals_the_two_launches(gpu, monkeypatch, n, depth):
+    """ELLHIP_REDUCE_SCALAR=1 (off by default: not faster): the reduction of the lower-triangle GEMV
+    and the scalar stage in ONE launch (k_symv_reduce_scalar; every workgroup waits in-launch for the others' partial
+    sums, then updates its own 128 elements) must give the bits of k_symv_reduce + k_scalar_apply_def."""
+    from ellalgo_rs_amd import synth
+    monkeypatch.setenv("ELLHIP_SYMV_MIN_N", "512")
+    k = 37
+    kinds, grads, b0, b1 = synth.parallel_cuts(n, k)
+    b0 = b0.copy()
+    b0[29] = 1e6   # fails: the queues halt there
+
+    def build(flag):
+        monkeypatch.setenv("ELLHIP_REDUCE_SCALAR", flag)
+        s = gpu.Ell.new_with_scalar(1.0, np.linspace(-1.0, 1.0, n))
+        s.defer_depth = depth
+        return s
+
+    ref, direct, twopass, piped = build("0"), build("1"), build("1"), build("1")
+    for i in range(29):
+        cut = (grads[i], (b0[i], b1[i]))
+        assert int(ref._update(int(kinds[i]), cut)) == int(direct._update(int(kinds[i]), cut)) == 0
+        assert ref.tsq() == direct.tsq() and ref.kappa == direct.kappa
+    for s, fused in ((twopass, False), (piped, True)):
+        s.queue_upload(kinds, grads, b0, b1)
+        s.queue_run(0, 11, fused=fused)
+        s.queue_run(11, k - 11, fused=fused)
+        st, _ = s.queue_results()
+        assert list(st[:30]) == [0] * 29 + [1]
+    for s in (direct, twopass, piped):
+        assert np.array_equal(s.xc(), ref.xc()) and s.kappa == ref.kappa
+        assert np.array_equal(s.mq, ref.mq)
