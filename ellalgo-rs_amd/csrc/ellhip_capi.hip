@@ -105,6 +105,7 @@ struct ellhip_space {
     int nftiles16 = 0;
     double* d_qhpart = nullptr;      // ... and the backward helpers' hand-over buffer (n)
     int stable_bwd_helpers = 1;
+    int exp_no_factor = 0, fq_stop_env = 0;  // ELLHIP_EXP_NO_FACTOR (measurement only), ELLHIP_STABLE_FQ_STOP; read at creation
     int nftiles = 0, fused_workers = 0;
     int persist_cap_h = 0;           // that limit (CU count x occupancy of k_st_fwd_helped)
     double* d_partial = nullptr;     // per-workgroup partial sums of omega (64)
@@ -547,13 +548,12 @@ int ellstable_issue(ellhip_space* s, const double* g_dev, const CutParams* cp_de
         if (fused_h) {
             const unsigned grid = (unsigned)(2 * nb);
             // (measurement only, results WRONG: ELLHIP_EXP_NO_FACTOR=1 leaves the factor tiles out to time the chain alone)
-            static const int no_factor = env_int("ELLHIP_EXP_NO_FACTOR", 0);
+            const int no_factor = s->exp_no_factor;
             const int nft = no_factor > 0 ? s->nftiles16 - s->nftiles16 / no_factor : s->nftiles16;  // 1: none, 2: half, ...
             // before their turn the chain workgroups pull factor tiles only when the matrix is on-die (n < 8192): from HBM
             // it made them late for their own block (n = 16384: stop distance 6 / 12 / 24 / 48+ blocks: 785 / 731 / 710 /
             // 685-695 us), on-die it pays (n = 4096: 139 us against 170 without)
-            static const int fq_env = env_int("ELLHIP_STABLE_FQ_STOP", 0);
-            const long long fq_stop = fq_env > 0 ? fq_env : (n >= 8192 ? nb + 1 : FQ_STOP);
+            const long long fq_stop = s->fq_stop_env > 0 ? s->fq_stop_env : (n >= 8192 ? nb + 1 : FQ_STOP);
             if (n >= 8192)
                 hipLaunchKernelGGL((k_st_bwd_factor_helped<2048, 8>), dim3(grid), dim3(256), 0, st, s->d_Q, ld, n, q, qpub,
                                    s->d_qhpart, err, (const DevState*)s->d_st, nb, (const double*)beta2, (const double*)w,
@@ -1102,6 +1102,8 @@ int alloc_common(ellhip_space* s) {
             s->fused_workers = (int)std::max<long long>(0, std::min<long long>(s->persist_cap1 - nbk, s->nftiles));
             s->fused_workers = env_int("ELLHIP_STABLE_WORKERS", s->fused_workers);
             s->stable_bwd_helpers = env_int("ELLHIP_STABLE_BWD_HELPERS", 1);
+            s->exp_no_factor = env_int("ELLHIP_EXP_NO_FACTOR", 0);
+            s->fq_stop_env = env_int("ELLHIP_STABLE_FQ_STOP", 0);
             {   // 16-row tiles of k_st_bwd_factor_helped
                 std::vector<int> f16, e16;
                 const long long ngrp = (n + FQ_H - 1) / FQ_H;
