@@ -412,6 +412,116 @@ def cpu_baseline(n: int, variant: str, kinds, grads, b0, b1, budget_s: float = 2
     }
 
 
+def ell_bytes_per_update(n2w: float, sched: str, dep: int, steps: int, symv_mode: bool, lower_apply: bool, sharded: bool = False):
+    """Algorithmic bytes ONE update moves per GPU-share under a schedule / depth IN A TIMED REGION OF `steps` UPDATES
+    that starts and ends with nothing recorded (bench.py flushes on both sides), and the model's description.  A
+    deferred schedule runs ceil(steps / depth) apply passes inside such a region -- 20 steps at depth 16 hold two -- so
+    the per-update figure depends on the region; it tends to the steady-state one for steps >> depth."""
+    if dep == 1:
+        if sched == "pipelined":
+            return 16.0 * n2w, "16*n^2 B/update (rank-1 pass of cut k fused with the GEMV of cut k+1)"
+        return 24.0 * n2w, "24*n^2 B/update (GEMV pass 8 + rank-1 pass 16; SURVEY 8d)"
+    passes = -(-steps // dep)
+    if symv_mode and lower_apply:
+        per = 4.0 + 8.0 * passes / steps
+        return per * n2w, (f"{per:g}*n^2 B/update = ({steps} lower-triangle GEMV passes of 4*n^2 + {passes} lower-triangle apply "
+                           f"passes of 8*n^2) / {steps} updates (deferred shrink, depth {dep}; steady state {4.0 + 8.0 / dep:g}*n^2; "
+                           "the upper triangle is mirrored back only when Q itself is read" +
+                           ("; per GPU 1/P of that: symmetric row shards of equal trapezoid area, one all-reduce of the "
+                            "n-vector per update)" if sharded else ")"))
+    if symv_mode:
+        per = 4.0 + 16.0 * passes / steps
+        return per * n2w, (f"{per:g}*n^2 B/update = ({steps} lower-triangle GEMV passes of 4*n^2 + {passes} full apply passes "
+                           f"of 16*n^2) / {steps} updates (deferred shrink, depth {dep})")
+    if sched == "pipelined":
+        per = 8.0 + 8.0 * passes / steps
+        return per * n2w, (f"{per:g}*n^2 B/update = ({steps} read-only GEMV passes of 8*n^2, {passes} of them carrying an apply "
+                           f"pass: +8*n^2 written) / {steps} updates (deferred shrink, depth {dep})")
+    per = 8.0 + 16.0 * passes / steps
+    return per * n2w, (f"{per:g}*n^2 B/update = ({steps} read-only GEMV passes of 8*n^2 + {passes} apply passes of 16*n^2) / "
+                       f"{steps} updates (deferred shrink, depth {dep})")
+
+
+# the BASELINE.json configurations besides the headline one, with the brief (steps, warmup, profile steps) they are run
+# at inside the default invocation so that the driver's one line carries all of them
+BRIEF_CONFIGS = [("n4096-deep", 200, 20, 40), ("n32768-deep", 64, 16, 16), ("n16384-ellstable", 48, 8, 16)]
+
+
+def brief_config(pkg, synth, torch, workload: str, K: int, W: int, P: int, device: int) -> dict:
+    """One BASELINE configuration, timed like the headline run (device-resident queue, pipelined schedule, the depth a
+    new handle of that size starts with; recorded updates flushed on both sides of the timed region), reduced to the
+    figures `other_configs` carries."""
+    n, variant, cutgen, desc = WORKLOADS[workload]
+    t_gen = time.perf_counter()
+    kinds, grads, b0, b1 = (synth.parallel_cuts if cutgen == "parallel" else synth.deep_cuts)(n, W + K + P)
+    if variant == "ell":
+        space = pkg.Ell.new_with_scalar(1.0, np.zeros(n), device=device)
+        depth = space.defer_depth
+    else:
+        space = pkg.EllStable.new_with_matrix(1.0, synth.stable_factor(n), np.zeros(n), device=device)
+        depth = 1
+    log(f"[other-configs] {workload}: inputs ready in {time.perf_counter() - t_gen:.1f}s (depth {depth})")
+    fused = variant == "ell"
+    space.queue_upload(kinds, grads, b0, b1)
+    del grads
+    space.queue_run(0, W, fused=fused)
+    if variant == "ell":
+        space.flush()
+    torch.cuda.synchronize()
+    space.synchronize()
+    t0 = time.perf_counter()
+    space.queue_run(W, K, fused=fused)
+    if variant == "ell":
+        space.flush()
+    space.synchronize()
+    elapsed = time.perf_counter() - t0
+    space.profile_enable(True)
+    space.queue_run(W + K, P, fused=fused)
+    space.synchronize()
+    prof = space.profile_read()
+    space.profile_enable(False)
+    status, _ = space.queue_results()
+    if not bool(np.all(status == 0)):
+        raise SystemExit(f"{workload}: cut {int(np.argmax(status != 0))} did not succeed: benchmark invalid")
+    n2 = float(n) * float(n)
+    opt = pkg.capi.default_option
+    symv_mode = variant == "ell" and n % 2 == 0 and n >= opt(pkg.capi.OPT_SYMV_MIN_N) and opt(pkg.capi.OPT_SYMV) != 0
+    lower_apply = symv_mode and opt(pkg.capi.OPT_APPLY_LOWER) != 0
+    alg = {"gemv": 8.0 * n2, "rank1": 16.0 * n2, "fused": 16.0 * n2, "apply": (8.0 if lower_apply else 16.0) * n2,
+           "apply_gemv": 16.0 * n2, "symv": 4.0 * n2, "stable_fwd": 8.0 * n2, "stable_bwd": 4.0 * n2, "stable_factor": 12.0 * n2}
+    if variant != "ell":
+        fb = 8.0 if space.get_option(pkg.capi.OPT_STABLE_FACTOR) != 0 else 12.0
+        alg["stable_factor"] = fb * n2
+        if prof.get("stable_factor", (0.0, 0))[1] == 0:   # pulled inside the backward solve's launch
+            alg["stable_bwd"] = (4.0 + fb) * n2
+        bytes_update, model = (12.0 + fb) * n2, f"{12.0 + fb:g}*n^2 B per update (EllStable: fwd 8 + bwd 4 + factor {fb:g})"
+    else:
+        bytes_update, model = ell_bytes_per_update(n2, "pipelined", depth, K, symv_mode, lower_apply)
+    per_kernel = {}
+    for name, (ms, cnt) in prof.items():
+        if cnt:
+            e = {"avg_ms": ms / cnt, "launches": cnt}
+            if name in alg:
+                e["alg_bytes"] = alg[name]
+                e["GBps"] = alg[name] / (e["avg_ms"] * 1e-3) / 1e9
+            per_kernel[name] = e
+    cands = [k for k in per_kernel if k in alg]
+    key = (lambda k: per_kernel[k]["avg_ms"] * per_kernel[k]["launches"]) if variant == "ell" else (lambda k: per_kernel[k]["avg_ms"])
+    dom = max(cands, key=key) if cands else None
+    ms_per_step = elapsed / K * 1e3
+    upd_gbps = bytes_update / (ms_per_step * 1e-3) / 1e9
+    roofline = {"whole_update": {"alg_bytes": bytes_update, "GBps": upd_gbps, "frac": upd_gbps / HBM_PEAK_GBS, "byte_model": model}}
+    if dom:
+        kname = {"symv": "k_symv", "apply": "k_apply_lower", "gemv": "k_sweep_gemv_dots"}.get(dom, dom)
+        roofline.update({"kernel": kname if variant == "ell" else "k_st_" + dom[7:], "achieved": per_kernel[dom]["GBps"],
+                         "frac": per_kernel[dom]["GBps"] / HBM_PEAK_GBS, "avg_launch_ms": per_kernel[dom]["avg_ms"],
+                         "alg_bytes_per_launch": per_kernel[dom]["alg_bytes"]})
+    roofline["per_kernel"] = per_kernel
+    del space
+    return {"workload": workload, "description": desc, "updates_per_s": K / elapsed, "ms_per_step": ms_per_step, "steps": K,
+            "warmup": W, "defer_depth": depth, "schedule": "pipelined" if variant == "ell" else "ellstable", "roofline": roofline}
+
+
 def main() -> None:
     # The contract is ONE JSON line on stdout.  Native libraries (RCCL prints a version banner) write to
     # fd 1 directly, so park the real stdout and point fd 1 at stderr for the rest of the run.
@@ -443,6 +553,9 @@ def main() -> None:
                     help="extra timed steps for each OTHER schedule / depth, reported alongside (0 = skip)")
     ap.add_argument("--force-sharded", action="store_true",
                     help="run the row-partitioned (multi-GPU) code path even with one rank (rehearsal)")
+    ap.add_argument("--other-configs", choices=["auto", "on", "off"], default="auto",
+                    help="after the headline run, time the other BASELINE.json configurations briefly in the same process and "
+                         "report them as `other_configs` (auto: with the default workload on one GPU)")
     ap.add_argument("--all-configs", action="store_true",
                     help="run every BASELINE.json configuration that has a one-GPU form, one after the other (n4096-deep, "
                          "n16384-parallel, n32768-deep, n16384-ellstable), each as its own process with the same "
@@ -514,10 +627,12 @@ def main() -> None:
     H = args.host_path_steps if not multi else 0
     fused = args.schedule == "pipelined" and variant == "ell"
     depth = args.defer if variant == "ell" else 1
+    opt = pkg.capi.default_option
+    symv_min_n = opt(pkg.capi.OPT_SYMV_MIN_N)
+    lower_ok = n % 2 == 0 and opt(pkg.capi.OPT_SYMV) != 0 and opt(pkg.capi.OPT_APPLY_LOWER) != 0
     if depth == 0:  # auto: 16 pending updates per apply pass where the lower-triangle schedule runs, else 8
-        lower_ok = n % 2 == 0 and os.environ.get("ELLHIP_SYMV", "1") != "0" and os.environ.get("ELLHIP_APPLY_LOWER", "1") != "0"
         if not sharded:
-            depth = 16 if (lower_ok and n >= int(os.environ.get("ELLHIP_SYMV_MIN_N", "8192"))) else 8
+            depth = 16 if (lower_ok and n >= symv_min_n) else 8
         else:
             sym = (n % 64 == 0 and n // 64 >= world and (float(n) * n / 2 / world) / (64 * 2048) >= 200
                    and os.environ.get("ELLHIP_SHARD_SYMMETRIC", "1") != "0")
@@ -538,7 +653,7 @@ def main() -> None:
     alts = []
     if C2 > 0:
         for alt in (("pipelined", 16), ("pipelined", 8), ("pipelined", 1), ("two-pass", 8), ("two-pass", 1)):
-            if alt[1] == 16 and (sharded or n % 2 or n < int(os.environ.get("ELLHIP_SYMV_MIN_N", "8192"))):
+            if alt[1] == 16 and (sharded or not lower_ok or n < symv_min_n):
                 continue  # depth 16 exists on the lower-triangle schedule only
             if alt != (args.schedule, depth):
                 alts.append(alt)
@@ -570,16 +685,35 @@ def main() -> None:
         space = None
         if os.environ.get("ELLHIP_BENCH_SHARDED", "abi") == "abi":
             from ellalgo_rs_amd import sharded_abi
-            try:
-                ids = [sharded_abi.unique_id() if rank == 0 else None]
-                dist.broadcast_object_list(ids, src=0)
-                space = pkg.ShardedEllAbi.new_with_scalar(1.0, np.zeros(n), device=local_rank, rank=rank, nranks=world,
-                                                          nccl_id=ids[0], symmetric=shard_sym,
-                                                          defer_depth=depth if shard_sym else 8)
+            # The choice between the C-ABI space and the torch.distributed fallback is COLLECTIVE: rank 0 always
+            # broadcasts (the id, or None if RCCL could not be opened), every rank then tries to create its handle and the
+            # ranks agree (all-reduce MIN of an ok flag) -- a rank that failed alone must not leave the others inside
+            # RCCL collectives it never joins.
+            ids = [None]
+            if rank == 0:
+                try:
+                    ids[0] = sharded_abi.unique_id()
+                except (pkg.capi.EllHipError, RuntimeError, OSError) as e:
+                    log(f"[rank 0] ellhip_sharded_unique_id failed ({type(e).__name__}: {e})")
+            dist.broadcast_object_list(ids, src=0)
+            ok_local = 0
+            if ids[0] is not None:
+                try:
+                    space = pkg.ShardedEllAbi.new_with_scalar(1.0, np.zeros(n), device=local_rank, rank=rank, nranks=world,
+                                                              nccl_id=ids[0], symmetric=shard_sym,
+                                                              defer_depth=depth if shard_sym else 8)
+                    ok_local = 1
+                except (pkg.capi.EllHipError, RuntimeError, OSError) as e:
+                    log(f"[rank {rank}] C-ABI sharded space unavailable ({type(e).__name__}: {e})")
+            flag = torch.tensor([ok_local], dtype=torch.int32, device="cuda")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 1:
                 sharded_via = "c-abi (RCCL inside libellhip.so)"
-            except (pkg.capi.EllHipError, RuntimeError, OSError) as e:
-                log(f"[rank {rank}] C-ABI sharded space unavailable ({type(e).__name__}: {e}); falling back to torch.distributed")
+            else:
+                if space is not None:
+                    del space
                 space = None
+                log(f"[rank {rank}] falling back to torch.distributed collectives on every rank")
         if space is None:
             from ellalgo_rs_amd.sharded import ShardedEll
             space = ShardedEll.new_with_scalar(1.0, np.zeros(n), device=local_rank, symmetric=shard_sym,
@@ -697,9 +831,8 @@ def main() -> None:
     ms_per_step = elapsed / K * 1e3
     value = K / elapsed * (world if replicas else 1)  # replicas: every rank completed K updates of its own
     # algorithmic bytes per launch of each kernel class (per GPU)
-    symv_mode = ((not sharded) and n % 2 == 0 and n >= int(os.environ.get("ELLHIP_SYMV_MIN_N", "8192"))
-                 and os.environ.get("ELLHIP_SYMV", "1") != "0") or shard_sym
-    lower_apply = symv_mode and os.environ.get("ELLHIP_APPLY_LOWER", "1") != "0"
+    symv_mode = ((not sharded) and n % 2 == 0 and n >= symv_min_n and opt(pkg.capi.OPT_SYMV) != 0) or shard_sym
+    lower_apply = symv_mode and opt(pkg.capi.OPT_APPLY_LOWER) != 0
     alg = {"gemv": 8.0 * n2w, "rank1": 16.0 * n2w, "fused": 16.0 * n2w, "apply": (8.0 if lower_apply else 16.0) * n2w,
            "apply_gemv": 16.0 * n2w, "symv": 4.0 * n2w,
            "stable_fwd": 8.0 * n * n, "stable_bwd": 4.0 * n * n, "stable_factor": 12.0 * n * n}
@@ -707,31 +840,13 @@ def main() -> None:
         # EllStable: the factor update rewrites the strict upper triangle from itself (8*n^2; the scratch entry the
         # reference adds IS fl(U*w)) unless the scratch-reading tile kernel is forced; and it runs
         # inside the backward solve's launch (k_st_bwd_factor) when no separate factor launch shows up in the profile
-        rows = os.environ.get("ELLHIP_STABLE_FACTOR_ROWS", "1") != "0"
+        rows = space.get_option(pkg.capi.OPT_STABLE_FACTOR) != 0
         alg["stable_factor"] = (8.0 if rows else 12.0) * n * n
         if prof and prof.get("stable_factor", (0.0, 0))[1] == 0:
             alg["stable_bwd"] = 4.0 * n * n + alg["stable_factor"]
 
-    def byte_model(sched, dep):
-        """algorithmic bytes ONE update moves per GPU-share under a schedule / depth, and its description"""
-        if dep == 1:
-            if sched == "pipelined":
-                return 16.0 * n2w, "16*n^2 B/update (rank-1 pass of cut k fused with the GEMV of cut k+1)"
-            return 24.0 * n2w, "24*n^2 B/update (GEMV pass 8 + rank-1 pass 16; SURVEY 8d)"
-        if symv_mode and lower_apply:
-            return (4.0 + 8.0 / dep) * n2w, (f"{4.0 + 8.0 / dep:g}*n^2 B/update (deferred shrink, depth {dep}: one lower-triangle "
-                               f"GEMV pass of 4*n^2 per update + one lower-triangle apply pass of 8*n^2 per {dep} updates; the "
-                               "upper triangle is mirrored back only when Q itself is read" +
-                               ("; per GPU 1/P of that: symmetric row shards of equal trapezoid area, one all-reduce "
-                                "of the n-vector per update)" if sharded else ")"))
-        if symv_mode:
-            return 6.0 * n2w, ("6*n^2 B/update (deferred shrink, depth 8, unsharded: eight lower-triangle GEMV passes of "
-                               "4*n^2 + one apply pass of 16*n^2 per 8 updates)")
-        if sched == "pipelined":
-            return 9.0 * n2w, ("9*n^2 B/update (deferred shrink, depth 8: seven read-only GEMV passes of 8*n^2 + one "
-                               "apply+GEMV pass of 16*n^2 per 8 updates)")
-        return 10.0 * n2w, ("10*n^2 B/update (deferred shrink, depth 8: eight read-only GEMV passes of 8*n^2 + one "
-                            "apply pass of 16*n^2 per 8 updates)")
+    def byte_model(sched, dep, steps):
+        return ell_bytes_per_update(n2w, sched, dep, steps, symv_mode, lower_apply, sharded)
 
     def kernel_table(pr):
         tab = {}
@@ -752,7 +867,7 @@ def main() -> None:
         fb = alg["stable_factor"] / (n * n)
         bytes_update, model = (12.0 + fb) * n * n, f"{12.0 + fb:g}*n^2 B per update (EllStable: fwd 8 + bwd 4 + factor {fb:g})"
     else:
-        bytes_update, model = byte_model("pipelined" if fused else "two-pass", depth)
+        bytes_update, model = byte_model("pipelined" if fused else "two-pass", depth, K)
     roofline = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None, "byte_model": model}
     if variant == "ell":
         # dominant = the kernel class with the largest total time in the profiled steps
@@ -773,6 +888,9 @@ def main() -> None:
         if pmc and world == 1 and dom:
             roofline["traffic"] = pmc.get(dom)
             roofline["traffic_source"] = pmc.get("source")
+            # the figure comes from separate rocprofv3 --pmc passes of the same command (profiles/), not from this run:
+            # what THIS run measured live is the per-kernel HIP-event table below (`per_kernel`)
+            roofline["traffic_measured_in_this_run"] = False
     except OSError:
         pass
     upd_gbps = bytes_update / (ms_per_step * 1e-3) / 1e9
@@ -782,7 +900,7 @@ def main() -> None:
     if "achieved" not in roofline:
         roofline.update({"kernel": "whole_update", "achieved": upd_gbps, "frac": upd_gbps / HBM_PEAK_GBS})
     for o in others:
-        ob, omodel = byte_model(o["schedule"], o["defer_depth"])
+        ob, omodel = byte_model(o["schedule"], o["defer_depth"], o["steps"])
         og = ob / (o["ms_per_step"] * 1e-3) / 1e9
         o["byte_model"] = omodel
         o["whole_update"] = {"alg_bytes_per_gpu": ob, "GBps_per_gpu": og, "frac": og / HBM_PEAK_GBS}
@@ -820,6 +938,12 @@ def main() -> None:
     if world == 1 and not args.no_cpu_baseline:
         log("[rank 0] timing the CPU oracle (bounded sample) ...")
         out["cpu_baseline"] = cpu_baseline(n, variant, kinds, grads, b0, b1, args.cpu_budget)
+    want_others = args.other_configs == "on" or (args.other_configs == "auto" and args.workload == "n16384-parallel")
+    if world == 1 and not args.force_sharded and want_others:
+        # BASELINE.json's other configurations (2, 4 in its one-GPU form, 5), briefly, on the same process and GPU
+        del space, grads
+        out["other_configs"] = [brief_config(pkg, synth, torch, wl, k, w, pr, local_rank) for (wl, k, w, pr) in BRIEF_CONFIGS
+                                if wl != args.workload]
     print(json.dumps(out), file=real_stdout, flush=True)
     if multi:
         dist.barrier()

@@ -17,6 +17,9 @@ SHARD_EQUAL_BLOCKS, SHARD_SYMMETRIC = 0, 1
 NCCL_ID_BYTES = 128
 E_INVALID, E_HIP, E_NODEVICE, E_NOMEM, E_STATE = -1, -2, -3, -4, -5
 NKERNEL_CLASSES = 13
+# option keys (include/ellhip.h, "options")
+(OPT_AUTO_DEFER, OPT_SYMV, OPT_SYMV_MIN_N, OPT_APPLY_LOWER, OPT_APPLY_KERNEL, OPT_FUSE_DOTS, OPT_STABLE_SOLVE,
+ OPT_STABLE_FACTOR, OPT_PAD, OPT_LP_GRID, OPT_LP_WIDE, OPT_BATCH_THREADS) = range(1, 13)
 KERNEL_CLASS_NAMES = ("gemv", "scalar", "rank1", "stable_fwd", "stable_bwd", "stable_factor", "fused", "apply",
                       "apply_gemv", "symv", "symv_reduce", "lp_scan", "lp_final")
 
@@ -30,6 +33,7 @@ EXPORTS = [
     "ellhip_queue_prime", "ellhip_queue_cut", "ellhip_queue_commit", "ellhip_queue_results", "ellhip_set_stream",
     "ellhip_synchronize", "ellhip_profile_enable", "ellhip_profile_read", "ellhip_device_count",
     "ellhip_last_error", "ellhip_version",
+    "ellhip_set_option", "ellhip_get_option", "ellhip_set_default_option", "ellhip_default_option",
     # include/ellhip_lowpass.h
     "ellhip_lowpass_create", "ellhip_lowpass_destroy", "ellhip_lowpass_assess_feas", "ellhip_lowpass_assess_optim",
     "ellhip_lowpass_state", "ellhip_lowpass_rows_visited", "ellhip_lowpass_get_spectrum", "ellhip_lowpass_optim", "ellhip_lowpass_feas",
@@ -47,6 +51,7 @@ EXPORTS = [
     "ellhip_sharded_set_xc", "ellhip_sharded_get_mq_rows", "ellhip_sharded_set_defer_depth", "ellhip_sharded_flush",
     "ellhip_sharded_queue_upload", "ellhip_sharded_queue_run", "ellhip_sharded_queue_run_fused",
     "ellhip_sharded_queue_results", "ellhip_sharded_synchronize", "ellhip_sharded_local", "ellhip_shards_exchange",
+    "ellhip_sharded_create_custom", "ellhip_sharded_set_collective",
 ]
 
 
@@ -180,6 +185,10 @@ def load():
         "ellhip_device_count": (i32, []),
         "ellhip_last_error": (C.c_char_p, []),
         "ellhip_version": (C.c_char_p, []),
+        "ellhip_set_option": (i32, [vp, i32, i64]),
+        "ellhip_get_option": (i32, [vp, i32, C.POINTER(i64)]),
+        "ellhip_set_default_option": (i32, [i32, i64]),
+        "ellhip_default_option": (i32, [i32, C.POINTER(i64)]),
         "ellhip_lowpass_create": (i32, [C.POINTER(vp), i64, dbl, dbl, dbl, dbl, dbl, vp, i32]),
         "ellhip_lowpass_destroy": (None, [vp]),
         "ellhip_lowpass_assess_feas": (i32, [vp, vp, vp, C.POINTER(dbl), C.POINTER(i32), C.POINTER(dbl)]),
@@ -233,6 +242,8 @@ def load():
         "ellhip_sharded_synchronize": (i32, [vp]),
         "ellhip_sharded_local": (vp, [vp]),
         "ellhip_shards_exchange": (i32, [vp, i32]),
+        "ellhip_sharded_create_custom": (i32, [C.POINTER(vp), i64, dbl, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp]),
+        "ellhip_sharded_set_collective": (i32, [vp, vp, vp, vp]),
     }
     for name in EXPORTS:
         fn = getattr(L, name)  # AttributeError if the library does not export it
@@ -247,3 +258,33 @@ def check(rc: int, what: str = "") -> int:
         msg = load().ellhip_last_error().decode(errors="replace")
         raise EllHipError(f"{what or 'ellhip'} failed with code {rc}: {msg}")
     return rc
+
+
+def set_default_option(key: int, value: int) -> None:
+    """ellhip_set_default_option: what handles created LATER in this process start with."""
+    check(load().ellhip_set_default_option(int(key), int(value)), "ellhip_set_default_option")
+
+
+def default_option(key: int) -> int:
+    v = C.c_int64()
+    check(load().ellhip_default_option(int(key), C.byref(v)), "ellhip_default_option")
+    return int(v.value)
+
+
+class default_options:
+    """Context manager: `with capi.default_options({capi.OPT_SYMV_MIN_N: 512}): ...` -- handles created inside start with
+    these values; the previous defaults come back on exit."""
+
+    def __init__(self, opts):
+        self.opts = dict(opts)
+
+    def __enter__(self):
+        self.old = {k: default_option(k) for k in self.opts}
+        for k, v in self.opts.items():
+            set_default_option(k, v)
+        return self
+
+    def __exit__(self, *exc):
+        for k, v in self.old.items():
+            set_default_option(k, v)
+        return False

@@ -35,8 +35,8 @@ int batch_alloc(ellhip_batch* h) {
 
 int batch_shape(ellhip_batch* h) {
     h->T = h->n <= 64 ? 256 : 128;
-    h->T = env_int("ELLHIP_BATCH_T", h->T);
-    if (h->T != 64 && h->T != 128 && h->T != 256) return fail(ELLHIP_E_INVALID, "ELLHIP_BATCH_T must be 64, 128 or 256");
+    if (g_defaults.batch_threads > 0) h->T = g_defaults.batch_threads;  // ELLHIP_OPT_BATCH_THREADS
+    if (h->T != 64 && h->T != 128 && h->T != 256) return fail(ELLHIP_E_INVALID, "ELLHIP_OPT_BATCH_THREADS must be 64, 128 or 256");
     if (h->T < h->n) h->T = 128;
     h->epw = h->T / h->n;
     if (h->epw > 64) h->epw = 64;  // one wave runs the scalar stage, one lane per ellipsoid

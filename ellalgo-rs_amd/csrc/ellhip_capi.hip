@@ -55,10 +55,23 @@ struct ProfEvent {
     int cls;
 };
 
-int env_int(const char* name, int dflt) {
-    const char* s = getenv(name);
-    return (s && *s) ? atoi(s) : dflt;
-}
+// What a NEW handle starts with (ellhip_set_default_option; process-wide, not thread-safe by contract).  The values are
+// the measured best on MI355X; nothing here is read from the environment.
+struct Defaults {
+    int auto_defer = 1;        // ELLHIP_OPT_AUTO_DEFER
+    int symv = 1;              // ELLHIP_OPT_SYMV
+    long long symv_min_n = 8192;  // ELLHIP_OPT_SYMV_MIN_N
+    int apply_lower = 1;       // ELLHIP_OPT_APPLY_LOWER
+    int apply_kernel = 1;      // ELLHIP_OPT_APPLY_KERNEL
+    int fuse_dots = 1;         // ELLHIP_OPT_FUSE_DOTS
+    int stable_solve = 2;      // ELLHIP_OPT_STABLE_SOLVE
+    int stable_factor = 2;     // ELLHIP_OPT_STABLE_FACTOR
+    int pad = -1;              // ELLHIP_OPT_PAD: extra doubles per row of Q; -1 = by size (create_impl)
+    int lp_grid = 0;           // ELLHIP_OPT_LP_GRID: workgroups per LowpassOracle scan launch; 0 = by size
+    int lp_wide = -1;          // ELLHIP_OPT_LP_WIDE: column-split scan kernel; -1 = by size
+    int batch_threads = 0;     // ELLHIP_OPT_BATCH_THREADS: threads per workgroup of the batched engine; 0 = by size
+};
+Defaults g_defaults;
 
 enum : int { CLS_GEMV = 0, CLS_SCALAR = 1, CLS_RANK1 = 2, CLS_ST_FWD = 3, CLS_ST_BWD = 4, CLS_ST_FACTOR = 5, CLS_FUSED = 6, CLS_APPLY = 7, CLS_APPLY_GEMV = 8, CLS_SYMV = 9, CLS_SYMV_REDUCE = 10, CLS_LP_SCAN = 11, CLS_LP_FINAL = 12 };
 
@@ -81,33 +94,15 @@ struct ellhip_space {
     double* d_gt[2] = {nullptr, nullptr};      // buffers in use (own or caller's)
     double* d_work = nullptr;        // EllStable vectors: w, z, gg, q, beta2
     double* d_hpart = nullptr;       // EllStable forward solve with helper workgroups: the helpers' hand-over buffer (n)
-    // one launch per update on the recorded full-row schedule (k_update_fused_def): a prime that is immediately followed
-    // by its cut is not launched by itself (lazy_prime), the cut launches GEMV + scalar stage together
-    int fused_update = 0;            // ELLHIP_FUSED_UPDATE (experimental, slower: see alloc_common)
-    bool allow_lazy = false;         // set by the callers that issue prime and cut back to back (queue runs, ellhip_update)
-    bool lazy_prime = false;         // the GEMV of lazy_g into slot lazy_slot has NOT been launched yet
-    const double* lazy_g = nullptr;
-    int lazy_slot = 0;
-    // k_symv_reduce_scalar: the reduction of a lower-triangle GEMV is held back (lazy_reduce) when the gradient's cut
-    // follows at once, and launched together with the scalar stage by do_cut
-    int reduce_scalar = 0;           // ELLHIP_REDUCE_SCALAR (experimental, not faster: see alloc_common)
-    bool lazy_reduce = false;
-    const double* lazy_rg = nullptr; // the gradient whose tiles have run
-    double* lazy_ry = nullptr;       // where its y goes
-    unsigned* d_arrived = nullptr;   // arrival counter of k_update_fused_def / k_symv_reduce_scalar (only grows)
-    unsigned fused_target = 0;       // its value once every workgroup of the launches so far has arrived
-    int stable_helpers = 1;          // k_st_fwd_helped when 2 * ceil(n/128) workgroups are resident at once
-    int stable_factor_rows = 1;      // factor update from U alone (k_st_factor_rows); 0: the tile kernel that reads the scratch
-    int stable_fused = 1;            // backward solve + factor update in one launch (k_st_bwd_factor)
-    int* d_ftiles = nullptr;         // its factor tiles (strip << 8 | segment), largest first
-    int* d_fnext = nullptr;          // ... and the queue position (reset by k_st_post before every launch)
+    // EllStable kernel forms (ellhip_set_option: ELLHIP_OPT_STABLE_SOLVE / ELLHIP_OPT_STABLE_FACTOR)
+    int stable_solve = 2;            // 0: one launch per block; 1: persistent solves; 2: persistent + helper workgroups
+    int stable_factor = 2;           // 0: tile kernel that reads the scratch triangle; 1: row kernel from U alone, beside the
+                                     // backward solve; 2: factor tiles pulled inside the helped backward solve's launch
+    int* d_fnext = nullptr;          // queue position of the factor tiles (reset by k_st_post before every launch)
     int* d_ftiles16 = nullptr;       // k_st_bwd_factor_helped: 16-row tiles (row group << 4 | segment)
     int nftiles16 = 0;
     double* d_qhpart = nullptr;      // ... and the backward helpers' hand-over buffer (n)
-    int stable_bwd_helpers = 1;
-    int exp_no_factor = 0, fq_stop_env = 0;  // ELLHIP_EXP_NO_FACTOR (measurement only), ELLHIP_STABLE_FQ_STOP; read at creation
-    int nftiles = 0, fused_workers = 0;
-    int persist_cap_h = 0;           // that limit (CU count x occupancy of k_st_fwd_helped)
+    int persist_cap_h = 0;           // resident-workgroup limit of the helped solves (CU count x occupancy of k_st_fwd_helped)
     double* d_partial = nullptr;     // per-workgroup partial sums of omega (64)
     double* d_pend = nullptr;        // deferred mode: MAXPEND pending gt vectors (n each)
     double* d_cpend = nullptr;       // deferred mode: their coefficients sigma/omega
@@ -120,9 +115,6 @@ struct ellhip_space {
     int symv_seg = SYMV_SEG;         // segment width of the lower-triangle GEMV's tiles (see symv_alloc)
     int apply_lower = 1;             // with symv: apply passes touch the lower triangle only (ELLHIP_APPLY_LOWER)
     int fuse_dots = 1;               // unsharded lower-triangle schedule: k_symv_reduce also yields the scalar stage's dot products (ELLHIP_FUSE_DOTS)
-    int symv_tail = 0;               // experimental: tiles and their reduction in ONE launch (k_symv_tail, ELLHIP_SYMV_TAIL=1)
-    SymvTailCtl* d_symv_ctl = nullptr;  // its queue head / completion counters
-    unsigned symv_tail_cap = 0;      // workgroups of k_symv_tail the device holds at once
     int dots_np = 0;                 // > 0: d_partial holds dot products of the primed gradient for this depth: [ceil(n/128)][dots_np + 1]
                                      // from k_symv_reduce, or [scalar_groups(n)][...] WITHOUT the g.y column from k_sweep_gemv_dots
     bool dots_need_gy = false;       // the latter: k_scalar_apply_def forms g.y itself
@@ -132,10 +124,7 @@ struct ellhip_space {
     int npend = 0;                   // updates recorded since the last flush (host view, optimistic in queue mode)
     int* d_flags = nullptr;          // EllStable persistent solves: block-ready flags (forward | backward)
     int epoch = 0;                   // hand-off epoch, bumped per persistent launch
-    int stable_persist = 1;          // one-launch flag-chained solves (0: one launch per block)
-    int stable_pair = 0;             // experimental: two 128-blocks per workgroup (ELLHIP_STABLE_PAIR: bit 0 = forward, bit 1 = backward)
-    int persist_cap1 = 0, persist_cap2 = 0;  // workgroups of the one-block / paired persistent solves the device holds at once
-    int stable_overlap = 1;          // factor update beside the persistent backward solve
+    int persist_cap1 = 0;            // workgroups of the persistent solves the device holds at once (CU count x occupancy)
     DevState* d_st = nullptr;
 
     double* h_stage[2] = {nullptr, nullptr};  // pinned, n doubles each
@@ -261,26 +250,14 @@ void pick_shape(ellhip_space* s) {
         s->sh_rank1 = {2, 8, 1};
         s->sh_fused = {2, 8, 1};
     }
-    s->symv = env_int("ELLHIP_SYMV", 1);
-    s->symv_rw = env_int("ELLHIP_SYMV_RW", 2);
-    s->symv_min_n = env_int("ELLHIP_SYMV_MIN_N", 8192);
-    s->apply_lower = env_int("ELLHIP_APPLY_LOWER", 1);
-    s->apply_kernel = env_int("ELLHIP_APPLY_KERNEL", 1);
-    s->fuse_dots = env_int("ELLHIP_FUSE_DOTS", 1);
-    s->symv_tail = env_int("ELLHIP_SYMV_TAIL", 0);   // measured slower than the two launches
     s->sh_apply = {4, 1, s->sh_fused.nt};  // 8 pending vectors per column step: more rows per workgroup amortise them
-    s->sh_apply.rw = env_int("ELLHIP_APPLY_RW", s->sh_apply.rw);
-    s->sh_apply.unr = env_int("ELLHIP_APPLY_UNR", s->sh_apply.unr);
-    s->sh_apply.nt = env_int("ELLHIP_APPLY_NT", s->sh_apply.nt);
-    s->sh_gemv.rw = env_int("ELLHIP_GEMV_RW", s->sh_gemv.rw);
-    s->sh_gemv.unr = env_int("ELLHIP_GEMV_UNR", s->sh_gemv.unr);
-    s->sh_gemv.nt = env_int("ELLHIP_GEMV_NT", s->sh_gemv.nt);
-    s->sh_rank1.rw = env_int("ELLHIP_RANK1_RW", s->sh_rank1.rw);
-    s->sh_rank1.unr = env_int("ELLHIP_RANK1_UNR", s->sh_rank1.unr);
-    s->sh_rank1.nt = env_int("ELLHIP_RANK1_NT", s->sh_rank1.nt);
-    s->sh_fused.rw = env_int("ELLHIP_FUSED_RW", s->sh_fused.rw);
-    s->sh_fused.unr = env_int("ELLHIP_FUSED_UNR", s->sh_fused.unr);
-    s->sh_fused.nt = env_int("ELLHIP_FUSED_NT", s->sh_fused.nt);
+    s->symv = g_defaults.symv;
+    s->symv_min_n = g_defaults.symv_min_n;
+    s->apply_lower = g_defaults.apply_lower;
+    s->apply_kernel = g_defaults.apply_kernel;
+    s->fuse_dots = g_defaults.fuse_dots;
+    s->stable_solve = g_defaults.stable_solve;
+    s->stable_factor = g_defaults.stable_factor;
 }
 
 // One pass over Q in the given roles.  gt_r1: vector of the rank-1 role; gvec / gv_out: operand and
@@ -355,37 +332,6 @@ int launch_gemv_dots(ellhip_space* s, const double* gvec, double* gv_out) {
     s->dots_np = 8;
     s->dots_need_gy = true;
     return 0;
-}
-
-// GEMV + dot products + scalar stage in ONE launch (k_update_fused_def): the cut's parameters are known at launch time.
-template <int VEC, bool NT>
-int launch_update_fused_t(ellhip_space* s, const Shape& sh, const double* gvec, double* gv_out, const CutParams* cp_dev,
-                          CutParams cp_val, int queue_mode, int* qst, double* qtsq) {
-    const long long nr = s->nrows;
-    const unsigned ntiles = (unsigned)((nr + sh.rw - 1) / sh.rw);
-    const unsigned grid = ntiles + (unsigned)scalar_groups(s->n);
-    EllCalcDev calc = EllCalcDev::make(s->n, s->use_parallel_cut);
-    s->fused_target += grid;
-#define FUSED_CASE(RW, UNR)                                                                                         \
-    if (sh.rw == RW && sh.unr == UNR) {                                                                             \
-        hipLaunchKernelGGL((k_update_fused_def<RW, UNR, VEC, NT, 8>), dim3(grid), dim3(256), 0, s->stream,           \
-                           (const double*)s->d_Q, s->ld, s->n, nr, s->row0, gvec, gv_out + s->row0, s->d_st, s->dir, \
-                           ntiles, s->d_pend, s->d_partial, s->d_xc, s->d_cpend, calc, cp_dev, cp_val, s->npend,     \
-                           queue_mode, qst, qtsq, s->d_arrived, s->fused_target);                                    \
-        return 0;                                                                                                   \
-    }
-    FUSED_CASE(1, 4) FUSED_CASE(1, 8) FUSED_CASE(2, 4) FUSED_CASE(2, 8) FUSED_CASE(4, 2) FUSED_CASE(4, 4)
-    FUSED_CASE(8, 1) FUSED_CASE(8, 2)
-#undef FUSED_CASE
-    s->fused_target -= grid;
-    return fail(ELLHIP_E_INVALID, "unsupported RW/UNR launch shape (supported: 1x4 1x8 2x4 2x8 4x2 4x4 8x1 8x2)");
-}
-
-bool deferring(const ellhip_space* s);
-// the schedule k_update_fused_def serves: what do_prime would hand to launch_gemv_dots
-bool fused_update_ok(const ellhip_space* s) {
-    return s->fused_update && s->d_arrived && deferring(s) && s->defer == 8 && !s->sharded && s->fuse_dots && s->n <= 8192 &&
-           s->d_pend && s->d_partial;
 }
 
 // Deferred mode is in force for Ell with depth > 1, except while the reference semantics need Q itself
@@ -485,13 +431,11 @@ int ellstable_issue(ellhip_space* s, const double* g_dev, const CutParams* cp_de
     hipStream_t st = s->stream;
     // One launch per solve when every workgroup of the chain can be resident at once (a workgroup that waits for its
     // predecessor holds its CU: the limit is what the DEVICE holds -- CU count x occupancy of the kernel, measured at
-    // handle creation -- not a constant); otherwise one launch per block.  Paired form: two 128-blocks per workgroup.
-    const long long npair = (nb + 1) / 2;
-    const bool pair_ok = s->stable_persist && npair <= s->persist_cap2;
-    const bool pair_fwd = pair_ok && (s->stable_pair & 1), pair_bwd = pair_ok && (s->stable_pair & 2);
-    const bool persist = pair_ok || (s->stable_persist && nb <= s->persist_cap1);
-    // forward solve with a helper workgroup per block (two workgroups per block, all resident): see k_st_fwd_helped
-    const bool helped = persist && !pair_fwd && s->stable_helpers && s->d_hpart && 2 * nb <= s->persist_cap_h;
+    // handle creation -- not a constant); otherwise one launch per block.
+    const bool persist = s->stable_solve >= 1 && nb <= s->persist_cap1;
+    // both solves with a helper workgroup per block (two workgroups per block, all resident): k_st_fwd_helped,
+    // k_st_bwd_factor_helped (which also pulls the factor tiles)
+    const bool helped = persist && s->stable_solve >= 2 && s->d_hpart && 2 * nb <= s->persist_cap_h;
     // Persistent forward solve: the workgroup that is next in the chain polls the VALUES of the block it waits for
     // (sentinel until stored, like the backward solve's qpub), everybody else the block's flag.  The published
     // vector therefore has to be all-sentinel when a solve starts: two buffers alternate by launch parity, and the
@@ -500,14 +444,14 @@ int ellstable_issue(ellhip_space* s, const double* g_dev, const CutParams* cp_de
     double* w = (persist && (s->epoch & 1)) ? w1 : w0;
     double* w_next = (persist && (s->epoch & 1)) ? w0 : w1;
     int* err = reinterpret_cast<int*>(reinterpret_cast<char*>(s->d_st) + offsetof(DevState, solve_err));
+    // factor update inside the backward solve's launch: needs the helped form and the row-wise (U alone) arithmetic
+    const bool fused_h = helped && s->stable_factor >= 2 && s->d_ftiles16 && s->d_fnext && s->d_qhpart &&
+                         2 * nb <= s->persist_cap1;
     {
         ProfScope ps(s, CLS_ST_FWD);
         if (helped) {
             hipLaunchKernelGGL(k_st_fwd_helped, dim3((unsigned)(2 * nb)), dim3(256), 0, st, s->d_Q, ld, n, g_dev, w,
                                s->d_hpart, z, gg, s->d_flags, err, s->epoch, s->d_st);
-        } else if (pair_fwd) {
-            hipLaunchKernelGGL(k_st_fwd_persist2, dim3((unsigned)npair), dim3(256), 0, st, s->d_Q, ld, n, g_dev, w, z, gg,
-                               s->d_flags, err, s->epoch, s->d_st);
         } else if (persist) {
             hipLaunchKernelGGL(k_st_fwd_persist, dim3((unsigned)nb), dim3(256), 0, st, s->d_Q, ld, n, g_dev, w, z, gg,
                                s->d_flags, err, s->epoch, s->d_st);
@@ -531,50 +475,31 @@ int ellstable_issue(ellhip_space* s, const double* g_dev, const CutParams* cp_de
                            (const double*)z, (const double*)gg, (const double*)cpre, q, beta2,
                            persist ? qpub : (double*)nullptr, persist ? w_next : (double*)nullptr,
                            (const DevState*)s->d_st, helped ? s->d_hpart : (double*)nullptr, s->d_fnext,
-                           (persist && s->stable_bwd_helpers) ? s->d_qhpart : (double*)nullptr);
+                           fused_h ? s->d_qhpart : (double*)nullptr);
         HIPCHK(hipGetLastError());
     }
-    // The factor update (reads S, rewrites U) and the backward solve (reads S, writes q) are independent.
-    // With the persistent backward solve (128 resident workgroups, latency-bound) the bandwidth-bound
-    // factor update runs beside it on the auxiliary stream, launched AFTER it so the solve's workgroups
-    // are placed first; the streams join before anything else touches the buffer.
-    const bool fused = persist && !pair_bwd && s->stable_fused && s->stable_factor_rows && s->d_ftiles && s->d_fnext &&
-                       s->fused_workers > 0 && nb + s->fused_workers <= s->persist_cap1;
-    const bool fused_h = fused && s->stable_bwd_helpers && s->d_ftiles16 && s->d_qhpart && 2 * nb <= s->persist_cap1;
-    const bool overlap = persist && s->stable_overlap && !fused;
+    // The factor update (rewrites U) and the backward solve (reads S, writes q) are independent.  Helped form: the
+    // factor tiles are pulled inside the backward solve's launch by whoever is idle.  Otherwise, with the persistent
+    // backward solve (latency-bound) the bandwidth-bound factor update runs beside it on the auxiliary stream,
+    // launched AFTER it so the solve's workgroups are placed first; the streams join before anything else touches Q.
+    const bool overlap = persist && !fused_h;
     if (overlap) HIPCHK(hipEventRecord(s->ev_fork, st));
     {
         ProfScope ps(s, CLS_ST_BWD);
         if (fused_h) {
             const unsigned grid = (unsigned)(2 * nb);
-            // (measurement only, results WRONG: ELLHIP_EXP_NO_FACTOR=1 leaves the factor tiles out to time the chain alone)
-            const int no_factor = s->exp_no_factor;
-            const int nft = no_factor > 0 ? s->nftiles16 - s->nftiles16 / no_factor : s->nftiles16;  // 1: none, 2: half, ...
             // before their turn the chain workgroups pull factor tiles only when the matrix is on-die (n < 8192): from HBM
             // it made them late for their own block (n = 16384: stop distance 6 / 12 / 24 / 48+ blocks: 785 / 731 / 710 /
             // 685-695 us), on-die it pays (n = 4096: 139 us against 170 without)
-            const long long fq_stop = s->fq_stop_env > 0 ? s->fq_stop_env : (n >= 8192 ? nb + 1 : FQ_STOP);
+            const long long fq_stop = n >= 8192 ? nb + 1 : FQ_STOP;
             if (n >= 8192)
                 hipLaunchKernelGGL((k_st_bwd_factor_helped<2048, 8>), dim3(grid), dim3(256), 0, st, s->d_Q, ld, n, q, qpub,
                                    s->d_qhpart, err, (const DevState*)s->d_st, nb, (const double*)beta2, (const double*)w,
-                                   (const int*)s->d_ftiles16, nft, s->d_fnext, fq_stop);
+                                   (const int*)s->d_ftiles16, s->nftiles16, s->d_fnext, fq_stop);
             else
                 hipLaunchKernelGGL((k_st_bwd_factor_helped<512, 8>), dim3(grid), dim3(256), 0, st, s->d_Q, ld, n, q, qpub,
                                    s->d_qhpart, err, (const DevState*)s->d_st, nb, (const double*)beta2, (const double*)w,
-                                   (const int*)s->d_ftiles16, nft, s->d_fnext, fq_stop);
-        } else if (fused) {
-            const unsigned grid = (unsigned)(nb + s->fused_workers);
-            if (n >= 8192)
-                hipLaunchKernelGGL((k_st_bwd_factor<2048, 8>), dim3(grid), dim3(256), 0, st, s->d_Q, ld, n, q, qpub, err,
-                                   (const DevState*)s->d_st, nb, (const double*)beta2, (const double*)w,
-                                   (const int*)s->d_ftiles, s->nftiles, s->d_fnext);
-            else
-                hipLaunchKernelGGL((k_st_bwd_factor<512, 16>), dim3(grid), dim3(256), 0, st, s->d_Q, ld, n, q, qpub, err,
-                                   (const DevState*)s->d_st, nb, (const double*)beta2, (const double*)w,
-                                   (const int*)s->d_ftiles, s->nftiles, s->d_fnext);
-        } else if (pair_bwd) {
-            hipLaunchKernelGGL(k_st_bwd_persist2, dim3((unsigned)npair), dim3(256), 0, st, s->d_Q, ld, n, q, qpub, err,
-                               s->d_st);
+                                   (const int*)s->d_ftiles16, s->nftiles16, s->d_fnext, fq_stop);
         } else if (persist) {
             hipLaunchKernelGGL(k_st_bwd_persist, dim3((unsigned)nb), dim3(256), 0, st, s->d_Q, ld, n, q, qpub, err,
                                s->d_st);
@@ -589,12 +514,12 @@ int ellstable_issue(ellhip_space* s, const double* g_dev, const CutParams* cp_de
         hipLaunchKernelGGL(k_st_xc, dim3(gx < 256 ? gx : 256), dim3(256), 0, st, n, q, s->d_xc, s->d_st);
         HIPCHK(hipGetLastError());
     }
-    if (!fused) {
+    if (!fused_h) {
         hipStream_t fs = overlap ? s->aux_stream : st;
         if (overlap) HIPCHK(hipStreamWaitEvent(fs, s->ev_fork, 0));
         {
             ProfScope ps(s, CLS_ST_FACTOR, fs);
-            if (s->stable_factor_rows) {
+            if (s->stable_factor >= 1) {
                 // row-wise, from U alone (the scratch entry it would read IS fl(U * w): see k_st_factor_rows)
                 const unsigned gy = (unsigned)((n + FROW_H - 1) / FROW_H);
                 if (n >= 8192)
@@ -636,25 +561,13 @@ int symv_alloc(ellhip_space* s) {
     s->symv_seg = (area / (64.0 * SYMV_SEG) < 200.0) ? SYMV_SEG_SMALL : SYMV_SEG;
     // rows in flight per thread: with about one 64 x 2048 tile per CU (n = 8192: 256 tiles) the workgroup itself has to
     // keep more loads in the air -- 4 rows: 61 vs 65 us per pass; with several tiles per CU (n = 16384) 2 and 4 tie
-    if (!getenv("ELLHIP_SYMV_RW")) s->symv_rw = (area / (64.0 * SYMV_SEG) < 600.0) ? 4 : 2;
-    s->symv_seg = env_int("ELLHIP_SYMV_SEG", s->symv_seg);
-    if (s->symv_seg != SYMV_SEG && s->symv_seg != SYMV_SEG_SMALL) return fail(ELLHIP_E_INVALID, "ELLHIP_SYMV_SEG must be 512 or 2048");
+    s->symv_rw = (area / (64.0 * SYMV_SEG) < 600.0) ? 4 : 2;
     const size_t nsegs = (size_t)((s->n + s->symv_seg - 1) / s->symv_seg), nstrips = (size_t)((s->nrows + SYMV_H - 1) / SYMV_H);
     HIPCHK(hipMalloc(&s->d_rowpart, nsegs * (size_t)s->n * sizeof(double)));
     HIPCHK(hipMalloc(&s->d_colpart, nstrips * (size_t)s->n * sizeof(double)));
     // rows of rowpart outside this shard are never written but are read by nobody either; zero them anyway
     HIPCHK(hipMemsetAsync(s->d_rowpart, 0, nsegs * (size_t)s->n * sizeof(double), s->stream));
     HIPCHK(hipMemsetAsync(s->d_colpart, 0, nstrips * (size_t)s->n * sizeof(double), s->stream));
-    if (!s->sharded && s->symv_tail && s->symv_seg == SYMV_SEG && (s->n + SYMV_SEG - 1) / SYMV_SEG <= SYMV_MAXSEGS) {
-        HIPCHK(hipMalloc(&s->d_symv_ctl, sizeof(SymvTailCtl)));
-        HIPCHK(hipMemsetAsync(s->d_symv_ctl, 0, sizeof(SymvTailCtl), s->stream));
-        hipDeviceProp_t prop;
-        HIPCHK(hipGetDeviceProperties(&prop, s->device));
-        int occ = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)k_symv_tail<2, true, 16>, 256, 0) != hipSuccess) occ = 0;
-        s->symv_tail_cap = (unsigned)std::max(0, occ * prop.multiProcessorCount);
-        if (s->symv_tail_cap < 512) s->symv_tail = 0;   // (a device this small: keep the two launches)
-    }
     return 0;
 }
 
@@ -668,54 +581,9 @@ void symv_go(ellhip_space* s, const double* g_dev, unsigned nstrips, unsigned ns
                            s->ld, s->n, s->row0, s->nrows, g_dev, s->d_rowpart, s->d_colpart, s->d_st);
 }
 
-template <int RW, int NPV>
-void symv_tail_go(ellhip_space* s, const double* g_dev, double* y_out, unsigned nstrips, unsigned nsegs, bool nt,
-                  unsigned nactive, unsigned pull_from) {
-    if (nt)
-        hipLaunchKernelGGL((k_symv_tail<RW, true, NPV>), dim3(nstrips, nsegs), dim3(256), 0, s->stream, (const double*)s->d_Q,
-                           s->ld, s->n, g_dev, s->d_rowpart, s->d_colpart, y_out, (const double*)s->d_pend, s->d_partial,
-                           s->d_st, s->d_symv_ctl, nactive, pull_from);
-    else
-        hipLaunchKernelGGL((k_symv_tail<RW, false, NPV>), dim3(nstrips, nsegs), dim3(256), 0, s->stream, (const double*)s->d_Q,
-                           s->ld, s->n, g_dev, s->d_rowpart, s->d_colpart, y_out, (const double*)s->d_pend, s->d_partial,
-                           s->d_st, s->d_symv_ctl, nactive, pull_from);
-}
-
 int launch_symv_reduce(ellhip_space* s, const double* g_dev, double* y_out);
-bool deferring(const ellhip_space* s);
-// the schedule k_symv_reduce_scalar serves: unsharded lower-triangle GEMV whose reduction carries the dot products
-bool reduce_scalar_ok(const ellhip_space* s) {
-    return s->reduce_scalar && s->d_arrived && !s->sharded && s->fuse_dots && deferring(s) && (s->defer == 8 || s->defer == 16) &&
-           !s->symv_tail && (s->n + 127) / 128 <= 256;
-}
-// launch the reduction a lazy prime held back (somebody needs y, or the cut is not the one that was announced)
-int finish_lazy_reduce(ellhip_space* s) {
-    if (!s->lazy_reduce) return 0;
-    s->lazy_reduce = false;
-    return launch_symv_reduce(s, s->lazy_rg, s->lazy_ry);
-}
-
 int launch_symv(ellhip_space* s, const double* g_dev, double* y_out) {
     const int seg = s->symv_seg;
-    if (!s->sharded && s->symv_tail && s->d_symv_ctl && seg == SYMV_SEG && (s->symv_rw == 2 || s->symv_rw == 4) &&
-        s->fuse_dots && (s->defer == 8 || s->defer == 16)) {
-        // tiles + reduction in one launch (k_symv_tail)
-        ProfScope ps(s, CLS_SYMV);
-        const unsigned nstrips = (unsigned)((s->n + SYMV_H - 1) / SYMV_H), nsegs = (unsigned)((s->n + seg - 1) / seg);
-        unsigned nactive = 0;
-        for (unsigned j = 0; j < nsegs; ++j) nactive += nstrips - (unsigned)(((long long)j * seg) / SYMV_H);
-        const unsigned pull_from = std::min(nactive, (unsigned)env_int("ELLHIP_SYMV_TAIL_NPULL", (int)((s->n + 127) / 128)));   // workgroups that pull: the last to finish
-        const bool nt = s->sh_gemv.nt != 0;
-        const int np = s->fuse_dots ? s->defer : 0;
-#define TAIL_GO(RWV)                                                                              \
-    if (np == 16) symv_tail_go<RWV, 16>(s, g_dev, y_out, nstrips, nsegs, nt, nactive, pull_from);  \
-    else symv_tail_go<RWV, 8>(s, g_dev, y_out, nstrips, nsegs, nt, nactive, pull_from)
-        if (s->symv_rw == 2) { TAIL_GO(2); } else { TAIL_GO(4); }
-#undef TAIL_GO
-        HIPCHK(hipGetLastError());
-        s->dots_np = np;
-        return 0;
-    }
     {
         ProfScope ps(s, CLS_SYMV);
         const unsigned nstrips = (unsigned)((s->nrows + SYMV_H - 1) / SYMV_H);  // local strips
@@ -729,19 +597,12 @@ int launch_symv(ellhip_space* s, const double* g_dev, double* y_out) {
                 case 2: symv_go<2, SYMV_SEG>(s, g_dev, nstrips, nsegs, nt); break;
                 case 4: symv_go<4, SYMV_SEG>(s, g_dev, nstrips, nsegs, nt); break;
                 case 8: symv_go<8, SYMV_SEG>(s, g_dev, nstrips, nsegs, nt); break;
-                default: return fail(ELLHIP_E_INVALID, "unsupported ELLHIP_SYMV_RW (1, 2, 4, 8)");
+                default: return fail(ELLHIP_E_INVALID, "unsupported rows-in-flight of the lower-triangle GEMV (1, 2, 4, 8)");
             }
         } else {
-            return fail(ELLHIP_E_INVALID, "unsupported ELLHIP_SYMV_SEG (512, 2048)");
+            return fail(ELLHIP_E_INVALID, "unsupported segment width of the lower-triangle GEMV (512, 2048)");
         }
         HIPCHK(hipGetLastError());
-    }
-    if (s->allow_lazy && reduce_scalar_ok(s) && seg == s->symv_seg) {
-        // the caller cuts this gradient next: its reduction runs in the scalar stage's launch (do_cut)
-        s->lazy_reduce = true;
-        s->lazy_rg = g_dev;
-        s->lazy_ry = y_out;
-        return 0;
     }
     return launch_symv_reduce(s, g_dev, y_out);
 }
@@ -774,12 +635,6 @@ int do_prime(ellhip_space* s, const double* g_dev, int slot) {
     if (symv_ok(s)) return launch_symv(s, g_dev, s->d_gt[slot]);
     if (s->shard_symmetric)
         return fail(ELLHIP_E_STATE, "symmetric row shard: only the deferred (depth 8) schedule is available");
-    if (s->allow_lazy && fused_update_ok(s)) {  // the caller cuts this very gradient next: one launch for both (do_cut)
-        s->lazy_prime = true;
-        s->lazy_g = g_dev;
-        s->lazy_slot = slot;
-        return 0;
-    }
     ProfScope ps(s, CLS_GEMV);
     // deferred depth 8 on full rows (no lower-triangle schedule at this size): the dot products ride along.  Up to
     // n = 8192 only: every workgroup of the scalar stage re-forms g.y from all of g and y, which stops paying beyond.
@@ -795,54 +650,6 @@ int do_cut(ellhip_space* s, const double* g_dev, const CutParams* cp_dev, CutPar
     // The dot products a prime left in d_partial belong to THIS cut only: whatever path the cut takes (also the
     // non-deferred one, after a depth switch between prime and cut) they are spent now, and a gradient primed later
     // by a fused pass (rank-1 + GEMV, apply + GEMV) has none.
-    if (s->lazy_reduce) {
-        if (g_dev != s->lazy_rg || s->lazy_ry != s->d_gt[s->cur] || !reduce_scalar_ok(s)) {
-            int rc = finish_lazy_reduce(s);  // (cannot happen with the callers that set allow_lazy; be safe)
-            if (rc) return rc;
-        } else {
-            s->lazy_reduce = false;
-            ProfScope ps(s, CLS_SYMV_REDUCE);
-            EllCalcDev calc = EllCalcDev::make(s->n, s->use_parallel_cut);
-            const unsigned grid = (unsigned)((s->n + 127) / 128);
-            s->fused_target += grid;
-#define RS_GO(NPV)                                                                                                      \
-    hipLaunchKernelGGL(k_symv_reduce_scalar<NPV>, dim3(grid), dim3(256), 0, s->stream, s->n, (long long)s->symv_seg,      \
-                       (const double*)s->d_rowpart, (const double*)s->d_colpart, s->d_gt[s->cur], s->d_st, g_dev, s->d_pend, \
-                       s->d_partial, s->d_xc, s->d_cpend, calc, cp_dev, cp_val, s->npend, queue_mode, qst, qtsq,          \
-                       s->d_arrived, s->fused_target)
-            if (s->defer == 16) RS_GO(16); else RS_GO(8);
-#undef RS_GO
-            HIPCHK(hipGetLastError());
-            s->dots_np = 0;
-            s->dots_need_gy = false;
-            s->npend += 1;
-            return 0;
-        }
-    }
-    if (s->lazy_prime) {
-        // the GEMV of this gradient was held back by do_prime: GEMV pass + scalar stage in one launch
-        s->lazy_prime = false;
-        if (g_dev != s->lazy_g || s->lazy_slot != s->cur || !fused_update_ok(s)) {
-            // (cannot happen with the callers that set allow_lazy; be safe: do what do_prime would have done)
-            int rc = launch_gemv_dots(s, s->lazy_g, s->d_gt[s->lazy_slot]);
-            if (rc) return rc;
-        } else {
-            ProfScope ps(s, CLS_GEMV);
-            const bool even = (s->n % 2) == 0;
-            const bool nt = even && s->sh_gemv.nt;
-            double* out = s->d_gt[s->cur];
-            int rc = !even ? launch_update_fused_t<1, false>(s, s->sh_gemv, g_dev, out, cp_dev, cp_val, queue_mode, qst, qtsq)
-                           : (nt ? launch_update_fused_t<2, true>(s, s->sh_gemv, g_dev, out, cp_dev, cp_val, queue_mode, qst, qtsq)
-                                 : launch_update_fused_t<2, false>(s, s->sh_gemv, g_dev, out, cp_dev, cp_val, queue_mode, qst, qtsq));
-            if (rc) return rc;
-            HIPCHK(hipGetLastError());
-            s->dir ^= 1;
-            s->dots_np = 0;
-            s->dots_need_gy = false;
-            s->npend += 1;
-            return 0;
-        }
-    }
     const int dots_np_now = s->dots_np;
     s->dots_np = 0;
     ProfScope ps(s, CLS_SCALAR);
@@ -934,12 +741,9 @@ int read_back(ellhip_space* s) {
         s->h_result->solve_err = 0;
         (void)hipMemsetAsync(reinterpret_cast<char*>(s->d_st) + offsetof(DevState, solve_err), 0, sizeof(int), s->stream);
         (void)hipStreamSynchronize(s->stream);
-        s->stable_persist = 0;
-        s->symv_tail = 0;
-        s->fused_update = 0;
-        s->reduce_scalar = 0;
-        return fail(ELLHIP_E_HIP, "a bounded in-launch wait timed out (EllStable persistent solve / k_symv_tail); this handle now "
-                                  "uses the forms without inter-workgroup waits");
+        s->stable_solve = 0;
+        return fail(ELLHIP_E_HIP, "a bounded in-launch wait of an EllStable persistent solve timed out; this handle now uses one "
+                                  "launch per block (no inter-workgroup waits)");
     }
     return 0;
 }
@@ -1040,15 +844,6 @@ int alloc_common(ellhip_space* s) {
     // lower-triangle GEMV's reduction produces them
     HIPCHK(hipMalloc(&s->d_partial, (size_t)std::max<long long>(64, (n + 127) / 128) * (MAXPEND + 1) * sizeof(double)));
     if (s->variant == ELLHIP_SPACE_ELL) {
-        // off by default: measured at n = 4096, the launch takes 40.1 us against 25.0 + 14.1 us for the two it replaces
-        // (the scalar stage's own dependency chain, not the launch, is what costs), and the queue loses the apply + GEMV
-        // pass of every 8th cut: 22 800 against 25 400 updates/s
-        s->fused_update = env_int("ELLHIP_FUSED_UPDATE", 0);
-        // likewise off: k_symv_reduce_scalar takes 23.9 us against 11.4 + 12.3 us (n = 16384: 4190 against 4230 updates/s)
-        s->reduce_scalar = env_int("ELLHIP_REDUCE_SCALAR", 0);
-        HIPCHK(hipMalloc(&s->d_arrived, sizeof(unsigned)));
-        HIPCHK(hipMemsetAsync(s->d_arrived, 0, sizeof(unsigned), s->stream));
-        s->fused_target = 0;
         HIPCHK(hipMalloc(&s->d_pend, (size_t)MAXPEND * vbytes));
         HIPCHK(hipMalloc(&s->d_cpend, MAXPEND * sizeof(double)));
         HIPCHK(hipMemsetAsync(s->d_pend, 0, (size_t)MAXPEND * vbytes, s->stream));
@@ -1058,8 +853,6 @@ int alloc_common(ellhip_space* s) {
         const size_t nflags = (size_t)std::max<long long>(512, (n + SB - 1) / SB);
         HIPCHK(hipMalloc(&s->d_flags, nflags * sizeof(int)));
         HIPCHK(hipMemsetAsync(s->d_flags, 0, nflags * sizeof(int), s->stream));
-        s->stable_persist = env_int("ELLHIP_STABLE_PERSIST", 1);
-        s->stable_pair = env_int("ELLHIP_STABLE_PAIR", 0);   // measured slower than one block per workgroup
         {   // how many workgroups of each persistent solve this device keeps resident at once
             hipDeviceProp_t prop;
             HIPCHK(hipGetDeviceProperties(&prop, s->device));
@@ -1070,66 +863,30 @@ int alloc_common(ellhip_space* s) {
                 return std::min(a, b) * prop.multiProcessorCount;
             };
             s->persist_cap1 = cap((const void*)k_st_fwd_persist, (const void*)k_st_bwd_persist, 256);
-            s->persist_cap2 = cap((const void*)k_st_fwd_persist2, (const void*)k_st_bwd_persist2, 256);
-            // (the factor update runs beside the backward solve on the auxiliary stream, launched after it: the
-            // solve's workgroups are placed first, and every wait in the solves is bounded)
-            {
-                int a = 0;
-                if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, (const void*)k_st_fwd_helped, 256, 0) != hipSuccess) a = 0;
-                s->persist_cap_h = env_int("ELLHIP_STABLE_CAP_H", a * prop.multiProcessorCount);
-            }
-            s->stable_helpers = env_int("ELLHIP_STABLE_HELPERS", 1);
-            s->stable_factor_rows = env_int("ELLHIP_STABLE_FACTOR_ROWS", 1);
-            s->persist_cap1 = env_int("ELLHIP_STABLE_CAP", s->persist_cap1);
-            s->persist_cap2 = env_int("ELLHIP_STABLE_CAP2", s->persist_cap2);
+            s->persist_cap_h = cap((const void*)k_st_fwd_helped, (const void*)k_st_bwd_factor_helped<2048, 8>, 256);
         }
-        s->stable_overlap = env_int("ELLHIP_STABLE_OVERLAP", 1);
-        s->stable_fused = env_int("ELLHIP_STABLE_FUSED", 1);
-        {   // the factor tiles of k_st_bwd_factor: the active tiles of k_st_factor_rows' grid, full ones first
+        {   // the 16-row factor tiles of k_st_bwd_factor_helped: the active tiles of the strict upper triangle, full ones first
             const long long seg = (n >= 8192) ? 2048 : 512;
-            const long long nstrip = (n + FROW_H - 1) / FROW_H, nseg = (n + seg - 1) / seg;
-            std::vector<int> full, edge;
-            for (long long I = 0; I < nstrip && nseg <= 255; ++I)
+            const long long nseg = (n + seg - 1) / seg;
+            std::vector<int> f16, e16;
+            const long long ngrp = (n + FQ_H - 1) / FQ_H;
+            for (long long I = 0; I < ngrp && nseg <= 16; ++I)
                 for (long long J = 0; J < nseg; ++J) {
-                    const long long r0 = I * FROW_H, c0 = J * seg;
+                    const long long r0 = I * FQ_H, c0 = J * seg;
                     if (c0 + seg - 1 <= r0) continue;
-                    const long long rlast = std::min(r0 + FROW_H - 1, n - 1);
-                    ((c0 > rlast && c0 + seg <= n) ? full : edge).push_back((int)((I << 8) | J));
+                    const long long rlast = std::min(r0 + FQ_H - 1, n - 1);
+                    ((c0 > rlast && c0 + seg <= n) ? f16 : e16).push_back((int)((I << 4) | J));
                 }
-            full.insert(full.end(), edge.begin(), edge.end());
-            s->nftiles = (int)full.size();
-            const long long nbk = (n + SB - 1) / SB;
-            s->fused_workers = (int)std::max<long long>(0, std::min<long long>(s->persist_cap1 - nbk, s->nftiles));
-            s->fused_workers = env_int("ELLHIP_STABLE_WORKERS", s->fused_workers);
-            s->stable_bwd_helpers = env_int("ELLHIP_STABLE_BWD_HELPERS", 1);
-            s->exp_no_factor = env_int("ELLHIP_EXP_NO_FACTOR", 0);
-            s->fq_stop_env = env_int("ELLHIP_STABLE_FQ_STOP", 0);
-            {   // 16-row tiles of k_st_bwd_factor_helped
-                std::vector<int> f16, e16;
-                const long long ngrp = (n + FQ_H - 1) / FQ_H;
-                for (long long I = 0; I < ngrp && nseg <= 16; ++I)
-                    for (long long J = 0; J < nseg; ++J) {
-                        const long long r0 = I * FQ_H, c0 = J * seg;
-                        if (c0 + seg - 1 <= r0) continue;
-                        const long long rlast = std::min(r0 + FQ_H - 1, n - 1);
-                        ((c0 > rlast && c0 + seg <= n) ? f16 : e16).push_back((int)((I << 4) | J));
-                    }
-                f16.insert(f16.end(), e16.begin(), e16.end());
-                s->nftiles16 = (int)f16.size();
-                if (s->nftiles16 > 0) {
-                    HIPCHK(hipMalloc(&s->d_ftiles16, f16.size() * sizeof(int)));
-                    HIPCHK(hipMemcpyAsync(s->d_ftiles16, f16.data(), f16.size() * sizeof(int), hipMemcpyHostToDevice, s->stream));
-                    HIPCHK(hipStreamSynchronize(s->stream));
-                    HIPCHK(hipMalloc(&s->d_qhpart, vbytes));
-                    hipLaunchKernelGGL(k_st_arm, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream, s->d_qhpart, n);
-                }
-            }
-            if (s->nftiles > 0) {
-                HIPCHK(hipMalloc(&s->d_fnext, sizeof(int)));
-                HIPCHK(hipMemsetAsync(s->d_fnext, 0, sizeof(int), s->stream));
-                HIPCHK(hipMalloc(&s->d_ftiles, full.size() * sizeof(int)));
-                HIPCHK(hipMemcpyAsync(s->d_ftiles, full.data(), full.size() * sizeof(int), hipMemcpyHostToDevice, s->stream));
-                HIPCHK(hipStreamSynchronize(s->stream));  // `full` goes out of scope
+            f16.insert(f16.end(), e16.begin(), e16.end());
+            s->nftiles16 = (int)f16.size();
+            HIPCHK(hipMalloc(&s->d_fnext, sizeof(int)));
+            HIPCHK(hipMemsetAsync(s->d_fnext, 0, sizeof(int), s->stream));
+            if (s->nftiles16 > 0) {
+                HIPCHK(hipMalloc(&s->d_ftiles16, f16.size() * sizeof(int)));
+                HIPCHK(hipMemcpyAsync(s->d_ftiles16, f16.data(), f16.size() * sizeof(int), hipMemcpyHostToDevice, s->stream));
+                HIPCHK(hipStreamSynchronize(s->stream));  // `f16` goes out of scope
+                HIPCHK(hipMalloc(&s->d_qhpart, vbytes));
+                hipLaunchKernelGGL(k_st_arm, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream, s->d_qhpart, n);
             }
         }
         HIPCHK(hipStreamCreateWithFlags(&s->aux_stream, hipStreamNonBlocking));
@@ -1208,7 +965,7 @@ int create_impl(ellhip_space** out, int variant, long long n, long long row0, lo
     // n = 16384: 5.8 -> 6.3 TB/s); blocks that live in the Infinity Cache are left dense.
     s->ld = n;
     if ((n % 512) == 0 && (double)nrows * (double)n * 8.0 > 200.0 * 1024 * 1024) s->ld = n + 16;
-    s->ld = n + std::max(0, env_int("ELLHIP_PAD", (int)(s->ld - n)));
+    if (g_defaults.pad >= 0) s->ld = n + g_defaults.pad;  // ELLHIP_OPT_PAD (tuning runs)
     if ((n % 2) == 0 && (s->ld % 2) != 0) s->ld += 1;
     if (variant == ELLHIP_SPACE_ELL_STABLE) s->ld = n + (n & 1);  // 16-byte aligned rows for the 2-column lanes
     pick_shape(s);
@@ -1269,7 +1026,7 @@ int create_impl(ellhip_space** out, int variant, long long n, long long row0, lo
     // everywhere; ellhip_set_defer_depth overrides either way.  Row shards stay at 1 until their owner chooses.
     // Between 3072 and that size (and for odd n) depth 8 with full-row GEMVs is the faster one, for synchronous calls
     // and for queues alike (tools/depth_sweep.py: n = 4096: 15 800 vs 10 400 calls/s; below ~3000 depth 1 wins).
-    if (variant == ELLHIP_SPACE_ELL && !sharded && env_int("ELLHIP_AUTO_DEFER", 1)) {
+    if (variant == ELLHIP_SPACE_ELL && !sharded && g_defaults.auto_defer) {
         const bool lower = s->symv && s->apply_lower && (n % 2) == 0 && n >= s->symv_min_n;
         const int depth = lower ? 16 : (n >= 3072 ? 8 : 1);
         if (depth != 1) {
@@ -1355,7 +1112,7 @@ int ellhip_device_count(void) {
 
 const char* ellhip_last_error(void) { return g_last_error.c_str(); }
 
-const char* ellhip_version(void) { return "ellhip 0.2.0 gfx950"; }
+const char* ellhip_version(void) { return "ellhip 0.3.0 gfx950"; }
 
 int ellhip_create(ellhip_space** out, int variant, int64_t n, double kappa, const double* mq, const double* diag,
                   const double* xc, int device) {
@@ -1386,8 +1143,6 @@ void ellhip_destroy(ellhip_space* s) {
     }
     if (s->d_work) (void)hipFree(s->d_work);
     if (s->d_hpart) (void)hipFree(s->d_hpart);
-    if (s->d_arrived) (void)hipFree(s->d_arrived);
-    if (s->d_ftiles) (void)hipFree(s->d_ftiles);
     if (s->d_fnext) (void)hipFree(s->d_fnext);
     if (s->d_ftiles16) (void)hipFree(s->d_ftiles16);
     if (s->d_qhpart) (void)hipFree(s->d_qhpart);
@@ -1396,7 +1151,6 @@ void ellhip_destroy(ellhip_space* s) {
     if (s->d_cpend) (void)hipFree(s->d_cpend);
     if (s->d_rowpart) (void)hipFree(s->d_rowpart);
     if (s->d_colpart) (void)hipFree(s->d_colpart);
-    if (s->d_symv_ctl) (void)hipFree(s->d_symv_ctl);
     if (s->d_flags) (void)hipFree(s->d_flags);
     if (s->d_st) (void)hipFree(s->d_st);
     if (s->h_result) (void)hipHostFree(s->h_result);
@@ -1438,19 +1192,12 @@ int ellhip_clone(const ellhip_space* src_c, ellhip_space** out) {
     s->apply_lower = src->apply_lower;
     s->apply_kernel = src->apply_kernel;
     s->fuse_dots = src->fuse_dots;
-    s->symv_tail = src->symv_tail;
     s->shard_symmetric = src->shard_symmetric;
     s->upper_stale = src->upper_stale;
     s->symv_seg = src->symv_seg;
+    s->stable_solve = src->stable_solve;
+    s->stable_factor = src->stable_factor;
     rc = alloc_common(s);
-    if (!rc) {
-        s->stable_persist = src->stable_persist;
-        s->stable_pair = src->stable_pair;
-        s->stable_helpers = src->stable_helpers;
-        s->stable_factor_rows = src->stable_factor_rows;
-        s->stable_fused = src->stable_fused;
-        s->stable_bwd_helpers = src->stable_bwd_helpers;
-    }
     if (rc) {
         ellhip_destroy(s);
         return rc;
@@ -1598,17 +1345,8 @@ int ellhip_update_end(ellhip_space* s) {
 }
 
 int ellhip_update(ellhip_space* s, int kind, const double* grad, double beta0, int has_beta1, double beta1) {
-    if (s) s->allow_lazy = true;  // begin and end back to back: GEMV + scalar stage in one launch where there is one
     int rc = ellhip_update_begin(s, kind, grad, beta0, has_beta1, beta1);
     if (!rc) rc = ellhip_update_end(s);
-    else if (s) s->lazy_prime = false;
-    if (s) {
-        s->allow_lazy = false;
-        if (s->lazy_reduce) {
-            DeviceGuard guard(s->device);
-            (void)finish_lazy_reduce(s);
-        }
-    }
     return rc;
 }
 
@@ -1737,6 +1475,122 @@ int ellhip_set_shard_symmetric(ellhip_space* s, int flag) {
     return 0;
 }
 
+// ---- options ----------------------------------------------------------------------------------
+namespace {
+int option_ok(int key, long long v) {
+    switch (key) {
+        case ELLHIP_OPT_AUTO_DEFER: case ELLHIP_OPT_SYMV: case ELLHIP_OPT_APPLY_LOWER: case ELLHIP_OPT_APPLY_KERNEL:
+        case ELLHIP_OPT_FUSE_DOTS:
+            return (v == 0 || v == 1) ? 0 : fail(ELLHIP_E_INVALID, "option value must be 0 or 1");
+        case ELLHIP_OPT_SYMV_MIN_N: return v >= 512 ? 0 : fail(ELLHIP_E_INVALID, "ELLHIP_OPT_SYMV_MIN_N must be >= 512");
+        case ELLHIP_OPT_STABLE_SOLVE: case ELLHIP_OPT_STABLE_FACTOR:
+            return (v >= 0 && v <= 2) ? 0 : fail(ELLHIP_E_INVALID, "option value must be 0, 1 or 2");
+        case ELLHIP_OPT_PAD: return (v >= -1 && v <= 4096) ? 0 : fail(ELLHIP_E_INVALID, "ELLHIP_OPT_PAD: -1 .. 4096");
+        case ELLHIP_OPT_LP_GRID: return (v >= 0 && v <= 65536) ? 0 : fail(ELLHIP_E_INVALID, "ELLHIP_OPT_LP_GRID: 0 .. 65536");
+        case ELLHIP_OPT_LP_WIDE: return (v >= -1 && v <= 1) ? 0 : fail(ELLHIP_E_INVALID, "ELLHIP_OPT_LP_WIDE: -1, 0, 1");
+        case ELLHIP_OPT_BATCH_THREADS:
+            return (v == 0 || v == 64 || v == 128 || v == 256) ? 0 : fail(ELLHIP_E_INVALID, "ELLHIP_OPT_BATCH_THREADS: 0, 64, 128, 256");
+        default: return fail(ELLHIP_E_INVALID, "unknown option key");
+    }
+}
+}  // namespace
+
+int ellhip_set_default_option(int key, int64_t value) {
+    int rc = option_ok(key, value);
+    if (rc) return rc;
+    switch (key) {
+        case ELLHIP_OPT_AUTO_DEFER: g_defaults.auto_defer = (int)value; break;
+        case ELLHIP_OPT_SYMV: g_defaults.symv = (int)value; break;
+        case ELLHIP_OPT_SYMV_MIN_N: g_defaults.symv_min_n = value; break;
+        case ELLHIP_OPT_APPLY_LOWER: g_defaults.apply_lower = (int)value; break;
+        case ELLHIP_OPT_APPLY_KERNEL: g_defaults.apply_kernel = (int)value; break;
+        case ELLHIP_OPT_FUSE_DOTS: g_defaults.fuse_dots = (int)value; break;
+        case ELLHIP_OPT_STABLE_SOLVE: g_defaults.stable_solve = (int)value; break;
+        case ELLHIP_OPT_STABLE_FACTOR: g_defaults.stable_factor = (int)value; break;
+        case ELLHIP_OPT_PAD: g_defaults.pad = (int)value; break;
+        case ELLHIP_OPT_LP_GRID: g_defaults.lp_grid = (int)value; break;
+        case ELLHIP_OPT_LP_WIDE: g_defaults.lp_wide = (int)value; break;
+        case ELLHIP_OPT_BATCH_THREADS: g_defaults.batch_threads = (int)value; break;
+    }
+    return 0;
+}
+
+int ellhip_default_option(int key, int64_t* value) {
+    if (!value) return fail(ELLHIP_E_INVALID, "value is NULL");
+    switch (key) {
+        case ELLHIP_OPT_AUTO_DEFER: *value = g_defaults.auto_defer; break;
+        case ELLHIP_OPT_SYMV: *value = g_defaults.symv; break;
+        case ELLHIP_OPT_SYMV_MIN_N: *value = g_defaults.symv_min_n; break;
+        case ELLHIP_OPT_APPLY_LOWER: *value = g_defaults.apply_lower; break;
+        case ELLHIP_OPT_APPLY_KERNEL: *value = g_defaults.apply_kernel; break;
+        case ELLHIP_OPT_FUSE_DOTS: *value = g_defaults.fuse_dots; break;
+        case ELLHIP_OPT_STABLE_SOLVE: *value = g_defaults.stable_solve; break;
+        case ELLHIP_OPT_STABLE_FACTOR: *value = g_defaults.stable_factor; break;
+        case ELLHIP_OPT_PAD: *value = g_defaults.pad; break;
+        case ELLHIP_OPT_LP_GRID: *value = g_defaults.lp_grid; break;
+        case ELLHIP_OPT_LP_WIDE: *value = g_defaults.lp_wide; break;
+        case ELLHIP_OPT_BATCH_THREADS: *value = g_defaults.batch_threads; break;
+        default: return fail(ELLHIP_E_INVALID, "unknown option key");
+    }
+    return 0;
+}
+
+int ellhip_set_option(ellhip_space* s, int key, int64_t value) {
+    if (!s) return fail(ELLHIP_E_INVALID, "NULL handle");
+    int rc = option_ok(key, value);
+    if (rc) return rc;
+    DeviceGuard guard(s->device);
+    const bool ell = s->variant == ELLHIP_SPACE_ELL;
+    switch (key) {
+        case ELLHIP_OPT_SYMV: case ELLHIP_OPT_SYMV_MIN_N: case ELLHIP_OPT_APPLY_LOWER: case ELLHIP_OPT_APPLY_KERNEL:
+        case ELLHIP_OPT_FUSE_DOTS: {
+            if (!ell) return fail(ELLHIP_E_INVALID, "this option exists on Ell only");
+            if (s->in_two_phase) return fail(ELLHIP_E_STATE, "update_begin without update_end");
+            // what has been recorded (and a stale upper triangle) belongs to the schedule in force: make Q current first
+            rc = make_q_current(s);
+            if (rc) return rc;
+            if (key == ELLHIP_OPT_SYMV) s->symv = (int)value;
+            else if (key == ELLHIP_OPT_SYMV_MIN_N) s->symv_min_n = value;
+            else if (key == ELLHIP_OPT_APPLY_LOWER) s->apply_lower = (int)value;
+            else if (key == ELLHIP_OPT_APPLY_KERNEL) s->apply_kernel = (int)value;
+            else s->fuse_dots = (int)value;
+            if (s->defer > 1) {
+                rc = symv_alloc(s);  // (a lowered threshold may bring the lower-triangle schedule into reach)
+                if (rc) return rc;
+            }
+            if (s->defer == 16) {  // depth 16 exists on the lower-triangle schedule only: fall back to 8 where it is gone
+                const bool lower = s->symv && s->apply_lower && (s->n % 2) == 0 && s->d_rowpart &&
+                                   (s->sharded ? s->shard_symmetric : s->n >= s->symv_min_n);
+                if (!lower) s->defer = 8;
+            }
+            return 0;
+        }
+        case ELLHIP_OPT_STABLE_SOLVE: case ELLHIP_OPT_STABLE_FACTOR:
+            if (ell) return fail(ELLHIP_E_INVALID, "this option exists on EllStable only");
+            HIPCHK(hipStreamSynchronize(s->stream));
+            if (key == ELLHIP_OPT_STABLE_SOLVE) s->stable_solve = (int)value; else s->stable_factor = (int)value;
+            return 0;
+        default:
+            return fail(ELLHIP_E_INVALID, "this option is a creation-time default only (ellhip_set_default_option)");
+    }
+}
+
+int ellhip_get_option(const ellhip_space* s, int key, int64_t* value) {
+    if (!s || !value) return fail(ELLHIP_E_INVALID, "NULL argument");
+    switch (key) {
+        case ELLHIP_OPT_SYMV: *value = s->symv; break;
+        case ELLHIP_OPT_SYMV_MIN_N: *value = s->symv_min_n; break;
+        case ELLHIP_OPT_APPLY_LOWER: *value = s->apply_lower; break;
+        case ELLHIP_OPT_APPLY_KERNEL: *value = s->apply_kernel; break;
+        case ELLHIP_OPT_FUSE_DOTS: *value = s->fuse_dots; break;
+        case ELLHIP_OPT_STABLE_SOLVE: *value = s->stable_solve; break;
+        case ELLHIP_OPT_STABLE_FACTOR: *value = s->stable_factor; break;
+        case ELLHIP_OPT_PAD: *value = s->ld - s->n; break;
+        default: return fail(ELLHIP_E_INVALID, "not a per-handle option");
+    }
+    return 0;
+}
+
 int ellhip_set_use_parallel_cut(ellhip_space* s, int flag) {
     if (!s) return fail(ELLHIP_E_INVALID, "NULL handle");
     s->use_parallel_cut = flag ? 1 : 0;
@@ -1844,12 +1698,8 @@ int ellhip_queue_run(ellhip_space* s, int64_t first, int64_t count) {
     if (!s || first < 0 || count < 0 || first + count > s->qk) return fail(ELLHIP_E_INVALID, "queue range");
     DeviceGuard guard(s->device);
     for (int64_t i = first; i < first + count; ++i) {
-        s->allow_lazy = true;  // prime and cut back to back: launches that can share one do (do_prime / launch_symv / do_cut)
         int rc = queue_prime_impl(s, i);
         if (!rc) rc = queue_cut_impl(s, i);
-        s->allow_lazy = false;
-        s->lazy_prime = false;
-        if (!rc) rc = finish_lazy_reduce(s);  // (only if the cut failed to take it)
         if (!rc) rc = queue_commit_impl(s, i, -1);
         if (rc) return rc;
     }
@@ -1860,24 +1710,12 @@ int ellhip_queue_run_fused(ellhip_space* s, int64_t first, int64_t count) {
     if (!s || first < 0 || count < 0 || first + count > s->qk) return fail(ELLHIP_E_INVALID, "queue range");
     DeviceGuard guard(s->device);
     for (int64_t i = first; i < first + count; ++i) {
-        // Where one launch does GEMV + scalar stage (k_update_fused_def: recorded full-row schedule) nothing is gained by
-        // priming the next gradient inside this cut's commit -- there is no rank-1 pass to share -- so the cut is issued
-        // as in ellhip_queue_run; elsewhere the commit carries the next GEMV.
-        const bool one_launch = fused_update_ok(s) && !(s->primed && s->primed_qindex == i);
-        // (the lower-triangle GEMV the commit issues for the next cut leaves its reduction to that cut's scalar stage)
-        s->allow_lazy = one_launch || reduce_scalar_ok(s);
         int rc = queue_prime_impl(s, i);  // (pipelined form: only the first cut of a run pays a separate GEMV pass)
         if (!rc) rc = queue_cut_impl(s, i);
-        s->lazy_prime = false;
-        if (!rc && i + 1 >= first + count) s->allow_lazy = false;  // the last commit of the run primes eagerly
-        if (!rc) rc = queue_commit_impl(s, i, (!one_launch && i + 1 < s->qk) ? i + 1 : -1);
-        s->allow_lazy = false;
-        if (rc) {
-            (void)finish_lazy_reduce(s);
-            return rc;
-        }
+        if (!rc) rc = queue_commit_impl(s, i, (i + 1 < s->qk) ? i + 1 : -1);
+        if (rc) return rc;
     }
-    return finish_lazy_reduce(s);
+    return 0;
 }
 
 int ellhip_queue_results(ellhip_space* s, int32_t* status_out, double* tsq_out) {

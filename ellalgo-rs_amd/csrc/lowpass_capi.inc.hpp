@@ -252,11 +252,11 @@ int ellhip_lowpass_create(ellhip_lowpass** out, int64_t ndim, double wpass, doub
     o->P.up_sq = up_sq;
     const double a_bytes = (double)mdim * (double)o->P.ld * 8.0;
     o->nt = a_bytes > 200.0 * 1024 * 1024;  // same rule as the Q stream: larger than the Infinity Cache share
-    o->wide = env_int("ELLHIP_LP_WIDE", ndim >= LP_WIDE_N ? 1 : 0) != 0;
+    o->wide = g_defaults.lp_wide >= 0 ? g_defaults.lp_wide != 0 : ndim >= LP_WIDE_N;  // ELLHIP_OPT_LP_WIDE
     const long long per_step = o->wide ? LP_RPW : LP_CHUNK;
     const long long nchunks = (mdim + per_step - 1) / per_step;
     o->grid = (unsigned)(nchunks < 1024 ? nchunks : 1024);
-    o->grid = (unsigned)env_int("ELLHIP_LP_GRID", (int)o->grid);
+    if (g_defaults.lp_grid > 0) o->grid = (unsigned)g_defaults.lp_grid;  // ELLHIP_OPT_LP_GRID
     if (o->grid < 1) o->grid = 1;
     DeviceGuard guard(device);
     auto bail = [&](int code) {

@@ -9,6 +9,14 @@
 #include <dlfcn.h>
 
 #include <cmath>
+#include <mutex>
+
+// Where the real header is installed, the restated ABI below is checked against it at compile time (nothing of it is
+// used otherwise: the library is opened at run time).
+#if __has_include(<rccl/rccl.h>)
+#include <rccl/rccl.h>
+#define ELLHIP_HAVE_RCCL_H 1
+#endif
 
 namespace {
 
@@ -28,28 +36,46 @@ struct Rccl {
     std::string why;
 };
 constexpr int RCCL_DOUBLE = 8, RCCL_SUM = 0;
+#ifdef ELLHIP_HAVE_RCCL_H
+static_assert(sizeof(ncclUniqueId) == ELLHIP_NCCL_ID_BYTES && sizeof(IdBytes) == sizeof(ncclUniqueId), "ncclUniqueId is 128 bytes");
+static_assert((int)ncclDouble == RCCL_DOUBLE && (int)ncclSum == RCCL_SUM && (int)ncclSuccess == 0, "restated RCCL enums");
+static_assert(sizeof(ncclComm_t) == sizeof(void*) && sizeof(ncclResult_t) == sizeof(int) && sizeof(ncclDataType_t) == sizeof(int) &&
+                  sizeof(ncclRedOp_t) == sizeof(int), "restated RCCL handle / enum sizes");
+// the restated signatures convert to the real ones with the same argument list (enums <-> int, ncclComm_t <-> void*,
+// ncclUniqueId <-> IdBytes are layout-compatible by the asserts above)
+static_assert(std::is_same<decltype(&ncclAllGather), ncclResult_t (*)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t)>::value, "ncclAllGather");
+static_assert(std::is_same<decltype(&ncclAllReduce), ncclResult_t (*)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t)>::value, "ncclAllReduce");
+static_assert(std::is_same<decltype(&ncclCommInitRank), ncclResult_t (*)(ncclComm_t*, int, ncclUniqueId, int)>::value, "ncclCommInitRank");
+static_assert(std::is_same<decltype(&ncclGetUniqueId), ncclResult_t (*)(ncclUniqueId*)>::value, "ncclGetUniqueId");
+static_assert(std::is_same<decltype(&ncclCommDestroy), ncclResult_t (*)(ncclComm_t)>::value, "ncclCommDestroy");
+#endif
 
-Rccl* rccl() {
-    static Rccl r;
-    static bool tried = false;
-    if (tried) return &r;
-    tried = true;
-    const char* names[] = {"librccl.so.1", "librccl.so"};
-    for (const char* nm : names) {  // a copy the process has already mapped (PyTorch-ROCm's) is reused
-        r.lib = dlopen(nm, RTLD_NOW | RTLD_NOLOAD);
-        if (r.lib) break;
-    }
-    if (!r.lib) {
-        const char* env = getenv("ELLHIP_RCCL_PATH");
-        if (env && *env) r.lib = dlopen(env, RTLD_NOW | RTLD_GLOBAL);
+void rccl_open(Rccl& r) {
+    // ELLHIP_RCCL_PATH names the library to use (a non-default install, or a test double); otherwise a copy the process
+    // has already mapped (PyTorch-ROCm's) is reused, then the usual names are tried.
+    const char* env = getenv("ELLHIP_RCCL_PATH");
+    std::string err;
+    auto note = [&]() {
+        const char* e = dlerror();  // (returns the message ONCE and clears it)
+        if (e) err = e;
+    };
+    if (env && *env) {
+        r.lib = dlopen(env, RTLD_NOW | RTLD_GLOBAL);
+        if (!r.lib) note();
+    } else {
+        for (const char* nm : {"librccl.so.1", "librccl.so"}) {
+            r.lib = dlopen(nm, RTLD_NOW | RTLD_NOLOAD);
+            if (r.lib) break;
+        }
         for (const char* nm : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
             if (r.lib) break;
             r.lib = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
+            if (!r.lib) note();
         }
     }
     if (!r.lib) {
-        r.why = std::string("librccl could not be opened: ") + (dlerror() ? dlerror() : "?");
-        return &r;
+        r.why = std::string("librccl could not be opened: ") + (err.empty() ? "?" : err);
+        return;
     }
     auto sym = [&](const char* nm) -> void* {
         void* p = dlsym(r.lib, nm);
@@ -62,6 +88,12 @@ Rccl* rccl() {
     r.AllGather = reinterpret_cast<decltype(r.AllGather)>(sym("ncclAllGather"));
     r.AllReduce = reinterpret_cast<decltype(r.AllReduce)>(sym("ncclAllReduce"));
     r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(sym("ncclGetErrorString"));
+}
+
+Rccl* rccl() {
+    static Rccl r;
+    static std::once_flag once;
+    std::call_once(once, [] { rccl_open(r); });
     return &r;
 }
 
@@ -80,16 +112,28 @@ struct ellhip_sharded {
     long long n = 0, row0 = 0, nrows = 0;
     void* comm = nullptr;
     bool own_comm = false;
-    long long qk = 0, primed_index = -1;
+    // host-supplied collective (ellhip_sharded_create_custom / ellhip_sharded_set_collective): used instead of RCCL
+    ellhip_allgather_fn user_allgather = nullptr;
+    ellhip_allreduce_fn user_allreduce = nullptr;
+    void* user_ctx = nullptr;
+    long long qk = 0;
 };
 
 namespace {
 
 // the collective of one update: in place on the buffer that holds Q*g of the gradient just primed
 int shard_exchange(ellhip_sharded* s) {
+    double* gt = ellhip_gt_dev(s->sh);
+    if (s->user_allgather || s->user_allreduce) {
+        DeviceGuard guard(s->sh->device);
+        const int urc = (s->partition == ELLHIP_SHARD_SYMMETRIC)
+                            ? s->user_allreduce(s->user_ctx, gt, s->n, s->sh->stream)
+                            : s->user_allgather(s->user_ctx, gt, s->row0, s->nrows, s->sh->stream);
+        if (urc != 0) return fail(ELLHIP_E_NORCCL, "the host-supplied collective reported a failure");
+        return 0;
+    }
     if (!s->comm) return 0;  // one rank, no communicator: the local pass already produced the whole vector
     Rccl* r = rccl();
-    double* gt = ellhip_gt_dev(s->sh);
     DeviceGuard guard(s->sh->device);
     int rc;
     if (s->partition == ELLHIP_SHARD_SYMMETRIC)
@@ -100,9 +144,13 @@ int shard_exchange(ellhip_sharded* s) {
     return 0;
 }
 
-// A shard whose recorded updates were applied by an observer (flush, get_mq_rows, a depth change) has dropped its
-// primed GEMV (it belonged to the old base): the next queue_run_fused primes -- and exchanges -- again.
-void sync_primed(ellhip_sharded* s) { s->primed_index = ellhip_queue_primed(s->sh); }
+// Invariant of this file: whenever the shard handle has a primed gradient (ellhip_queue_primed >= 0, or a direct
+// gradient between update_begin and update_end), its vector HAS been exchanged -- every call that runs a GEMV is
+// followed by shard_exchange before anything else happens.  So "is cut i primed?" is asked of the shard handle itself
+// (a shard whose recorded updates were applied by an observer -- flush, get_mq_rows, a depth change -- has dropped its
+// prime, a direct update or a halted queue leaves none): nothing is cached here that could go stale, and a vector that
+// is already complete is never exchanged twice (an all-reduce is not idempotent).
+bool shard_primed(const ellhip_sharded* s, long long index) { return ellhip_queue_primed(s->sh) == index; }
 
 }  // namespace
 
@@ -154,16 +202,23 @@ int ellhip_sharded_unique_id(void* id_out) {
     return 0;
 }
 
-int ellhip_sharded_create(ellhip_sharded** out, int64_t n, double kappa, const double* mq_rows, const double* diag,
-                          const double* xc, int device, int rank, int nranks, const void* nccl_id, void* nccl_comm,
-                          int partition, int defer_depth) {
+}  // extern "C"
+
+namespace {
+int sharded_create_impl(ellhip_sharded** out, int64_t n, double kappa, const double* mq_rows, const double* diag,
+                        const double* xc, int device, int rank, int nranks, const void* nccl_id, void* nccl_comm,
+                        int partition, int defer_depth, ellhip_allgather_fn ag, ellhip_allreduce_fn ar, void* ctx) {
     if (!out) return fail(ELLHIP_E_INVALID, "out is NULL");
     *out = nullptr;
+    const bool custom = ag || ar;
+    if (custom && (!ag || !ar)) return fail(ELLHIP_E_INVALID, "a host-supplied collective needs both callbacks");
     if (nccl_id && nccl_comm) return fail(ELLHIP_E_INVALID, "give either the unique id or a communicator, not both");
-    if (nranks > 1 && !nccl_id && !nccl_comm) return fail(ELLHIP_E_INVALID, "more than one rank needs a communicator");
+    if (nranks > 1 && !nccl_id && !nccl_comm && !custom) return fail(ELLHIP_E_INVALID, "more than one rank needs a communicator");
     if (defer_depth != 1 && defer_depth != 8 && defer_depth != 16) return fail(ELLHIP_E_INVALID, "defer depth must be 1, 8 or 16");
     if (partition == ELLHIP_SHARD_SYMMETRIC && defer_depth == 1)
         return fail(ELLHIP_E_INVALID, "symmetric row shards run the recorded schedule only (depth 8 or 16)");
+    if (partition == ELLHIP_SHARD_SYMMETRIC && n < 512)
+        return fail(ELLHIP_E_INVALID, "symmetric row shards: the lower-triangle schedule needs n >= 512");
     int64_t row0 = 0, nrows = 0;
     int rc = ellhip_sharded_partition(n, nranks, rank, partition, &row0, &nrows);
     if (rc) return rc;
@@ -175,6 +230,9 @@ int ellhip_sharded_create(ellhip_sharded** out, int64_t n, double kappa, const d
     s->n = n;
     s->row0 = row0;
     s->nrows = nrows;
+    s->user_allgather = ag;
+    s->user_allreduce = ar;
+    s->user_ctx = ctx;
     rc = ellhip_create_shard(&s->sh, n, row0, nrows, kappa, mq_rows, diag, xc, device);
     if (!rc && partition == ELLHIP_SHARD_SYMMETRIC) rc = ellhip_set_shard_symmetric(s->sh, 1);
     if (!rc && defer_depth != 1) rc = ellhip_set_defer_depth(s->sh, defer_depth);
@@ -198,6 +256,37 @@ int ellhip_sharded_create(ellhip_sharded** out, int64_t n, double kappa, const d
         return rc;
     }
     *out = s;
+    return 0;
+}
+}  // namespace
+
+extern "C" {
+
+int ellhip_sharded_create(ellhip_sharded** out, int64_t n, double kappa, const double* mq_rows, const double* diag,
+                          const double* xc, int device, int rank, int nranks, const void* nccl_id, void* nccl_comm,
+                          int partition, int defer_depth) {
+    return sharded_create_impl(out, n, kappa, mq_rows, diag, xc, device, rank, nranks, nccl_id, nccl_comm, partition,
+                               defer_depth, nullptr, nullptr, nullptr);
+}
+
+int ellhip_sharded_create_custom(ellhip_sharded** out, int64_t n, double kappa, const double* mq_rows, const double* diag,
+                                 const double* xc, int device, int rank, int nranks, int partition, int defer_depth,
+                                 ellhip_allgather_fn allgather, ellhip_allreduce_fn allreduce, void* ctx) {
+    if (!allgather || !allreduce) return fail(ELLHIP_E_INVALID, "both collective callbacks are required");
+    return sharded_create_impl(out, n, kappa, mq_rows, diag, xc, device, rank, nranks, nullptr, nullptr, partition,
+                               defer_depth, allgather, allreduce, ctx);
+}
+
+int ellhip_sharded_set_collective(ellhip_sharded* s, ellhip_allgather_fn allgather, ellhip_allreduce_fn allreduce, void* ctx) {
+    if (!s) return fail(ELLHIP_E_INVALID, "NULL handle");
+    if ((allgather == nullptr) != (allreduce == nullptr)) return fail(ELLHIP_E_INVALID, "give both callbacks, or neither");
+    if (!allgather && s->nranks > 1 && !s->comm)
+        return fail(ELLHIP_E_INVALID, "this handle has no RCCL communicator to fall back to");
+    int rc = ellhip_synchronize(s->sh);
+    if (rc) return rc;
+    s->user_allgather = allgather;
+    s->user_allreduce = allreduce;
+    s->user_ctx = ctx;
     return 0;
 }
 
@@ -231,21 +320,15 @@ int ellhip_sharded_set_xc(ellhip_sharded* s, const double* xc) {
 }
 int ellhip_sharded_get_mq_rows(ellhip_sharded* s, double* rows_out) {
     if (!s) return fail(ELLHIP_E_INVALID, "NULL handle");
-    const int rc = ellhip_get_mq(s->sh, rows_out);
-    sync_primed(s);
-    return rc;
+    return ellhip_get_mq(s->sh, rows_out);
 }
 int ellhip_sharded_set_defer_depth(ellhip_sharded* s, int depth) {
     if (!s) return fail(ELLHIP_E_INVALID, "NULL handle");
-    const int rc = ellhip_set_defer_depth(s->sh, depth);
-    sync_primed(s);
-    return rc;
+    return ellhip_set_defer_depth(s->sh, depth);
 }
 int ellhip_sharded_flush(ellhip_sharded* s) {
     if (!s) return fail(ELLHIP_E_INVALID, "NULL handle");
-    const int rc = ellhip_flush(s->sh);
-    sync_primed(s);
-    return rc;
+    return ellhip_flush(s->sh);
 }
 
 int ellhip_sharded_queue_upload(ellhip_sharded* s, int64_t k, const int32_t* kinds, const double* grads,
@@ -254,19 +337,20 @@ int ellhip_sharded_queue_upload(ellhip_sharded* s, int64_t k, const int32_t* kin
     const int rc = ellhip_queue_upload(s->sh, k, kinds, grads, beta0, has_beta1, beta1);
     if (rc) return rc;
     s->qk = k;
-    s->primed_index = -1;
     return 0;
 }
 
 int ellhip_sharded_queue_run(ellhip_sharded* s, int64_t first, int64_t count) {
     if (!s || first < 0 || count < 0 || first + count > s->qk) return fail(ELLHIP_E_INVALID, "queue range");
     for (int64_t i = first; i < first + count; ++i) {
+        // cut i may already be primed AND exchanged (a preceding queue_run_fused primes the cut after its last one):
+        // begin is then a no-op and the complete vector must not be exchanged again
+        const bool ready = shard_primed(s, i);
         int rc = ellhip_queue_begin(s->sh, i);
-        if (!rc) rc = shard_exchange(s);
+        if (!rc && !ready) rc = shard_exchange(s);
         if (!rc) rc = ellhip_queue_end(s->sh, i);
         if (rc) return rc;
     }
-    s->primed_index = -1;
     return 0;
 }
 
@@ -275,7 +359,7 @@ int ellhip_sharded_queue_run_fused(ellhip_sharded* s, int64_t first, int64_t cou
     if (count == 0) return 0;
     int rc = 0;
     // pipelined: one pass over the local rows per cut; the collective follows whichever call ran a GEMV
-    if (s->primed_index != first) {
+    if (!shard_primed(s, first)) {
         rc = ellhip_queue_prime(s->sh, first);
         if (!rc) rc = shard_exchange(s);
         if (rc) return rc;
@@ -286,20 +370,13 @@ int ellhip_sharded_queue_run_fused(ellhip_sharded* s, int64_t first, int64_t cou
         if (!rc) rc = ellhip_queue_commit(s->sh, i, nxt);
         if (!rc && nxt >= 0) rc = shard_exchange(s);
         if (rc) return rc;
-        s->primed_index = nxt;
     }
     return 0;
 }
 
 int ellhip_sharded_queue_results(ellhip_sharded* s, int32_t* status_out, double* tsq_out) {
     if (!s) return fail(ELLHIP_E_INVALID, "NULL handle");
-    std::vector<int32_t> st((size_t)std::max<long long>(s->qk, 1));
-    const int rc = ellhip_queue_results(s->sh, st.data(), tsq_out);
-    if (rc) return rc;
-    for (long long i = 0; i < s->qk; ++i)
-        if (st[(size_t)i] > 0) s->primed_index = -1;  // the queue halted: nothing stays primed
-    if (status_out) memcpy(status_out, st.data(), (size_t)s->qk * sizeof(int32_t));
-    return 0;
+    return ellhip_queue_results(s->sh, status_out, tsq_out);
 }
 
 int ellhip_sharded_synchronize(ellhip_sharded* s) {

@@ -166,6 +166,15 @@ class _SpaceBase:
     def set_use_parallel_cut(self, flag: bool) -> None:
         capi.check(self._lib.ellhip_set_use_parallel_cut(self._h, int(flag)))
 
+    def set_option(self, key: int, value: int) -> None:
+        """ellhip_set_option (keys: capi.OPT_*)"""
+        capi.check(self._lib.ellhip_set_option(self._h, int(key), int(value)), "ellhip_set_option")
+
+    def get_option(self, key: int) -> int:
+        v = C.c_int64()
+        capi.check(self._lib.ellhip_get_option(self._h, int(key), C.byref(v)), "ellhip_get_option")
+        return int(v.value)
+
     # ---- device-resident cut queue
     def queue_upload(self, kinds, grads, beta0, beta1=None) -> int:
         """beta1: array with NaN where the cut has no second value, or None."""

@@ -142,14 +142,21 @@ class EllShardGroup {
     EllShardGroup(double kappa, const double* mq, const double* diag, const Arr& xc, const std::vector<int>& devices)
         : n_(xc.size()) {
         const int P = (int)devices.size();
-        for (int r = 0; r < P; ++r) {
-            int64_t r0 = 0, nr = 0;
-            check(ellhip_sharded_partition((int64_t)n_, P, r, ELLHIP_SHARD_EQUAL_BLOCKS, &r0, &nr), "ellhip_sharded_partition");
-            ellhip_space* s = nullptr;
-            check(ellhip_create_shard(&s, (int64_t)n_, r0, nr, kappa, mq ? mq + (std::size_t)r0 * n_ : nullptr, diag,
-                                      xc.data(), devices[(std::size_t)r]), "ellhip_create_shard");
-            sh_.push_back(s);
-            nrows_.push_back((std::size_t)nr);
+        if (P < 1) throw Error(ELLHIP_E_INVALID, "EllShardGroup: at least one row block (device) is required");
+        try {
+            for (int r = 0; r < P; ++r) {
+                int64_t r0 = 0, nr = 0;
+                check(ellhip_sharded_partition((int64_t)n_, P, r, ELLHIP_SHARD_EQUAL_BLOCKS, &r0, &nr), "ellhip_sharded_partition");
+                ellhip_space* s = nullptr;
+                check(ellhip_create_shard(&s, (int64_t)n_, r0, nr, kappa, mq ? mq + (std::size_t)r0 * n_ : nullptr, diag,
+                                          xc.data(), devices[(std::size_t)r]), "ellhip_create_shard");
+                sh_.push_back(s);
+                nrows_.push_back((std::size_t)nr);
+            }
+        } catch (...) {  // (the destructor does not run for a constructor that throws: release the blocks made so far)
+            for (ellhip_space* s : sh_) ellhip_destroy(s);
+            sh_.clear();
+            throw;
         }
     }
     template <class Cut>

@@ -157,8 +157,8 @@ int ellhip_commit(ellhip_space *s, const double *next_grad);
  * depth = 1: Q is rewritten at every successful cut, exactly as src/ell.rs:117-128 does.  This is what a new handle
  * starts with, EXCEPT an unsharded Ell handle with n >= 3072: it starts at depth 16 when n is even and >= 8192 and
  * at depth 8 otherwise (the fastest schedules at those sizes; same results to the parity tolerance).
- * ELLHIP_AUTO_DEFER=0 in the environment makes every handle start at depth 1; ellhip_set_defer_depth(h, 1) does
- * it for one handle.
+ * ellhip_set_default_option(ELLHIP_OPT_AUTO_DEFER, 0) makes every later handle start at depth 1;
+ * ellhip_set_defer_depth(h, 1) does it for one handle.
  * depth = 8: successful cuts are RECORDED as pairs (sigma/omega, gt); the next GEMV reads the unchanged
  * matrix (a read-only pass) and is corrected with the recorded pairs,
  *     gt = Q_base*g - sum_j c_j (v_j.g) v_j ,   omega = g.(Q_base*g) - sum_j c_j (v_j.g)^2 ,
@@ -198,6 +198,49 @@ int64_t ellhip_queue_primed(const ellhip_space *s);
  * too: ellhip_get_mq on such a shard returns rows that are current up to their diagonal (the mirrored elements
  * live on other ranks).  Depth-1 schedules and no_defer_trick are refused (ELLHIP_E_STATE). */
 int ellhip_set_shard_symmetric(ellhip_space *s, int flag);
+
+/* ---- options ----------------------------------------------------------------------------------
+ * Schedule / kernel-form choices a host may want to pin (A/B measurements, bit-identity tests between forms, a
+ * device on which a form misbehaves).  Every option has the measured-best value as its default; nothing is read
+ * from the environment.  ellhip_set_option changes ONE handle (Q is made current first, so it is legal at any
+ * point between updates); ellhip_set_default_option changes what handles created LATER in this process start
+ * with (process-wide, call it before creating handles from other threads).
+ *   key                          values     default  meaning
+ *   ELLHIP_OPT_AUTO_DEFER        0 / 1      1        default only: 0 = every new handle starts at depth 1 (the
+ *                                                    reference's data flow) instead of 16 / 8 by size
+ *   ELLHIP_OPT_SYMV              0 / 1      1        Ell: lower-triangle GEMV on the recorded schedule (4 n^2 bytes)
+ *   ELLHIP_OPT_SYMV_MIN_N        >= 512     8192     Ell: smallest n of an unsharded handle that takes it
+ *   ELLHIP_OPT_APPLY_LOWER       0 / 1      1        Ell: apply passes touch the lower triangle only (8 n^2 bytes)
+ *   ELLHIP_OPT_APPLY_KERNEL      0 / 1      1        Ell, depth 8: 1 = k_apply_lower (16-row tiles), 0 = k_sweep_apply
+ *   ELLHIP_OPT_FUSE_DOTS         0 / 1      1        Ell: the scalar stage's dot products come out of the GEMV's launch
+ *   ELLHIP_OPT_STABLE_SOLVE      0 / 1 / 2  2        EllStable: 0 = one launch per 128-block (no in-launch waits),
+ *                                                    1 = persistent solves, 2 = persistent + helper workgroups
+ *   ELLHIP_OPT_STABLE_FACTOR     0 / 1 / 2  2        EllStable factor update: 0 = tile kernel reading the scratch
+ *                                                    triangle (the reference's data flow, 12 n^2 bytes), 1 = row kernel
+ *                                                    from U alone (8 n^2) beside the backward solve, 2 = pulled inside
+ *                                                    the helped backward solve's launch
+ *   ELLHIP_OPT_PAD               -1 .. 4096 -1       default only: extra doubles per row of Q (-1 = by size)
+ *   ELLHIP_OPT_LP_GRID           0 .. 65536 0        default only: workgroups per LowpassOracle scan launch (0 = by size)
+ *   ELLHIP_OPT_LP_WIDE           -1 / 0 / 1 -1       default only: column-split LowpassOracle scan kernel (-1 = by size)
+ *   ELLHIP_OPT_BATCH_THREADS     0/64/128/256 0      default only: threads per workgroup of the batched engine
+ * All forms of one option produce identical bits, except SYMV / SYMV_MIN_N (the lower-triangle GEMV sums Q*g in
+ * another association than the full-row GEMV: results agree to ~1e-15, see "deferred shrink" above). */
+#define ELLHIP_OPT_AUTO_DEFER 1
+#define ELLHIP_OPT_SYMV 2
+#define ELLHIP_OPT_SYMV_MIN_N 3
+#define ELLHIP_OPT_APPLY_LOWER 4
+#define ELLHIP_OPT_APPLY_KERNEL 5
+#define ELLHIP_OPT_FUSE_DOTS 6
+#define ELLHIP_OPT_STABLE_SOLVE 7
+#define ELLHIP_OPT_STABLE_FACTOR 8
+#define ELLHIP_OPT_PAD 9
+#define ELLHIP_OPT_LP_GRID 10
+#define ELLHIP_OPT_LP_WIDE 11
+#define ELLHIP_OPT_BATCH_THREADS 12
+int ellhip_set_option(ellhip_space *s, int key, int64_t value);
+int ellhip_get_option(const ellhip_space *s, int key, int64_t *value);
+int ellhip_set_default_option(int key, int64_t value);
+int ellhip_default_option(int key, int64_t *value);
 
 /* ---- device-resident cut queue (benchmarks, replay of recorded cut sequences) ---------------
  * Uploads k cuts once; run/begin/end then execute them without touching host memory, stopping

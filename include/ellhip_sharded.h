@@ -57,6 +57,25 @@ int ellhip_sharded_create(ellhip_sharded **out, int64_t n, double kappa, const d
                           int partition, int defer_depth);
 void ellhip_sharded_destroy(ellhip_sharded *s);
 
+/* The same with a HOST-SUPPLIED collective instead of RCCL (an MPI host, another transport, a test double that lets
+ * several ranks share one GPU -- RCCL refuses two ranks per device).  The library calls the callbacks where it would
+ * call ncclAllGather / ncclAllReduce: once per update, on the calling host thread, between the local pass and the
+ * scalar stage.  `vec_dev` is this rank's n-vector in DEVICE memory; the local pass that produced it has been
+ * ENQUEUED on `hip_stream` (a hipStream_t) and the work that consumes it will be enqueued there after the callback
+ * returns: a callback either enqueues its own work on that stream, or synchronises it, exchanges, and returns.
+ *   allgather  in place: this rank contributed vec_dev[offset, offset + count) (its rows; every rank has the same
+ *              count, rank r's offset is r * count); on return the vector holds every rank's part
+ *   allreduce  in place: on return vec_dev[0, count) holds the element-wise SUM over the ranks, the same bits on
+ *              every rank (the scalar stage runs redundantly and must see identical input)
+ * Both return 0 on success; anything else fails the update with ELLHIP_E_NORCCL.  Both callbacks are required. */
+typedef int (*ellhip_allgather_fn)(void *ctx, double *vec_dev, int64_t offset, int64_t count, void *hip_stream);
+typedef int (*ellhip_allreduce_fn)(void *ctx, double *vec_dev, int64_t count, void *hip_stream);
+int ellhip_sharded_create_custom(ellhip_sharded **out, int64_t n, double kappa, const double *mq_rows, const double *diag,
+                                 const double *xc, int device, int rank, int nranks, int partition, int defer_depth,
+                                 ellhip_allgather_fn allgather, ellhip_allreduce_fn allreduce, void *ctx);
+/* Replace the collective of an existing handle (both NULL: back to the handle's RCCL communicator). */
+int ellhip_sharded_set_collective(ellhip_sharded *s, ellhip_allgather_fn allgather, ellhip_allreduce_fn allreduce, void *ctx);
+
 /* SearchSpace (src/cutting_plane.rs:154-182); collective: every rank passes the same cut */
 int ellhip_sharded_update(ellhip_sharded *s, int kind, const double *grad, double beta0, int has_beta1, double beta1);
 double ellhip_sharded_tsq(const ellhip_sharded *s);

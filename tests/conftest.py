@@ -42,3 +42,19 @@ def orc():
     from oracle import oracle
     oracle.lib()
     return oracle
+
+
+FACTORY_DEFAULTS = {"AUTO_DEFER": 1, "SYMV": 1, "SYMV_MIN_N": 8192, "APPLY_LOWER": 1, "APPLY_KERNEL": 1, "FUSE_DOTS": 1,
+                    "STABLE_SOLVE": 2, "STABLE_FACTOR": 2, "PAD": -1, "LP_GRID": 0, "LP_WIDE": -1, "BATCH_THREADS": 0}
+
+
+@pytest.fixture(autouse=True)
+def _factory_default_options(request):
+    """Tests pin kernel forms with ellhip_set_default_option (tests/util.py: set_default); every test starts from and
+    leaves behind the library's factory defaults."""
+    yield
+    if "ellalgo_rs_amd" in sys.modules:
+        capi = sys.modules["ellalgo_rs_amd"].capi
+        if capi._lib is not None:
+            for name, v in FACTORY_DEFAULTS.items():
+                capi.set_default_option(getattr(capi, "OPT_" + name), v)

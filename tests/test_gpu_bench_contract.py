@@ -15,7 +15,7 @@ COMMON = {"metric": str, "value": float, "unit": str, "n_gpus": int, "steps": in
           "higher_is_better": bool, "scaling": str, "dtype": str, "data": str, "config": dict, "roofline": dict}
 
 
-def run_bench(*args, timeout=600):
+def run_bench(*args, timeout=900):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], capture_output=True, text=True,
                        timeout=timeout, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
@@ -49,6 +49,19 @@ def test_headline_workload_contract():
     assert c["kind"] == "port" and c["cores"] == 1 and c["unit"] == "updates/s" and c["value"] > 0 and c["sample"]
     assert c["all_cores"]["threads"] >= 1 and "NOT the reference" in c["all_cores"]["note"]
     assert d["host_call_path"]["updates_per_s"] > 0
+    assert r["traffic_measured_in_this_run"] is False and r["per_kernel"]["symv"]["avg_ms"] > 0
+    # 16 timed steps at depth 16 hold ONE apply pass: (16 * 4 n^2 + 1 * 8 n^2) / 16 = 4.5 n^2 per update
+    assert abs(r["whole_update"]["alg_bytes_per_gpu"] - 4.5 * 16384 ** 2) < 1.0
+    # the default invocation carries BASELINE.json's other configurations in the same line
+    oc = {o["workload"]: o for o in d["other_configs"]}
+    assert set(oc) == {"n4096-deep", "n32768-deep", "n16384-ellstable"}
+    for wl, o in oc.items():
+        assert o["updates_per_s"] > 0 and abs(o["updates_per_s"] - 1e3 / o["ms_per_step"]) < 1e-6 * o["updates_per_s"]
+        ro = o["roofline"]
+        assert 0.0 < ro["frac"] < 1.0 and ro["kernel"] and 0.0 < ro["whole_update"]["frac"] < 1.0
+    assert oc["n32768-deep"]["defer_depth"] == 16 and oc["n4096-deep"]["defer_depth"] == 8
+    # 64 steps at depth 16: four apply passes, (64 * 4 + 4 * 8) / 64 = 4.5
+    assert abs(oc["n32768-deep"]["roofline"]["whole_update"]["alg_bytes"] - 4.5 * 32768 ** 2) < 1.0
 
 
 @pytest.mark.parametrize("workload,args", [("n4096-deep", ("--steps", "40", "--warmup", "8", "--compare-steps", "0")),

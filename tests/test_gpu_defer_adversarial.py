@@ -20,7 +20,7 @@ from util import rel_inf
 
 pytestmark = pytest.mark.gpu
 
-FACTOR = 4.0     # default-depth error may exceed the depth-1 error by at most this factor ...
+FACTOR = 2.0     # default-depth error may exceed the depth-1 error by at most this factor ...
 FLOOR = 1e-10    # ... unless it is within the north-star tolerance anyway
 
 

@@ -6,7 +6,7 @@ import ctypes as C
 import numpy as np
 import pytest
 
-from util import assert_state_close, run_mixed
+from util import assert_state_close, run_mixed, set_default
 
 pytestmark = pytest.mark.gpu
 
@@ -26,7 +26,7 @@ def test_deferred_mixed_sequence_matches_oracle(gpu, orc, n):
 @pytest.mark.parametrize("n", [512, 1000, 2112, 4096])
 def test_deferred_symv_mixed_sequence_matches_oracle(gpu, orc, n, monkeypatch):
     """Depth 8 with the lower-triangle GEMV forced on at small sizes (default threshold n >= 8192)."""
-    monkeypatch.setenv("ELLHIP_SYMV_MIN_N", "512")
+    set_default("SYMV_MIN_N", 512)
     xc0 = np.linspace(-1.0, 1.0, n)
     g = gpu.Ell.new_with_scalar(2.0, xc0)
     g.defer_depth = 8
@@ -145,7 +145,7 @@ def test_deferred_row_shards_bit_identical_to_one_shard_and_close_to_unsharded(g
     L = pkg.capi.load()
     n, half = 1024, 512
     rng = np.random.default_rng(9)
-    monkeypatch.setenv("ELLHIP_SYMV_MIN_N", "512")
+    set_default("SYMV_MIN_N", 512)
     ref = pkg.Ell.new_with_scalar(1.5, np.zeros(n))
     ref.defer_depth = 8
 
@@ -196,13 +196,13 @@ def test_symv_equals_full_gemv_to_rounding(gpu, monkeypatch):
     from ellalgo_rs_amd import synth
     n, k = 2048 + 64, 20          # not a multiple of the segment width: exercises the ragged diagonal segment
     kinds, grads, b0, b1 = synth.parallel_cuts(n, k)
-    monkeypatch.setenv("ELLHIP_SYMV_MIN_N", "512")   # the default threshold (8192) would skip it at this size
+    set_default("SYMV_MIN_N", 512)   # the default threshold (8192) would skip it at this size
     a = gpu.Ell.new_with_scalar(1.0, np.zeros(n))
     a.defer_depth = 8
-    monkeypatch.setenv("ELLHIP_SYMV", "0")
+    set_default("SYMV", 0)
     b = gpu.Ell.new_with_scalar(1.0, np.zeros(n))
     b.defer_depth = 8
-    monkeypatch.delenv("ELLHIP_SYMV")
+    set_default("SYMV", 1)
     for i in range(k):
         cut = (grads[i], (b0[i], b1[i]))
         assert int(a._update(int(kinds[i]), cut)) == int(b._update(int(kinds[i]), cut)) == 0
@@ -218,7 +218,7 @@ def test_symv_equals_full_gemv_to_rounding(gpu, monkeypatch):
 def test_lower_triangle_schedule_depths_match_oracle(gpu, orc, n, depth, monkeypatch):
     """k_symv + k_apply_lower (16-row tiles) at depth 8 and 16, forced on at small sizes; get_mq in between
     exercises the mirror at every phase of the pending count."""
-    monkeypatch.setenv("ELLHIP_SYMV_MIN_N", "512")
+    set_default("SYMV_MIN_N", 512)
     xc0 = np.linspace(-1.0, 1.0, n)
     g = gpu.Ell.new_with_scalar(2.0, xc0)
     g.defer_depth = depth
@@ -241,13 +241,13 @@ def test_depth16_needs_the_lower_triangle_schedule(gpu):
 def test_apply_kernels_agree_bit_for_bit(gpu, monkeypatch):
     """k_apply_lower (16-row tiles) and k_sweep_apply<LOWER> (4-row tiles) put every lower-triangle element through
     the same roundings."""
-    monkeypatch.setenv("ELLHIP_SYMV_MIN_N", "512")
+    set_default("SYMV_MIN_N", 512)
     n, k = 1536, 24
     from ellalgo_rs_amd import synth
     kinds, grads, b0, b1 = synth.parallel_cuts(n, k)
     outs = []
     for kern in ("0", "1"):
-        monkeypatch.setenv("ELLHIP_APPLY_KERNEL", kern)
+        set_default("APPLY_KERNEL", int(kern))
         e = gpu.Ell.new_with_scalar(1.0, np.zeros(n))
         e.defer_depth = 8
         e.queue_upload(kinds, grads, b0, b1)
@@ -260,7 +260,7 @@ def test_apply_kernels_agree_bit_for_bit(gpu, monkeypatch):
 
 def test_default_depth_of_new_handles(gpu, monkeypatch):
     """ellhip_create: depth 16 wherever the lower-triangle schedule exists (unsharded Ell, even n >= 8192), depth 8
-    for other n >= 3072, else the reference's data flow; ELLHIP_AUTO_DEFER=0 keeps depth 1 everywhere; clones
+    for other n >= 3072, else the reference's data flow; ELLHIP_OPT_AUTO_DEFER = 0 keeps depth 1 everywhere; clones
     inherit; the setter overrides."""
     assert gpu.Ell.new_with_scalar(1.0, np.zeros(2048)).defer_depth == 1
     assert gpu.Ell.new_with_scalar(1.0, np.zeros(4096)).defer_depth == 8      # 3072 <= n < 8192: full-row GEMVs, depth 8
@@ -269,9 +269,9 @@ def test_default_depth_of_new_handles(gpu, monkeypatch):
     assert e.defer_depth == 16 and e.clone().defer_depth == 16
     e.defer_depth = 1
     assert e.defer_depth == 1 and e.clone().defer_depth == 1
-    monkeypatch.setenv("ELLHIP_AUTO_DEFER", "0")
+    set_default("AUTO_DEFER", 0)
     assert gpu.Ell.new_with_scalar(1.0, np.zeros(8192)).defer_depth == 1
-    monkeypatch.delenv("ELLHIP_AUTO_DEFER")
+    set_default("AUTO_DEFER", 1)
     # a caller-supplied NON-symmetric matrix: the first successful update mirrors it as the reference does, then
     # the recorded schedule takes over -- same state as depth 1 to rounding
     n = 8192
@@ -298,7 +298,7 @@ def test_observers_between_prime_and_cut_keep_the_primed_gradient_valid(gpu, orc
     recompute y: the sequence has to come out the same as the undisturbed one."""
     from ellalgo_rs_amd import synth
     from util import TOL
-    monkeypatch.setenv("ELLHIP_SYMV_MIN_N", "512")
+    set_default("SYMV_MIN_N", 512)
     n, k = 1024, 30
     kinds, grads, b0, b1 = synth.parallel_cuts(n, k)
     a = gpu.Ell.new_with_scalar(1.0, np.zeros(n))
@@ -385,7 +385,7 @@ def test_long_run_stays_inside_the_parity_tolerance(gpu, orc, depth, monkeypatch
     incl. the lower-triangle one) and checks the state against the oracle at 100, 300 and 600: the rounding
     differences of the GEMV orders do not accumulate beyond the 1e-10 tolerance."""
     from ellalgo_rs_amd import synth
-    monkeypatch.setenv("ELLHIP_SYMV_MIN_N", "512")
+    set_default("SYMV_MIN_N", 512)
     n, k = 1536, 600
     kinds, grads, b0, b1 = synth.deep_cuts(n, k)
     b0 = 0.3 * b0      # (the synthetic betas are sized for 220 cuts: keep tau above them for 600)
@@ -409,7 +409,7 @@ def test_depth_switches_between_prime_and_cut_do_not_leak_dot_products(gpu, orc,
     """A prime on a recorded schedule leaves the scalar stage's dot products behind for the NEXT cut.  If the depth is
     switched to 1 before that cut, a fused pass primes the following gradient without any, and the depth is switched
     back, the old ones must not be taken for the new gradient's."""
-    monkeypatch.setenv("ELLHIP_SYMV_MIN_N", "512")
+    set_default("SYMV_MIN_N", 512)
     rng = np.random.default_rng(77)
     gs = [rng.standard_normal(n) for _ in range(6)]
     e = gpu.Ell.new_with_scalar(1.0, np.zeros(n))
@@ -431,10 +431,11 @@ def test_depth_switches_between_prime_and_cut_do_not_leak_dot_products(gpu, orc,
 
 
 @pytest.mark.parametrize("n", [5, 130, 257, 1000, 4096])
-def test_one_launch_update_equals_the_two_launches(gpu, monkeypatch, n):
-    """ELLHIP_FUSED_UPDATE=1 (off by default: slower): GEMV pass + dot products + scalar stage of a
-    cut in ONE launch (k_update_fused_def, the scalar stage's workgroups wait in-launch for the row tiles) must give
-    the bits of the two launches -- direct updates, the two-pass queue and the pipelined queue, with a failing cut."""
+def test_dot_products_beside_the_full_row_gemv_equal_the_separate_launch(gpu, n):
+    """ELLHIP_OPT_FUSE_DOTS (default 1): on the recorded full-row schedule the v_j . g partial sums are formed by extra
+    workgroups of the GEMV's launch (k_sweep_gemv_dots) and g . y inside k_scalar_apply_def -- in k_scalar_dot_def's exact
+    shape, so the bits equal those of the separate launch (option 0): direct updates, the two-pass queue and the
+    pipelined queue, with a failing cut."""
     from ellalgo_rs_amd import synth
     k = 21
     kinds, grads, b0, b1 = synth.parallel_cuts(n, k)
@@ -442,13 +443,13 @@ def test_one_launch_update_equals_the_two_launches(gpu, monkeypatch, n):
     b0[13] = 1e6   # fails: NoSoln halts the queues there
 
     def build(flag):
-        monkeypatch.setenv("ELLHIP_FUSED_UPDATE", flag)
         s = gpu.Ell.new_with_scalar(1.0, np.linspace(-1.0, 1.0, n))
         s.defer_depth = 8
+        s.set_option(gpu.capi.OPT_FUSE_DOTS, flag)
+        assert s.get_option(gpu.capi.OPT_FUSE_DOTS) == flag
         return s
 
-    ref, direct, twopass, piped = build("0"), build("1"), build("1"), build("1")
-    monkeypatch.delenv("ELLHIP_FUSED_UPDATE")
+    ref, direct, twopass, piped = build(0), build(1), build(1), build(1)
     for i in range(13):
         cut = (grads[i], (b0[i], b1[i]))
         assert int(ref._update(int(kinds[i]), cut)) == int(direct._update(int(kinds[i]), cut)) == 0
@@ -464,24 +465,24 @@ def test_one_launch_update_equals_the_two_launches(gpu, monkeypatch, n):
 
 
 @pytest.mark.parametrize("n,depth", [(1024, 8), (1024, 16), (2112, 16)])
-def test_reduction_inside_the_scalar_stage_launch_equals_the_two_launches(gpu, monkeypatch, n, depth):
-    """ELLHIP_REDUCE_SCALAR=1 (off by default: not faster): the reduction of the lower-triangle GEMV
-    and the scalar stage in ONE launch (k_symv_reduce_scalar; every workgroup waits in-launch for the others' partial
-    sums, then updates its own 128 elements) must give the bits of k_symv_reduce + k_scalar_apply_def."""
+def test_dot_products_from_the_symv_reduction_equal_the_separate_launch(gpu, n, depth):
+    """ELLHIP_OPT_FUSE_DOTS on the lower-triangle schedule: k_symv_reduce<NP> yields g . y and v_j . g beside y; with
+    the option off the separate k_scalar_dot_def launch forms them.  Same bits either way, in every driver."""
     from ellalgo_rs_amd import synth
-    monkeypatch.setenv("ELLHIP_SYMV_MIN_N", "512")
+    set_default("SYMV_MIN_N", 512)
     k = 37
     kinds, grads, b0, b1 = synth.parallel_cuts(n, k)
     b0 = b0.copy()
     b0[29] = 1e6   # fails: the queues halt there
 
     def build(flag):
-        monkeypatch.setenv("ELLHIP_REDUCE_SCALAR", flag)
         s = gpu.Ell.new_with_scalar(1.0, np.linspace(-1.0, 1.0, n))
         s.defer_depth = depth
+        s.set_option(gpu.capi.OPT_FUSE_DOTS, flag)
+        assert s.defer_depth == depth
         return s
 
-    ref, direct, twopass, piped = build("0"), build("1"), build("1"), build("1")
+    ref, direct, twopass, piped = build(0), build(1), build(1), build(1)
     for i in range(29):
         cut = (grads[i], (b0[i], b1[i]))
         assert int(ref._update(int(kinds[i]), cut)) == int(direct._update(int(kinds[i]), cut)) == 0

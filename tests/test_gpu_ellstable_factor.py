@@ -11,7 +11,7 @@ buffer (D, U, S), xc, kappa and tsq against the CPU oracle to the north-star tol
 import numpy as np
 import pytest
 
-from util import TOL, assert_state_close, random_factor, rel_inf, run_mixed_stable
+from util import TOL, assert_state_close, random_factor, rel_inf, run_mixed_stable, set_default
 
 pytestmark = pytest.mark.gpu
 
@@ -69,14 +69,14 @@ def test_first_update_overwrites_all_scratch_junk(gpu, orc, n):
 
 
 @pytest.mark.parametrize("n", [65, 129, 257, 1000, 2048])
-def test_persistent_equals_per_block_launches_on_random_factor(gpu, monkeypatch, n):
+def test_persistent_equals_per_block_launches_on_random_factor(gpu, n):
     """The flag-chained single-launch solves against one launch per block (no inter-workgroup hand-off): same
     arithmetic in the same order, so the same bits -- now on data where an indexing slip would show."""
     f = random_factor(n, 77 + n)
     a = gpu.EllStable.new_with_matrix(1.0, f, np.zeros(n))
-    monkeypatch.setenv("ELLHIP_STABLE_PERSIST", "0")
+    set_default("STABLE_SOLVE", 0)
     b = gpu.EllStable.new_with_matrix(1.0, f, np.zeros(n))
-    monkeypatch.delenv("ELLHIP_STABLE_PERSIST")
+    set_default("STABLE_SOLVE", 2)
     rng = np.random.default_rng(5 * n)
     for i in range(10):
         gr = rng.standard_normal(n)
@@ -90,57 +90,50 @@ def test_persistent_equals_per_block_launches_on_random_factor(gpu, monkeypatch,
     assert _offdiag_nonzeros(a.mq) > 0
 
 
-@pytest.mark.parametrize("n", [129, 300, 1000, 2048, 2048 + 128])
-def test_paired_persistent_solves_equal_per_block_launches(gpu, monkeypatch, n):
-    """ELLHIP_STABLE_PAIR=3: the experimental persistent solves with TWO 128-blocks per workgroup (512 threads, block A's
-    result handed to block B's half of the workgroup through LDS; off by default -- slower) must give
-    the bits of the one-launch-per-block path too: even and odd block counts, ragged last blocks, a failing cut."""
-    f = random_factor(n, 177 + n)
-    monkeypatch.setenv("ELLHIP_STABLE_PAIR", "3")
-    a = gpu.EllStable.new_with_matrix(1.0, f, np.zeros(n))
-    monkeypatch.setenv("ELLHIP_STABLE_PAIR", "0")
-    monkeypatch.setenv("ELLHIP_STABLE_PERSIST", "0")
-    b = gpu.EllStable.new_with_matrix(1.0, f, np.zeros(n))
-    monkeypatch.delenv("ELLHIP_STABLE_PERSIST")
-    rng = np.random.default_rng(7 * n)
-    for i in range(8):
-        gr = rng.standard_normal(n)
-        gr /= np.linalg.norm(gr)
-        beta = 5.0 if i == 5 else 0.05 * rng.random()
-        sa, sb = int(a.update_bias_cut((gr, beta))), int(b.update_bias_cut((gr, beta)))
-        assert sa == sb == (1 if i == 5 else 0)
-        assert a.tsq() == b.tsq() and a.kappa == b.kappa
-    assert np.array_equal(a.xc(), b.xc()) and np.array_equal(a.mq, b.mq)
-
-
 @pytest.mark.parametrize("n", [2, 63, 64, 65, 129, 300, 513, 1000, 2048, 2048 + 128, 2049, 8192, 8200, 8191])
-def test_default_solves_and_factor_update_equal_the_plain_kernels(gpu, monkeypatch, n):
-    """The default EllStable path -- forward solve with a helper workgroup per block (k_st_fwd_helped) and the factor
-    update computed from U alone (k_st_factor_rows: the scratch entry it would read IS fl(U * w)) -- must give the bits
-    of the plain path: one launch per block, factor update reading the scratch triangle through LDS transposes.  Odd and
-    even n, ragged last blocks, one block, a failing cut in the middle; 8191 / 8192 / 8200 straddle the size where the
-    factor tiles switch from 512- to 2048-column segments and the chain workgroups stop pulling tiles before their turn."""
+def test_default_solves_and_factor_update_equal_the_plain_kernels(gpu, n):
+    """Every EllStable kernel form must give the bits of the plain path (one launch per block, factor update reading the
+    scratch triangle through LDS transposes): the default -- both solves with a helper workgroup per block
+    (k_st_fwd_helped, k_st_bwd_factor_helped) and the factor update computed from U alone inside the backward solve's
+    launch (the scratch entry it would read IS fl(U * w)) --, the persistent solves without helpers with the row-wise
+    factor kernel beside them (k_st_fwd_persist, k_st_bwd_persist, k_st_factor_rows), and the forms switched on an
+    existing handle with ellhip_set_option.  Odd and even n, ragged last blocks, one block, a failing cut in the middle;
+    8191 / 8192 / 8200 straddle the size where the factor tiles switch from 512- to 2048-column segments and the chain
+    workgroups stop pulling tiles before their turn."""
+    capi = gpu.capi
     f = random_factor(n, 271 + n)
     a = gpu.EllStable.new_with_matrix(1.0, f, np.zeros(n))
-    monkeypatch.setenv("ELLHIP_STABLE_HELPERS", "0")
-    monkeypatch.setenv("ELLHIP_STABLE_FACTOR_ROWS", "0")
-    monkeypatch.setenv("ELLHIP_STABLE_PERSIST", "0")
+    assert a.get_option(capi.OPT_STABLE_SOLVE) == 2 and a.get_option(capi.OPT_STABLE_FACTOR) == 2
+    set_default("STABLE_SOLVE", 0)
+    set_default("STABLE_FACTOR", 0)
     b = gpu.EllStable.new_with_matrix(1.0, f, np.zeros(n))
-    monkeypatch.delenv("ELLHIP_STABLE_PERSIST")
-    monkeypatch.setenv("ELLHIP_STABLE_FACTOR_ROWS", "1")
-    monkeypatch.setenv("ELLHIP_STABLE_BWD_HELPERS", "0")
-    # persistent solves without helpers, backward solve + row-wise factor update in one launch with dedicated workers
+    assert b.get_option(capi.OPT_STABLE_SOLVE) == 0 and b.get_option(capi.OPT_STABLE_FACTOR) == 0
+    set_default("STABLE_SOLVE", 1)
+    set_default("STABLE_FACTOR", 1)
     c = gpu.EllStable.new_with_matrix(1.0, f, np.zeros(n))
+    set_default("STABLE_SOLVE", 2)
+    set_default("STABLE_FACTOR", 2)
+    d = gpu.EllStable.new_with_matrix(1.0, f, np.zeros(n))   # walks through the forms, one per cut
+    forms = [(0, 0), (1, 0), (1, 1), (2, 1), (2, 2), (0, 1), (2, 0), (1, 2)]
     rng = np.random.default_rng(13 * n)
     for i in range(8):
         gr = rng.standard_normal(n)
         gr /= np.linalg.norm(gr)
         beta = 5.0 if i == 5 else 0.05 * rng.random()
-        sa, sb, sc = (int(x.update_bias_cut((gr, beta))) for x in (a, b, c))
-        assert sa == sb == sc == (1 if i == 5 else 0)
-        assert a.tsq() == b.tsq() == c.tsq() and a.kappa == b.kappa == c.kappa
-    assert np.array_equal(a.xc(), b.xc()) and np.array_equal(a.mq, b.mq)
-    assert np.array_equal(c.xc(), b.xc()) and np.array_equal(c.mq, b.mq)
+        d.set_option(capi.OPT_STABLE_SOLVE, forms[i][0])
+        d.set_option(capi.OPT_STABLE_FACTOR, forms[i][1])
+        sa, sb, sc, sd = (int(x.update_bias_cut((gr, beta))) for x in (a, b, c, d))
+        assert sa == sb == sc == sd == (1 if i == 5 else 0)
+        assert a.tsq() == b.tsq() == c.tsq() == d.tsq() and a.kappa == b.kappa == c.kappa == d.kappa
+    qb = b.mq
+    for x in (a, c, d):
+        assert np.array_equal(x.xc(), b.xc()) and np.array_equal(x.mq, qb)
+    with pytest.raises(capi.EllHipError):
+        gpu.Ell.new_with_scalar(1.0, np.zeros(8)).set_option(capi.OPT_STABLE_SOLVE, 1)   # an EllStable option
+    with pytest.raises(capi.EllHipError):
+        a.set_option(capi.OPT_SYMV, 0)                                                   # an Ell option
+    with pytest.raises(capi.EllHipError):
+        a.set_option(capi.OPT_STABLE_SOLVE, 3)
 
 
 def test_failed_cut_in_the_middle_of_a_sequence(gpu, orc):

@@ -9,6 +9,8 @@ instead of the (too slow) CPU oracle:
 import numpy as np
 import pytest
 
+from util import set_default
+
 pytestmark = pytest.mark.gpu
 
 N = 16384
@@ -214,26 +216,33 @@ def test_ell_n32768_matches_oracle(gpu, orc):
         assert np.max(np.abs(qg[r:r + 512] - qo[r:r + 512])) <= TOL * scale
 
 
-def test_ellstable_n32768_persistent_equals_per_block_launches(gpu, monkeypatch):
-    """n = 32768 is the largest size the persistent solves cover (256 column strips = one workgroup per CU).  Three
-    deep cuts; the flag-chained single launch must give the bits of the one-launch-per-block path (same arithmetic,
-    no inter-workgroup hand-off), and the first update has a closed form (identity factor: only the diagonal moves)."""
+def test_ellstable_n32768_persistent_equals_per_block_launches(gpu):
+    """n = 32768 is the largest size the persistent solves cover (256 column strips = one workgroup per CU) and the one
+    size where k_st_fwd_persist / k_st_bwd_persist are the DEFAULT (the helped forms need two workgroups per strip).
+    From a NON-trivial factor (synth.stable_factor: random unit-upper-triangular factor, random diagonal, junk scratch --
+    from the identity every off-diagonal entry stays exactly zero and the comparison would be one of zeros): three deep
+    cuts; the flag-chained single launches must give the bits of the one-launch-per-block path (same arithmetic, no
+    inter-workgroup hand-off) over the whole 8 GiB buffer, compared in bands of rows to bound host memory."""
     from ellalgo_rs_amd import synth
     n, k = 32768, 3
     kinds, grads, b0, _ = synth.deep_cuts(n, k)
-    a = gpu.EllStable.new_with_scalar(1.0, np.zeros(n))
-    monkeypatch.setenv("ELLHIP_STABLE_PERSIST", "0")
-    b = gpu.EllStable.new_with_scalar(1.0, np.zeros(n))
-    monkeypatch.delenv("ELLHIP_STABLE_PERSIST")
+    f = synth.stable_factor(n)
+    a = gpu.EllStable.new_with_matrix(1.0, f, np.zeros(n))
+    set_default("STABLE_SOLVE", 0)
+    b = gpu.EllStable.new_with_matrix(1.0, f, np.zeros(n))
+    set_default("STABLE_SOLVE", 2)
+    f0 = f[:8, :64].copy()
+    del f
     for i in range(k):
         sa = int(a.update_bias_cut((grads[i], float(b0[i]))))
         sb = int(b.update_bias_cut((grads[i], float(b0[i]))))
         assert sa == sb == 0
         assert a.tsq() == b.tsq() and a.kappa == b.kappa
-        if i == 0:
-            g = grads[0]
-            assert abs(a.tsq() - float(g @ g)) <= 1e-12     # kappa0 = 1, w = g, omega = g.g
     assert np.array_equal(a.xc(), b.xc())
-    qa, qb = a.mq, b.mq
+    qa = a.mq
+    assert not np.array_equal(qa[:8, :64], f0)          # the factor moved ...
+    qb = b.mq
     for r in range(0, n, 4096):
         assert np.array_equal(qa[r:r + 4096], qb[r:r + 4096])
+    assert np.count_nonzero(np.triu(qa[:4096], 1)) > 4096 * 4096    # ... and the comparison was not one of zeros
+    assert np.count_nonzero(np.tril(qa[n - 4096:, n - 4096:], -1)) > 4096 * 1024

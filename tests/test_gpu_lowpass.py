@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 
 from lowpass_probes import CONSTANT_SETS, negative_x0_probe, probe_points, transition_probe
-from util import assert_state_close, rel_inf
+from util import assert_state_close, rel_inf, set_default
 
 pytestmark = pytest.mark.gpu
 
@@ -74,7 +74,7 @@ def test_every_return_statement_on_the_device(gpu, orc):
 def test_early_exit_across_grid_rounds(gpu, orc, grid, monkeypatch):
     """A tiny grid forces many rounds of 16-row chunks per workgroup: the first violation must still be the one
     the sequential walk finds, wherever it sits."""
-    monkeypatch.setenv("ELLHIP_LP_GRID", str(grid))
+    set_default("LP_GRID", grid)
     n = 64
     c = CONSTANT_SETS["very_loose"]
     dev_o = gpu.LowpassOracle(n, *c)
@@ -88,8 +88,8 @@ def test_early_exit_across_grid_rounds(gpu, orc, grid, monkeypatch):
 def test_wide_scan_kernel_at_small_sizes(gpu, orc, n, grid, monkeypatch):
     """k_lp_scan_wide (the n >= 1024 kernel: 4 positions per workgroup step, columns split over the waves)
     forced on where the oracle is cheap, over several rounds of chunks."""
-    monkeypatch.setenv("ELLHIP_LP_WIDE", "1")
-    monkeypatch.setenv("ELLHIP_LP_GRID", str(grid))
+    set_default("LP_WIDE", 1)
+    set_default("LP_GRID", grid)
     rng = np.random.default_rng(grid + n)
     for cset in ("very_loose", "loose", "corrected"):
         c = CONSTANT_SETS[cset]
@@ -347,7 +347,7 @@ def test_cpp_host_mirror_three_drivers_agree_with_the_oracle_loop(gpu, orc):
 def test_optim_loop_on_the_lower_triangle_schedule(gpu, orc, depth, max_iters, monkeypatch):
     """The device-resident loop over the schedule a large handle runs by default (lower-triangle GEMV, recorded
     updates applied 8 / 16 at a time; forced on at n = 640 here): same cut sequence and state as the oracle loop."""
-    monkeypatch.setenv("ELLHIP_SYMV_MIN_N", "512")
+    set_default("SYMV_MIN_N", 512)
     n = 640
     c = CONSTANT_SETS["corrected"]
     dev_o = gpu.LowpassOracle(n, *c)

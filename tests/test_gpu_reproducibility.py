@@ -5,6 +5,8 @@ reduction shapes are fixed by the problem size."""
 import numpy as np
 import pytest
 
+from util import set_default
+
 pytestmark = pytest.mark.gpu
 
 
@@ -26,7 +28,7 @@ def run_ell(gpu, variant, n, k, depth):
 
 @pytest.mark.parametrize("variant,n,depth", [("ell", 2048, 1), ("ell", 2048, 8), ("ell", 2048, 16), ("stable", 1024, 1)])
 def test_search_space_runs_are_bit_reproducible(gpu, variant, n, depth, monkeypatch):
-    monkeypatch.setenv("ELLHIP_SYMV_MIN_N", "512")  # depth 8 / 16 take the lower-triangle schedule here
+    set_default("SYMV_MIN_N", 512)  # depth 8 / 16 take the lower-triangle schedule here
     a = run_ell(gpu, variant, n, 40, depth)
     b = run_ell(gpu, variant, n, 40, depth)
     for x, y in zip(a, b):

@@ -8,7 +8,7 @@ card over gloo) and tests/cpp/sharded_runner.cpp (in-process shards through the 
 import numpy as np
 import pytest
 
-from util import TOL, assert_state_close, run_mixed
+from util import TOL, assert_state_close, run_mixed, set_default
 
 pytestmark = pytest.mark.gpu
 
@@ -57,8 +57,8 @@ def test_one_rank_equal_blocks_matches_the_oracle(gpu, orc, n):
 
 @pytest.mark.parametrize("depth", [1, 8])
 def test_one_rank_equal_blocks_is_bit_identical_to_the_unsharded_engine(gpu, depth, monkeypatch):
-    monkeypatch.setenv("ELLHIP_AUTO_DEFER", "0")
-    monkeypatch.setenv("ELLHIP_SYMV", "0")     # an equal-block shard runs full-row GEMVs: so must the reference here
+    set_default("AUTO_DEFER", 0)
+    set_default("SYMV", 0)     # an equal-block shard runs full-row GEMVs: so must the reference here
     from ellalgo_rs_amd import synth
     n, k = 1536, 20
     kinds, grads, b0, b1 = synth.parallel_cuts(n, k)

@@ -1,0 +1,37 @@
+"""The C-ABI row-partitioned Ell (include/ellhip_sharded.h) with MORE THAN ONE RANK on the one GPU a test box has: every
+rank is a host thread with its own `ellhip_sharded` handle, and the one collective per update goes either through the
+library's RCCL call path against an in-process stand-in for librccl (tests/cpp/fake_rccl.cpp, handed over with
+ELLHIP_RCCL_PATH -- RCCL itself refuses two ranks per device) or through host-supplied callbacks
+(ellhip_sharded_create_custom).  tests/cpp/sharded_ranks_runner.cpp drives direct updates, the two-pass and the
+pipelined queue in pieces, a flush between two pipelined runs, a two-pass run right after a pipelined one (the vector is
+already exchanged: an all-reduce must not run twice) and a failing cut, and checks every rank against the unsharded
+engine (equal blocks: bit for bit, symmetric shards: 1e-12) and the CPU oracle (1e-10).  Partition: src/ell.rs:97-137."""
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+EQUAL, SYMMETRIC = 0, 1
+CASES = [
+    # (n, P, partition, depth)
+    (192, 2, EQUAL, 1), (192, 3, EQUAL, 8), (2048, 2, EQUAL, 1), (2048, 2, EQUAL, 8), (3072, 3, EQUAL, 8), (4096, 2, EQUAL, 8),
+    (512, 2, SYMMETRIC, 8), (2048, 2, SYMMETRIC, 8), (2048, 3, SYMMETRIC, 16), (4096, 2, SYMMETRIC, 16), (4096, 3, SYMMETRIC, 8),
+]
+
+
+@pytest.mark.parametrize("mode", ["rccl", "custom"])
+@pytest.mark.parametrize("n,P,partition,depth", CASES)
+def test_ranks_on_one_gpu(gpu, mode, n, P, partition, depth):
+    from cpp_build import build_fake_rccl, build_runner, run_json_lines
+    exe = build_runner("sharded_ranks_runner.cpp", "hip+oracle")
+    env = {"ELLHIP_RCCL_PATH": build_fake_rccl()} if mode == "rccl" else None
+    out = run_json_lines(exe, mode, str(n), str(P), str(partition), str(depth), env=env)["ranks"]
+    assert out["ok"] is True, out
+    assert out["vs_oracle"] <= 1e-10
+    if partition == EQUAL:
+        assert out["bit_identical"] is True
+    else:
+        assert out["vs_unsharded"] <= 1e-12
+    if mode == "custom":
+        # one collective per GEMV: 10 direct + 26 queued cuts up to the failing one, plus the re-prime after the flush and
+        # the prime beyond the halt at most -- and never two for one vector
+        assert 36 <= out["collectives"] <= 40, out

@@ -8,7 +8,7 @@ observers of Q in the middle of all of it -- must describe the same ellipsoid as
 import numpy as np
 import pytest
 
-from util import TOL, assert_state_close, beta_of, mixed_cut, random_factor, stable_tau
+from util import TOL, assert_state_close, beta_of, mixed_cut, random_factor, stable_tau, set_default
 
 pytestmark = pytest.mark.gpu
 
@@ -195,7 +195,7 @@ class Walk:
 @pytest.mark.parametrize("seed", range(max(12, _EXTRA)))
 @pytest.mark.parametrize("n", [40, 129, 640, 1024])
 def test_random_walks_match_oracle(gpu, orc, n, seed, monkeypatch):
-    monkeypatch.setenv("ELLHIP_SYMV_MIN_N", "512")   # n = 640, 1024 run the lower-triangle schedule at depth 8 / 16
+    set_default("SYMV_MIN_N", 512)   # n = 640, 1024 run the lower-triangle schedule at depth 8 / 16
     depths = (1, 8, 16) if (n >= 512 and n % 2 == 0) else (1, 8)
     Walk(gpu, orc, n, 7000 + 31 * seed + n, depths).run(36)
 

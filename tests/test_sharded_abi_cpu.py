@@ -50,3 +50,57 @@ def test_bad_arguments_are_refused():
     if lib.ellhip_device_count() == 0:   # no CPU fallback here either
         assert lib.ellhip_sharded_create(C.byref(h), 128, 1.0, None, None, p, -1, 0, 1, None, None, 0, 1) == pkg.capi.E_NODEVICE
         assert not h.value
+
+
+def _run(code, env):
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    return subprocess.run([sys.executable, "-c", code], cwd=root, env={**os.environ, **env}, capture_output=True, text=True, timeout=300)
+
+
+def test_missing_rccl_is_an_error_code_not_a_crash():
+    """RCCL absent: ellhip_sharded_unique_id / _create must fail with ELLHIP_E_NORCCL and a message (the first version
+    called dlerror() twice and crashed in strlen(NULL)).  Own process: the library opens RCCL once."""
+    code = (
+        "import ctypes as C\n"
+        "import ellalgo_rs_amd as pkg\n"
+        "L = pkg.capi.load()\n"
+        "buf = (C.c_char * 128)()\n"
+        "rc = L.ellhip_sharded_unique_id(buf)\n"
+        "msg = L.ellhip_last_error().decode()\n"
+        "assert rc == pkg.capi.E_NORCCL, rc\n"
+        "assert 'could not be opened' in msg and 'no_such_librccl' in msg, msg\n"
+        "rc2 = L.ellhip_sharded_unique_id(buf)\n"
+        "assert rc2 == pkg.capi.E_NORCCL\n"
+        "print('ok')\n")
+    r = _run(code, {"ELLHIP_RCCL_PATH": "/nonexistent/no_such_librccl.so"})
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (r.returncode, r.stdout, r.stderr)
+
+
+def test_rccl_path_selects_the_library():
+    """ELLHIP_RCCL_PATH names the collective library to open: the in-process stand-in of the multi-rank tests."""
+    from cpp_build import build_fake_rccl
+    code = (
+        "import ctypes as C\n"
+        "import ellalgo_rs_amd as pkg\n"
+        "L = pkg.capi.load()\n"
+        "buf = (C.c_char * 128)()\n"
+        "assert L.ellhip_sharded_unique_id(buf) == 0, L.ellhip_last_error()\n"
+        "assert bytes(buf[:8]) == b'FAKERCCL'\n"
+        "print('ok')\n")
+    r = _run(code, {"ELLHIP_RCCL_PATH": build_fake_rccl()})
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (r.returncode, r.stdout, r.stderr)
+
+
+def test_custom_collective_needs_both_callbacks():
+    import ctypes as C
+    import ellalgo_rs_amd as pkg
+    L = pkg.capi.load()
+    h = C.c_void_p()
+    rc = L.ellhip_sharded_create_custom(C.byref(h), 128, 1.0, None, None, None, 0, 0, 2, 0, 1, None, None, None)
+    assert rc == pkg.capi.E_INVALID
+    # symmetric shards below the lower-triangle schedule's smallest size are refused up front (before any device work)
+    rc = L.ellhip_sharded_create(C.byref(h), 192, 1.0, None, None, None, 0, 0, 1, None, None, pkg.capi.SHARD_SYMMETRIC, 8)
+    assert rc == pkg.capi.E_INVALID and b"n >= 512" in L.ellhip_last_error()

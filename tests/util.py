@@ -114,3 +114,10 @@ def run_mixed_stable(gpu_space, orc_space, k, seed, check_every=0, tol=TOL):
         if check_every and (i + 1) % check_every == 0:
             assert_state_close(gpu_space, orc_space, tol, what=f"step {i}")
     return nsucc
+
+
+def set_default(name: str, value: int) -> None:
+    """ellhip_set_default_option(ELLHIP_OPT_<name>, value): what handles created from now on start with (conftest.py puts
+    the factory defaults back after every test)."""
+    import ellalgo_rs_amd as pkg
+    pkg.capi.set_default_option(getattr(pkg.capi, "OPT_" + name), int(value))

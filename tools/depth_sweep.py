@@ -15,7 +15,7 @@ for n in [int(a) for a in sys.argv[1:]] or [256, 512, 1024, 2048, 3072, 4096, 61
     k = 400
     kinds, grads, b0, b1 = synth.deep_cuts(n, 2 * k)
     row = [f"n={n:6d}"]
-    lower = n % 2 == 0 and n >= int(os.environ.get("ELLHIP_SYMV_MIN_N", "8192"))
+    lower = n % 2 == 0 and n >= pkg.capi.default_option(pkg.capi.OPT_SYMV_MIN_N)
     for depth in ((1, 8, 16) if lower else (1, 8)):
         e = pkg.Ell.new_with_scalar(1.0, np.zeros(n))
         e.defer_depth = depth
