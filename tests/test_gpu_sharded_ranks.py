@@ -32,6 +32,9 @@ def test_ranks_on_one_gpu(gpu, mode, n, P, partition, depth):
     else:
         assert out["vs_unsharded"] <= 1e-12
     if mode == "custom":
-        # one collective per GEMV: 10 direct + 26 queued cuts up to the failing one, plus the re-prime after the flush and
-        # the prime beyond the halt at most -- and never two for one vector
-        assert 36 <= out["collectives"] <= 40, out
+        # ONE collective per GEMV and never two for one vector: 10 direct + 6 two-pass + (1 prime + 8 commits) + after the
+        # flush (0 or 1 re-prime: the prime is dropped only if the flush applied something) + 6 commits + 3 two-pass cuts
+        # (cut 30 is already primed and exchanged) + (1 prime + 5 commits; the ones behind the failing cut are issued by
+        # the host and are no-ops on the device) = 40 or 41.  The double exchange of cut 30 would make it 41 or 42 AND
+        # break the symmetric shards' results (an all-reduce is not idempotent), which the comparisons above catch.
+        assert out["collectives"] in (40, 41), out
