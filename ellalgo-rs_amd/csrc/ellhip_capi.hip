@@ -64,7 +64,6 @@ struct Defaults {
     int apply_lower = 1;       // ELLHIP_OPT_APPLY_LOWER
     int apply_kernel = 1;      // ELLHIP_OPT_APPLY_KERNEL
     int fuse_dots = 1;         // ELLHIP_OPT_FUSE_DOTS
-    int symv_units = 1;        // ELLHIP_OPT_SYMV_UNITS
     int stable_solve = 2;      // ELLHIP_OPT_STABLE_SOLVE
     int stable_factor = 2;     // ELLHIP_OPT_STABLE_FACTOR
     int pad = -1;              // ELLHIP_OPT_PAD: extra doubles per row of Q; -1 = by size (create_impl)
@@ -114,10 +113,6 @@ struct ellhip_space {
     long long symv_min_n = 8192;     // below this the full-row pass is faster (few, small triangle tiles)
     bool shard_symmetric = false;    // row shard whose GEMVs are partial symmetric sums (ellhip_set_shard_symmetric)
     int symv_seg = SYMV_SEG;         // segment width of the lower-triangle GEMV's tiles (see symv_alloc)
-    int4* d_symv_units = nullptr;    // k_symv_units: the tiles as work units of equal size (full tile | two diagonal tiles)
-    unsigned n_symv_units = 0;
-    unsigned symv_lds_cap = 0;       // dynamic LDS per workgroup that caps the residency at symv_per_cu workgroups per CU
-    int symv_units = 1;              // ELLHIP_OPT_SYMV_UNITS: 1 = k_symv_units, 0 = the static (strip, segment) grid
     int apply_lower = 1;             // with symv: apply passes touch the lower triangle only (ELLHIP_APPLY_LOWER)
     int fuse_dots = 1;               // unsharded lower-triangle schedule: k_symv_reduce also yields the scalar stage's dot products (ELLHIP_FUSE_DOTS)
     int dots_np = 0;                 // > 0: d_partial holds dot products of the primed gradient for this depth: [ceil(n/128)][dots_np + 1]
@@ -261,7 +256,6 @@ void pick_shape(ellhip_space* s) {
     s->apply_lower = g_defaults.apply_lower;
     s->apply_kernel = g_defaults.apply_kernel;
     s->fuse_dots = g_defaults.fuse_dots;
-    s->symv_units = g_defaults.symv_units;
     s->stable_solve = g_defaults.stable_solve;
     s->stable_factor = g_defaults.stable_factor;
 }
@@ -574,78 +568,11 @@ int symv_alloc(ellhip_space* s) {
     // rows of rowpart outside this shard are never written but are read by nobody either; zero them anyway
     HIPCHK(hipMemsetAsync(s->d_rowpart, 0, nsegs * (size_t)s->n * sizeof(double), s->stream));
     HIPCHK(hipMemsetAsync(s->d_colpart, 0, nstrips * (size_t)s->n * sizeof(double), s->stream));
-    {   // the work units of k_symv_units (see ell_kernels.hpp): full tiles one by one, diagonal tiles in pairs
-        const long long seg = s->symv_seg, rend = s->row0 + s->nrows;
-        std::vector<int4> full;
-        std::vector<std::pair<double, int4>> diag;  // (elements at or left of the diagonal, tile)
-        for (long long I = 0; I < (long long)nstrips; ++I) {
-            const long long r0 = s->row0 + I * SYMV_H, rl = std::min(r0 + SYMV_H - 1, rend - 1);
-            for (long long J = 0; J * seg <= rl; ++J) {
-                const long long c0 = J * seg;
-                if (c0 + seg - 1 < r0 && r0 + SYMV_H - 1 < rend) {
-                    full.push_back(int4{(int)I, (int)J, -2, 0});
-                } else {
-                    double area = 0.0;
-                    for (long long r = r0; r <= rl; ++r) area += (double)(std::min(r, c0 + seg - 1) - c0 + 1);
-                    diag.push_back({area, int4{(int)I, (int)J, -1, 0}});
-                }
-            }
-        }
-        std::sort(diag.begin(), diag.end(), [](const auto& a, const auto& b) { return a.first > b.first; });
-        std::vector<int4> units;
-        const double full_area = (double)SYMV_H * (double)seg;
-        size_t lo = 0, hi = diag.size();
-        while (lo < hi) {  // largest with smallest while the two together do not exceed ~a full tile
-            int4 u = diag[lo].second;
-            if (hi - lo >= 2 && diag[lo].first + diag[hi - 1].first <= 1.02 * full_area) {
-                u.z = diag[hi - 1].second.x;
-                u.w = diag[hi - 1].second.y;
-                --hi;
-            }
-            units.push_back(u);
-            ++lo;
-        }
-        units.insert(units.end(), full.begin(), full.end());  // the (slower, predicated) diagonal units start first
-        s->n_symv_units = (unsigned)units.size();
-        HIPCHK(hipMalloc(&s->d_symv_units, units.size() * sizeof(int4)));
-        HIPCHK(hipMemcpy(s->d_symv_units, units.data(), units.size() * sizeof(int4), hipMemcpyHostToDevice));
-        // Residency cap: with U units on C CUs, ceil(U / C) per CU makes every CU hold the same number when U is a
-        // multiple of C (n = 16384: 1024 = 4 x 256) and lets the dispatcher balance the rest dynamically otherwise; never
-        // below 4 (latency hiding), and nothing to do where the registers allow no more anyway.  The amount of (unused)
-        // dynamic LDS that yields exactly that residency is asked of the occupancy calculator, not assumed.
-        hipDeviceProp_t prop;
-        HIPCHK(hipGetDeviceProperties(&prop, s->device));
-        const unsigned cus = (unsigned)std::max(1, prop.multiProcessorCount);
-        const unsigned per_cu = std::max(4u, (s->n_symv_units + cus - 1) / cus);
-        const void* kern = s->symv_seg == SYMV_SEG_SMALL ? (const void*)k_symv_units<8, true, SYMV_SEG_SMALL>
-                                                         : (s->symv_rw == 4 ? (const void*)k_symv_units<4, true, SYMV_SEG>
-                                                                            : (const void*)k_symv_units<2, true, SYMV_SEG>);
-        s->symv_lds_cap = 0;
-        for (unsigned dyn = 0; dyn <= 60 * 1024; dyn += 2048) {
-            int occ = 0;
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, 256, dyn) != hipSuccess) break;
-            if (occ <= (int)per_cu) {
-                if (occ == (int)per_cu) s->symv_lds_cap = dyn;
-                break;
-            }
-        }
-    }
     return 0;
 }
 
 template <int RW, int SEG>
 void symv_go(ellhip_space* s, const double* g_dev, unsigned nstrips, unsigned nsegs, bool nt) {
-    if (s->symv_units && s->d_symv_units && s->n_symv_units > 0) {  // the same tiles as work units of equal size
-        if (nt)
-            hipLaunchKernelGGL((k_symv_units<RW, true, SEG>), dim3(s->n_symv_units), dim3(256), s->symv_lds_cap, s->stream,
-                               (const double*)s->d_Q, s->ld, s->n, s->row0, s->nrows, g_dev, s->d_rowpart, s->d_colpart,
-                               (const DevState*)s->d_st, (const int4*)s->d_symv_units);
-        else
-            hipLaunchKernelGGL((k_symv_units<RW, false, SEG>), dim3(s->n_symv_units), dim3(256), s->symv_lds_cap, s->stream,
-                               (const double*)s->d_Q, s->ld, s->n, s->row0, s->nrows, g_dev, s->d_rowpart, s->d_colpart,
-                               (const DevState*)s->d_st, (const int4*)s->d_symv_units);
-        return;
-    }
     if (nt)
         hipLaunchKernelGGL((k_symv<RW, true, 0, SEG>), dim3(nstrips, nsegs), dim3(256), 0, s->stream, (const double*)s->d_Q,
                            s->ld, s->n, s->row0, s->nrows, g_dev, s->d_rowpart, s->d_colpart, s->d_st);
@@ -1222,7 +1149,6 @@ void ellhip_destroy(ellhip_space* s) {
     if (s->d_partial) (void)hipFree(s->d_partial);
     if (s->d_pend) (void)hipFree(s->d_pend);
     if (s->d_cpend) (void)hipFree(s->d_cpend);
-    if (s->d_symv_units) (void)hipFree(s->d_symv_units);
     if (s->d_rowpart) (void)hipFree(s->d_rowpart);
     if (s->d_colpart) (void)hipFree(s->d_colpart);
     if (s->d_flags) (void)hipFree(s->d_flags);
@@ -1266,7 +1192,6 @@ int ellhip_clone(const ellhip_space* src_c, ellhip_space** out) {
     s->apply_lower = src->apply_lower;
     s->apply_kernel = src->apply_kernel;
     s->fuse_dots = src->fuse_dots;
-    s->symv_units = src->symv_units;
     s->shard_symmetric = src->shard_symmetric;
     s->upper_stale = src->upper_stale;
     s->symv_seg = src->symv_seg;
@@ -1555,7 +1480,7 @@ namespace {
 int option_ok(int key, long long v) {
     switch (key) {
         case ELLHIP_OPT_AUTO_DEFER: case ELLHIP_OPT_SYMV: case ELLHIP_OPT_APPLY_LOWER: case ELLHIP_OPT_APPLY_KERNEL:
-        case ELLHIP_OPT_FUSE_DOTS: case ELLHIP_OPT_SYMV_UNITS:
+        case ELLHIP_OPT_FUSE_DOTS:
             return (v == 0 || v == 1) ? 0 : fail(ELLHIP_E_INVALID, "option value must be 0 or 1");
         case ELLHIP_OPT_SYMV_MIN_N: return v >= 512 ? 0 : fail(ELLHIP_E_INVALID, "ELLHIP_OPT_SYMV_MIN_N must be >= 512");
         case ELLHIP_OPT_STABLE_SOLVE: case ELLHIP_OPT_STABLE_FACTOR:
@@ -1580,7 +1505,6 @@ int ellhip_set_default_option(int key, int64_t value) {
         case ELLHIP_OPT_APPLY_LOWER: g_defaults.apply_lower = (int)value; break;
         case ELLHIP_OPT_APPLY_KERNEL: g_defaults.apply_kernel = (int)value; break;
         case ELLHIP_OPT_FUSE_DOTS: g_defaults.fuse_dots = (int)value; break;
-        case ELLHIP_OPT_SYMV_UNITS: g_defaults.symv_units = (int)value; break;
         case ELLHIP_OPT_STABLE_SOLVE: g_defaults.stable_solve = (int)value; break;
         case ELLHIP_OPT_STABLE_FACTOR: g_defaults.stable_factor = (int)value; break;
         case ELLHIP_OPT_PAD: g_defaults.pad = (int)value; break;
@@ -1600,7 +1524,6 @@ int ellhip_default_option(int key, int64_t* value) {
         case ELLHIP_OPT_APPLY_LOWER: *value = g_defaults.apply_lower; break;
         case ELLHIP_OPT_APPLY_KERNEL: *value = g_defaults.apply_kernel; break;
         case ELLHIP_OPT_FUSE_DOTS: *value = g_defaults.fuse_dots; break;
-        case ELLHIP_OPT_SYMV_UNITS: *value = g_defaults.symv_units; break;
         case ELLHIP_OPT_STABLE_SOLVE: *value = g_defaults.stable_solve; break;
         case ELLHIP_OPT_STABLE_FACTOR: *value = g_defaults.stable_factor; break;
         case ELLHIP_OPT_PAD: *value = g_defaults.pad; break;
@@ -1620,10 +1543,6 @@ int ellhip_set_option(ellhip_space* s, int key, int64_t value) {
     const bool ell = s->variant == ELLHIP_SPACE_ELL;
     switch (key) {
         case ELLHIP_OPT_SYMV: case ELLHIP_OPT_SYMV_MIN_N: case ELLHIP_OPT_APPLY_LOWER: case ELLHIP_OPT_APPLY_KERNEL:
-        case ELLHIP_OPT_SYMV_UNITS:
-            if (!ell) return fail(ELLHIP_E_INVALID, "this option exists on Ell only");
-            s->symv_units = (int)value;  // (same tiles, same partial sums: nothing recorded depends on it)
-            return 0;
         case ELLHIP_OPT_FUSE_DOTS: {
             if (!ell) return fail(ELLHIP_E_INVALID, "this option exists on Ell only");
             if (s->in_two_phase) return fail(ELLHIP_E_STATE, "update_begin without update_end");
@@ -1664,7 +1583,6 @@ int ellhip_get_option(const ellhip_space* s, int key, int64_t* value) {
         case ELLHIP_OPT_APPLY_LOWER: *value = s->apply_lower; break;
         case ELLHIP_OPT_APPLY_KERNEL: *value = s->apply_kernel; break;
         case ELLHIP_OPT_FUSE_DOTS: *value = s->fuse_dots; break;
-        case ELLHIP_OPT_SYMV_UNITS: *value = s->symv_units; break;
         case ELLHIP_OPT_STABLE_SOLVE: *value = s->stable_solve; break;
         case ELLHIP_OPT_STABLE_FACTOR: *value = s->stable_factor; break;
         case ELLHIP_OPT_PAD: *value = s->ld - s->n; break;

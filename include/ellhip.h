@@ -213,9 +213,6 @@ int ellhip_set_shard_symmetric(ellhip_space *s, int flag);
  *   ELLHIP_OPT_APPLY_LOWER       0 / 1      1        Ell: apply passes touch the lower triangle only (8 n^2 bytes)
  *   ELLHIP_OPT_APPLY_KERNEL      0 / 1      1        Ell, depth 8: 1 = k_apply_lower (16-row tiles), 0 = k_sweep_apply
  *   ELLHIP_OPT_FUSE_DOTS         0 / 1      1        Ell: the scalar stage's dot products come out of the GEMV's launch
- *   ELLHIP_OPT_SYMV_UNITS        0 / 1      1        Ell: the lower-triangle GEMV's tiles run as work units of equal size
- *                                                    (a full tile, or two diagonal tiles), residency capped so that every CU
- *                                                    holds the same number; 0 = the static (strip, segment) grid
  *   ELLHIP_OPT_STABLE_SOLVE      0 / 1 / 2  2        EllStable: 0 = one launch per 128-block (no in-launch waits),
  *                                                    1 = persistent solves, 2 = persistent + helper workgroups
  *   ELLHIP_OPT_STABLE_FACTOR     0 / 1 / 2  2        EllStable factor update: 0 = tile kernel reading the scratch
@@ -241,7 +238,6 @@ int ellhip_set_shard_symmetric(ellhip_space *s, int flag);
 #define ELLHIP_OPT_LP_GRID 10
 #define ELLHIP_OPT_LP_WIDE 11
 #define ELLHIP_OPT_BATCH_THREADS 12
-#define ELLHIP_OPT_SYMV_UNITS 13
 int ellhip_set_option(ellhip_space *s, int key, int64_t value);
 int ellhip_get_option(const ellhip_space *s, int key, int64_t *value);
 int ellhip_set_default_option(int key, int64_t value);

@@ -501,29 +501,3 @@ def test_dot_products_from_the_symv_reduction_agree_with_the_separate_launch(gpu
         assert np.array_equal(s.mq, qd)
     assert np.max(np.abs(ref.xc() - direct.xc())) <= 1e-12 * np.max(np.abs(ref.xc()))
     assert np.max(np.abs(ref.mq - qd)) <= 1e-12 * np.max(np.abs(qd))
-
-
-@pytest.mark.parametrize("n,depth", [(512, 8), (1000, 8), (2112, 16), (4096, 16), (8192 + 64, 16)])
-def test_symv_work_units_equal_the_static_grid_bit_for_bit(gpu, n, depth):
-    """ELLHIP_OPT_SYMV_UNITS (default 1): the lower-triangle GEMV's tiles run as work units of equal size -- a full tile
-    through the predicate-free body, or two diagonal tiles one after the other -- on a 1-D grid with capped residency.
-    Every tile is computed by the same routine and writes the same partial sums as the static (strip, segment) grid
-    (option 0): the two must agree to the bit, ragged last strips and segments included."""
-    from ellalgo_rs_amd import synth
-    set_default("SYMV_MIN_N", 512)
-    k = 40
-    kinds, grads, b0, b1 = synth.parallel_cuts(n, k)
-    outs = []
-    for units in (1, 0):
-        e = gpu.Ell.new_with_scalar(1.0, np.linspace(-1.0, 1.0, n))
-        e.defer_depth = depth
-        e.set_option(gpu.capi.OPT_SYMV_UNITS, units)
-        assert e.get_option(gpu.capi.OPT_SYMV_UNITS) == units
-        e.queue_upload(kinds, grads, b0, b1)
-        e.queue_run(0, 17, fused=True)
-        e.queue_run(17, k - 17, fused=False)
-        st, ts = e.queue_results()
-        assert np.all(st == 0)
-        outs.append((ts, e.xc(), e.kappa, e.mq))
-    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1]) and outs[0][2] == outs[1][2]
-    assert np.array_equal(outs[0][3], outs[1][3])
