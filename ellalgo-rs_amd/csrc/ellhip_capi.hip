@@ -27,6 +27,7 @@
 
 #include "ell_kernels.hpp"
 #include "ellstable_kernels.hpp"
+#include "resident_kernels.hpp"
 
 using namespace ellhip;
 
@@ -64,6 +65,7 @@ struct Defaults {
     int apply_lower = 1;       // ELLHIP_OPT_APPLY_LOWER
     int apply_kernel = 1;      // ELLHIP_OPT_APPLY_KERNEL
     int fuse_dots = 1;         // ELLHIP_OPT_FUSE_DOTS
+    int resident = 1;          // ELLHIP_OPT_RESIDENT
     int stable_solve = 2;      // ELLHIP_OPT_STABLE_SOLVE
     int stable_factor = 2;     // ELLHIP_OPT_STABLE_FACTOR
     int pad = -1;              // ELLHIP_OPT_PAD: extra doubles per row of Q; -1 = by size (create_impl)
@@ -73,7 +75,7 @@ struct Defaults {
 };
 Defaults g_defaults;
 
-enum : int { CLS_GEMV = 0, CLS_SCALAR = 1, CLS_RANK1 = 2, CLS_ST_FWD = 3, CLS_ST_BWD = 4, CLS_ST_FACTOR = 5, CLS_FUSED = 6, CLS_APPLY = 7, CLS_APPLY_GEMV = 8, CLS_SYMV = 9, CLS_SYMV_REDUCE = 10, CLS_LP_SCAN = 11, CLS_LP_FINAL = 12 };
+enum : int { CLS_GEMV = 0, CLS_SCALAR = 1, CLS_RANK1 = 2, CLS_ST_FWD = 3, CLS_ST_BWD = 4, CLS_ST_FACTOR = 5, CLS_FUSED = 6, CLS_APPLY = 7, CLS_APPLY_GEMV = 8, CLS_SYMV = 9, CLS_SYMV_REDUCE = 10, CLS_LP_SCAN = 11, CLS_LP_FINAL = 12, CLS_RESIDENT = 13 };
 
 struct Shape {
     int rw = 0, unr = 0, nt = 0;
@@ -115,6 +117,12 @@ struct ellhip_space {
     int symv_seg = SYMV_SEG;         // segment width of the lower-triangle GEMV's tiles (see symv_alloc)
     int apply_lower = 1;             // with symv: apply passes touch the lower triangle only (ELLHIP_APPLY_LOWER)
     int fuse_dots = 1;               // unsharded lower-triangle schedule: k_symv_reduce also yields the scalar stage's dot products (ELLHIP_FUSE_DOTS)
+    // queue runs with the matrix parked on-chip (resident_kernels.hpp, ELLHIP_OPT_RESIDENT)
+    int resident = 1;
+    int rs_R = 0, rs_S = 0;          // super-tile edge / rows chosen for this n and device (0: does not fit)
+    double* d_rs_part = nullptr;     // [2][grid][2 R 64]
+    double* d_rs_omega = nullptr;    // [2][grid]
+    unsigned* d_rs_bar = nullptr;    // RS_BAR_WORDS
     int dots_np = 0;                 // > 0: d_partial holds dot products of the primed gradient for this depth: [ceil(n/128)][dots_np + 1]
                                      // from k_symv_reduce, or [scalar_groups(n)][...] WITHOUT the g.y column from k_sweep_gemv_dots
     bool dots_need_gy = false;       // the latter: k_scalar_apply_def forms g.y itself
@@ -256,6 +264,7 @@ void pick_shape(ellhip_space* s) {
     s->apply_lower = g_defaults.apply_lower;
     s->apply_kernel = g_defaults.apply_kernel;
     s->fuse_dots = g_defaults.fuse_dots;
+    s->resident = g_defaults.resident;
     s->stable_solve = g_defaults.stable_solve;
     s->stable_factor = g_defaults.stable_factor;
 }
@@ -1098,6 +1107,101 @@ int queue_commit_impl(ellhip_space* s, long long index, long long next) {
     return 0;
 }
 
+
+// ---- queue runs with the matrix parked on-chip (resident_kernels.hpp) ------------------------------------------------
+// Chosen for a run of at least RS_MIN_COUNT queued cuts of an unsharded Ell handle whose lower triangle fits the
+// register files: R = the smallest super-tile edge with no more super-tiles than the device has CUs, and one workgroup
+// of k_ell_resident<R> must fit a CU.  Not while no_defer_trick is set (the kernel has no scale pass) or before a
+// non-symmetric input has been mirrored, and not for the device-resident cutting-plane loops (tolerance stop).
+constexpr long long RS_MIN_COUNT = 4;
+
+int resident_setup(ellhip_space* s) {  // once per handle: can this n run resident on this device, and with which R?
+    if (s->rs_R != 0) return 0;
+    s->rs_R = -1;
+    if (s->variant != ELLHIP_SPACE_ELL || s->sharded) return 0;
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, s->device));
+    const int T = (int)((s->n + RS_TS - 1) / RS_TS);
+    for (int r = 1; r <= RS_RMAX; ++r) {
+        const int S = (T + r - 1) / r;
+        if (S > RS_SMAX || S * (S + 1) / 2 > prop.multiProcessorCount) continue;
+        int occ = 0;
+        const void* k = r == 1 ? (const void*)k_ell_resident<1> : (r == 2 ? (const void*)k_ell_resident<2> : (const void*)k_ell_resident<3>);
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k, RS_THREADS, 0) != hipSuccess || occ < 1) continue;
+        const size_t G = (size_t)S * (S + 1) / 2, NV = 2 * (size_t)r * RS_TS;
+        HIPCHK(hipMalloc(&s->d_rs_part, 2 * G * NV * sizeof(double)));
+        HIPCHK(hipMalloc(&s->d_rs_omega, 2 * G * sizeof(double)));
+        HIPCHK(hipMalloc(&s->d_rs_bar, RS_BAR_WORDS * sizeof(unsigned)));
+        s->rs_R = r;
+        s->rs_S = S;
+        break;
+    }
+    return 0;
+}
+
+bool resident_ok(ellhip_space* s, long long count) {
+    if (!s->resident || count < RS_MIN_COUNT || s->variant != ELLHIP_SPACE_ELL || s->sharded || s->no_defer_trick || s->needs_mirror)
+        return false;
+    if (s->h_result && s->h_result->tol >= 0.0) return false;
+    if (resident_setup(s) != 0) return false;
+    return s->rs_R > 0;
+}
+
+int resident_run(ellhip_space* s, long long first, long long count) {
+    // the lower triangle must be current: commit a pending shrink, apply what the recorded schedule holds; a primed
+    // gradient is simply dropped (the kernel forms every Q g itself)
+    int rc = ensure_committed(s);
+    if (rc) return rc;
+    if (s->npend > 0) {
+        rc = flush_pending(s, nullptr, nullptr);
+        if (rc) return rc;
+    }
+    drop_prime(s);
+    ResidentArgs A{};
+    A.Q = s->d_Q;
+    A.ld = s->ld;
+    A.n = s->n;
+    A.T = (int)((s->n + RS_TS - 1) / RS_TS);
+    A.R = s->rs_R;
+    A.S = s->rs_S;
+    A.qgrads = s->d_qgrads;
+    A.qparams = s->d_qparams;
+    A.qstatus = s->d_qstatus;
+    A.qtsq = s->d_qtsq;
+    A.first = first;
+    A.count = count;
+    A.xc = s->d_xc;
+    A.st = s->d_st;
+    A.part = s->d_rs_part;
+    A.omega_part = s->d_rs_omega;
+    A.ctr = s->d_rs_bar;
+    A.stamps = nullptr;
+    A.calc = EllCalcDev::make(s->n, s->use_parallel_cut);
+    const unsigned G = (unsigned)(s->rs_S * (s->rs_S + 1) / 2);
+    HIPCHK(hipMemsetAsync(s->d_rs_bar, 0, RS_BAR_WORDS * sizeof(unsigned), s->stream));
+    {
+        ProfScope ps(s, CLS_RESIDENT);
+        if (s->rs_R == 1) hipLaunchKernelGGL(k_ell_resident<1>, dim3(G), dim3(RS_THREADS), 0, s->stream, A);
+        else if (s->rs_R == 2) hipLaunchKernelGGL(k_ell_resident<2>, dim3(G), dim3(RS_THREADS), 0, s->stream, A);
+        else hipLaunchKernelGGL(k_ell_resident<3>, dim3(G), dim3(RS_THREADS), 0, s->stream, A);
+        HIPCHK(hipGetLastError());
+    }
+    // The kernel wrote the lower triangle (diagonal tiles whole).  Where the streamed schedule of this handle reads
+    // full rows, the mirrored half is rebuilt at once; a handle on the lower-triangle schedule leaves it stale as its
+    // own apply passes do (make_q_current mirrors before anything observes Q).
+    if (symv_ok(s) && s->apply_lower) {
+        s->upper_stale = true;
+    } else {
+        const unsigned t = (unsigned)((s->n + 31) / 32);
+        hipLaunchKernelGGL(k_mirror_lower_now, dim3(t, t), dim3(256), 0, s->stream, s->d_Q, s->ld, s->n);
+        HIPCHK(hipGetLastError());
+        s->upper_stale = false;
+    }
+    s->shrink_pending = false;
+    s->scalars_stale = true;
+    return 0;
+}
+
 }  // namespace
 
 // ================================================================================= C ABI ======
@@ -1149,6 +1253,9 @@ void ellhip_destroy(ellhip_space* s) {
     if (s->d_partial) (void)hipFree(s->d_partial);
     if (s->d_pend) (void)hipFree(s->d_pend);
     if (s->d_cpend) (void)hipFree(s->d_cpend);
+    if (s->d_rs_part) (void)hipFree(s->d_rs_part);
+    if (s->d_rs_omega) (void)hipFree(s->d_rs_omega);
+    if (s->d_rs_bar) (void)hipFree(s->d_rs_bar);
     if (s->d_rowpart) (void)hipFree(s->d_rowpart);
     if (s->d_colpart) (void)hipFree(s->d_colpart);
     if (s->d_flags) (void)hipFree(s->d_flags);
@@ -1192,6 +1299,7 @@ int ellhip_clone(const ellhip_space* src_c, ellhip_space** out) {
     s->apply_lower = src->apply_lower;
     s->apply_kernel = src->apply_kernel;
     s->fuse_dots = src->fuse_dots;
+    s->resident = src->resident;
     s->shard_symmetric = src->shard_symmetric;
     s->upper_stale = src->upper_stale;
     s->symv_seg = src->symv_seg;
@@ -1480,7 +1588,7 @@ namespace {
 int option_ok(int key, long long v) {
     switch (key) {
         case ELLHIP_OPT_AUTO_DEFER: case ELLHIP_OPT_SYMV: case ELLHIP_OPT_APPLY_LOWER: case ELLHIP_OPT_APPLY_KERNEL:
-        case ELLHIP_OPT_FUSE_DOTS:
+        case ELLHIP_OPT_FUSE_DOTS: case ELLHIP_OPT_RESIDENT:
             return (v == 0 || v == 1) ? 0 : fail(ELLHIP_E_INVALID, "option value must be 0 or 1");
         case ELLHIP_OPT_SYMV_MIN_N: return v >= 512 ? 0 : fail(ELLHIP_E_INVALID, "ELLHIP_OPT_SYMV_MIN_N must be >= 512");
         case ELLHIP_OPT_STABLE_SOLVE: case ELLHIP_OPT_STABLE_FACTOR:
@@ -1505,6 +1613,7 @@ int ellhip_set_default_option(int key, int64_t value) {
         case ELLHIP_OPT_APPLY_LOWER: g_defaults.apply_lower = (int)value; break;
         case ELLHIP_OPT_APPLY_KERNEL: g_defaults.apply_kernel = (int)value; break;
         case ELLHIP_OPT_FUSE_DOTS: g_defaults.fuse_dots = (int)value; break;
+        case ELLHIP_OPT_RESIDENT: g_defaults.resident = (int)value; break;
         case ELLHIP_OPT_STABLE_SOLVE: g_defaults.stable_solve = (int)value; break;
         case ELLHIP_OPT_STABLE_FACTOR: g_defaults.stable_factor = (int)value; break;
         case ELLHIP_OPT_PAD: g_defaults.pad = (int)value; break;
@@ -1524,6 +1633,7 @@ int ellhip_default_option(int key, int64_t* value) {
         case ELLHIP_OPT_APPLY_LOWER: *value = g_defaults.apply_lower; break;
         case ELLHIP_OPT_APPLY_KERNEL: *value = g_defaults.apply_kernel; break;
         case ELLHIP_OPT_FUSE_DOTS: *value = g_defaults.fuse_dots; break;
+        case ELLHIP_OPT_RESIDENT: *value = g_defaults.resident; break;
         case ELLHIP_OPT_STABLE_SOLVE: *value = g_defaults.stable_solve; break;
         case ELLHIP_OPT_STABLE_FACTOR: *value = g_defaults.stable_factor; break;
         case ELLHIP_OPT_PAD: *value = g_defaults.pad; break;
@@ -1543,6 +1653,10 @@ int ellhip_set_option(ellhip_space* s, int key, int64_t value) {
     const bool ell = s->variant == ELLHIP_SPACE_ELL;
     switch (key) {
         case ELLHIP_OPT_SYMV: case ELLHIP_OPT_SYMV_MIN_N: case ELLHIP_OPT_APPLY_LOWER: case ELLHIP_OPT_APPLY_KERNEL:
+        case ELLHIP_OPT_RESIDENT:
+            if (!ell) return fail(ELLHIP_E_INVALID, "this option exists on Ell only");
+            s->resident = (int)value;  // (chosen per queue run: nothing recorded depends on it)
+            return 0;
         case ELLHIP_OPT_FUSE_DOTS: {
             if (!ell) return fail(ELLHIP_E_INVALID, "this option exists on Ell only");
             if (s->in_two_phase) return fail(ELLHIP_E_STATE, "update_begin without update_end");
@@ -1583,6 +1697,7 @@ int ellhip_get_option(const ellhip_space* s, int key, int64_t* value) {
         case ELLHIP_OPT_APPLY_LOWER: *value = s->apply_lower; break;
         case ELLHIP_OPT_APPLY_KERNEL: *value = s->apply_kernel; break;
         case ELLHIP_OPT_FUSE_DOTS: *value = s->fuse_dots; break;
+        case ELLHIP_OPT_RESIDENT: *value = s->resident; break;
         case ELLHIP_OPT_STABLE_SOLVE: *value = s->stable_solve; break;
         case ELLHIP_OPT_STABLE_FACTOR: *value = s->stable_factor; break;
         case ELLHIP_OPT_PAD: *value = s->ld - s->n; break;
@@ -1697,6 +1812,7 @@ int ellhip_queue_end(ellhip_space* s, int64_t index) {
 int ellhip_queue_run(ellhip_space* s, int64_t first, int64_t count) {
     if (!s || first < 0 || count < 0 || first + count > s->qk) return fail(ELLHIP_E_INVALID, "queue range");
     DeviceGuard guard(s->device);
+    if (resident_ok(s, count)) return resident_run(s, first, count);
     for (int64_t i = first; i < first + count; ++i) {
         int rc = queue_prime_impl(s, i);
         if (!rc) rc = queue_cut_impl(s, i);
@@ -1709,6 +1825,7 @@ int ellhip_queue_run(ellhip_space* s, int64_t first, int64_t count) {
 int ellhip_queue_run_fused(ellhip_space* s, int64_t first, int64_t count) {
     if (!s || first < 0 || count < 0 || first + count > s->qk) return fail(ELLHIP_E_INVALID, "queue range");
     DeviceGuard guard(s->device);
+    if (resident_ok(s, count)) return resident_run(s, first, count);
     for (int64_t i = first; i < first + count; ++i) {
         int rc = queue_prime_impl(s, i);  // (pipelined form: only the first cut of a run pays a separate GEMV pass)
         if (!rc) rc = queue_cut_impl(s, i);

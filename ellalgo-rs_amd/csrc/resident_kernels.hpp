@@ -227,7 +227,8 @@ __global__ __launch_bounds__(RS_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
     };
     if (A.count > 0 && !halted && tid < NV) g_put(0, tid, g_at(A.qgrads + A.first * n, tid));
     __syncthreads();
-    for (long long cut = A.first; cut < A.first + A.count && !halted; ++cut) {
+    long long cut = A.first;
+    for (; cut < A.first + A.count && !halted; ++cut) {
         const int par = (int)((cut - A.first) & 1);
         RS_STAMP(0);
         // ---- 1. partial sums of y = Q g on the resident tiles, and this workgroup's share of omega
@@ -363,6 +364,7 @@ __global__ __launch_bounds__(RS_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
         }
         if (status != 0) {  // :107-109: Q, xc, kappa untouched; the queue halts here (src/cutting_plane.rs:308)
             halted = 1;
+            ++cut;
             break;
         }
         RS_STAMP(5);
@@ -447,6 +449,12 @@ __global__ __launch_bounds__(RS_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
     if (wg == 0 && tid == 0) {
         A.st->kappa = kappa;
         if (err) atomicExch(&A.st->solve_err, RS_WAIT_ERR);
+        // cuts behind a halt never ran: the status the streamed scalar stage reports for them (ELLHIP_UNKNOWN)
+        const double t_last = A.st->tsq;
+        for (long long c = cut; c < A.first + A.count; ++c) {
+            A.qstatus[c] = ST_UNKNOWN;
+            A.qtsq[c] = t_last;
+        }
     }
 }
 

@@ -213,6 +213,10 @@ int ellhip_set_shard_symmetric(ellhip_space *s, int flag);
  *   ELLHIP_OPT_APPLY_LOWER       0 / 1      1        Ell: apply passes touch the lower triangle only (8 n^2 bytes)
  *   ELLHIP_OPT_APPLY_KERNEL      0 / 1      1        Ell, depth 8: 1 = k_apply_lower (16-row tiles), 0 = k_sweep_apply
  *   ELLHIP_OPT_FUSE_DOTS         0 / 1      1        Ell: the scalar stage's dot products come out of the GEMV's launch
+ *   ELLHIP_OPT_RESIDENT          0 / 1      1        Ell: ellhip_queue_run / _run_fused of >= 4 cuts park the lower triangle in the
+ *                                                    chip's register files and run the whole batch in ONE persistent launch
+ *                                                    (n <= 4224 on a 256-CU device: 9 us instead of 39 us per update at
+ *                                                    n = 4096); 0 = always the streamed schedules
  *   ELLHIP_OPT_STABLE_SOLVE      0 / 1 / 2  2        EllStable: 0 = one launch per 128-block (no in-launch waits),
  *                                                    1 = persistent solves, 2 = persistent + helper workgroups
  *   ELLHIP_OPT_STABLE_FACTOR     0 / 1 / 2  2        EllStable factor update: 0 = tile kernel reading the scratch
@@ -224,8 +228,9 @@ int ellhip_set_shard_symmetric(ellhip_space *s, int flag);
  *   ELLHIP_OPT_LP_WIDE           -1 / 0 / 1 -1       default only: column-split LowpassOracle scan kernel (-1 = by size)
  *   ELLHIP_OPT_BATCH_THREADS     0/64/128/256 0      default only: threads per workgroup of the batched engine
  * All forms of one option produce identical bits, except SYMV / SYMV_MIN_N (the lower-triangle GEMV sums Q*g in
- * another association than the full-row GEMV) and FUSE_DOTS on the lower-triangle schedule (dot products summed per
- * 128 columns instead of per slice): there results agree to ~1e-15, see "deferred shrink" above. */
+ * another association than the full-row GEMV), FUSE_DOTS on the lower-triangle schedule (dot products summed per
+ * 128 columns instead of per slice) and RESIDENT (Q*g summed per 4 x 2 register block and super-tile): there results
+ * agree to ~1e-15, see "deferred shrink" above. */
 #define ELLHIP_OPT_AUTO_DEFER 1
 #define ELLHIP_OPT_SYMV 2
 #define ELLHIP_OPT_SYMV_MIN_N 3
@@ -238,6 +243,7 @@ int ellhip_set_shard_symmetric(ellhip_space *s, int flag);
 #define ELLHIP_OPT_LP_GRID 10
 #define ELLHIP_OPT_LP_WIDE 11
 #define ELLHIP_OPT_BATCH_THREADS 12
+#define ELLHIP_OPT_RESIDENT 13
 int ellhip_set_option(ellhip_space *s, int key, int64_t value);
 int ellhip_get_option(const ellhip_space *s, int key, int64_t *value);
 int ellhip_set_default_option(int key, int64_t value);
@@ -277,8 +283,9 @@ int ellhip_synchronize(ellhip_space *s);
  * 6 = fused pass (rank-1 of cut k + GEMV of cut k+1), 7 = deferred apply pass (8 recorded updates),
  * 8 = deferred apply pass fused with the next GEMV, 9 = symmetric GEMV pass (lower triangle only,
  * 4 n^2 bytes; deferred mode on an unsharded handle), 10 = the partial-sum reduction that follows it,
- * 11 = LowpassOracle scan (ellhip_lowpass.h), 12 = LowpassOracle finish (cut assembly). */
-#define ELLHIP_NKERNEL_CLASSES 13
+ * 11 = LowpassOracle scan (ellhip_lowpass.h), 12 = LowpassOracle finish (cut assembly), 13 = resident queue run (one
+ * launch per batch of cuts, the matrix parked on-chip). */
+#define ELLHIP_NKERNEL_CLASSES 14
 int ellhip_profile_enable(ellhip_space *s, int flag);
 int ellhip_profile_read(ellhip_space *s, double *ms_out, int64_t *count_out);
 

@@ -228,7 +228,9 @@ int main(int argc, char** argv) {
             std::printf("{\"case\": \"ranks\", \"ok\": false, \"error\": \"ellhip_create: %s\"}\n", ellhip_last_error());
             return 0;
         }
-        // an equal-block shard runs full-row GEMVs: so must the reference, for the comparison to be one of bits
+        // an equal-block shard runs full-row GEMVs: so must the reference, for the comparison to be one of bits -- and
+        // neither may its queue runs take the resident kernel (its own summation shape)
+        (void)ellhip_set_option(h.s, ELLHIP_OPT_RESIDENT, 0);
         if (partition == ELLHIP_SHARD_EQUAL_BLOCKS) (void)ellhip_set_option(h.s, ELLHIP_OPT_SYMV, 0);
         else (void)ellhip_set_option(h.s, ELLHIP_OPT_SYMV_MIN_N, 512);
         (void)ellhip_set_defer_depth(h.s, depth);

@@ -52,6 +52,7 @@ def test_deferred_deep_cuts_large(gpu, orc, n):
 
 def test_deferred_all_schedules_bit_identical(gpu):
     """direct updates == two-pass queue == pipelined queue == prime/cut/commit, for depth 8."""
+    set_default("RESIDENT", 0)   # the STREAMED schedules are compared bit for bit here; the resident queue run sums Q g in its own shape (test_gpu_resident.py)
     from ellalgo_rs_amd import synth
     n, k = 640, 21
     kinds, grads, b0, b1 = synth.parallel_cuts(n, k)
@@ -436,6 +437,7 @@ def test_dot_products_beside_the_full_row_gemv_equal_the_separate_launch(gpu, n)
     workgroups of the GEMV's launch (k_sweep_gemv_dots) and g . y inside k_scalar_apply_def -- in k_scalar_dot_def's exact
     shape, so the bits equal those of the separate launch (option 0): direct updates, the two-pass queue and the
     pipelined queue, with a failing cut."""
+    set_default("RESIDENT", 0)   # the STREAMED schedules are compared bit for bit here; the resident queue run sums Q g in its own shape (test_gpu_resident.py)
     from ellalgo_rs_amd import synth
     k = 21
     kinds, grads, b0, b1 = synth.parallel_cuts(n, k)
@@ -470,6 +472,7 @@ def test_dot_products_from_the_symv_reduction_agree_with_the_separate_launch(gpu
     sums per 128 columns); with the option off the separate k_scalar_dot_def launch forms them in its own shape.  The two
     associate the dot products differently, so they agree to rounding (1e-13), not to the bit; the drivers of ONE form
     (direct updates, two-pass queue, pipelined queue, with a failing cut) agree bit for bit."""
+    set_default("RESIDENT", 0)   # the STREAMED schedules are compared bit for bit here; the resident queue run sums Q g in its own shape (test_gpu_resident.py)
     from ellalgo_rs_amd import synth
     set_default("SYMV_MIN_N", 512)
     k = 37

@@ -14,6 +14,7 @@ import traceback
 
 import numpy as np
 import pytest
+
 import torch.multiprocessing as mp
 
 pytestmark = pytest.mark.gpu
@@ -59,6 +60,9 @@ def _worker(rank, world, port, backend, n, k, fused, defer, errq, symmetric=Fals
             gt.copy_(t.to(gt.device))
 
         kinds, grads, b0, b1 = synth.parallel_cuts(n, k)
+        # row shards stream; their unsharded reference must too for a comparison of bits (the resident queue run of an
+        # unsharded handle sums Q g in its own shape: test_gpu_resident.py)
+        pkg.capi.set_default_option(pkg.capi.OPT_RESIDENT, 0)
         ref = pkg.Ell.new_with_scalar(1.0, np.zeros(n), device=0)
         ex = None if backend == "nccl" else (bounce_sum if symmetric else bounce)
         sh = ShardedEll.new_with_scalar(1.0, np.zeros(n), device=0, exchange=ex, symmetric=symmetric)
