@@ -489,12 +489,21 @@ def brief_config(pkg, synth, torch, workload: str, K: int, W: int, P: int, devic
     lower_apply = symv_mode and opt(pkg.capi.OPT_APPLY_LOWER) != 0
     alg = {"gemv": 8.0 * n2, "rank1": 16.0 * n2, "fused": 16.0 * n2, "apply": (8.0 if lower_apply else 16.0) * n2,
            "apply_gemv": 16.0 * n2, "symv": 4.0 * n2, "stable_fwd": 8.0 * n2, "stable_bwd": 4.0 * n2, "stable_factor": 12.0 * n2}
+    resident = variant == "ell" and prof.get("resident", (0.0, 0))[1] > 0
     if variant != "ell":
         fb = 8.0 if space.get_option(pkg.capi.OPT_STABLE_FACTOR) != 0 else 12.0
         alg["stable_factor"] = fb * n2
         if prof.get("stable_factor", (0.0, 0))[1] == 0:   # pulled inside the backward solve's launch
             alg["stable_bwd"] = (4.0 + fb) * n2
         bytes_update, model = (12.0 + fb) * n2, f"{12.0 + fb:g}*n^2 B per update (EllStable: fwd 8 + bwd 4 + factor {fb:g})"
+    elif resident:
+        # one persistent launch per batch: the lower triangle is parked in the register files (4 n^2 read), written back
+        # (4 n^2) and mirrored (16 n^2) ONCE per batch; per update only the gradient (8 n) and O(n) partial sums move
+        alg["resident"] = (8.0 * n2 + 8.0 * n * P) if P else 8.0 * n2
+        bytes_update = 24.0 * n2 / K + 8.0 * n
+        model = (f"(24*n^2 per batch of {K} cuts: park 4 + write back 4 + mirror 16) / {K} + 8*n B per update -- the matrix lives in "
+                 "the register files for the whole batch (k_ell_resident): NOT HBM-bound, the update is two on-chip hand-offs "
+                 "(one grid barrier) long")
     else:
         bytes_update, model = ell_bytes_per_update(n2, "pipelined", depth, K, symv_mode, lower_apply)
     per_kernel = {}
@@ -512,14 +521,19 @@ def brief_config(pkg, synth, torch, workload: str, K: int, W: int, P: int, devic
     upd_gbps = bytes_update / (ms_per_step * 1e-3) / 1e9
     roofline = {"whole_update": {"alg_bytes": bytes_update, "GBps": upd_gbps, "frac": upd_gbps / HBM_PEAK_GBS, "byte_model": model}}
     if dom:
-        kname = {"symv": "k_symv", "apply": "k_apply_lower", "gemv": "k_sweep_gemv_dots"}.get(dom, dom)
+        kname = {"symv": "k_symv", "apply": "k_apply_lower", "gemv": "k_sweep_gemv_dots", "resident": "k_ell_resident"}.get(dom, dom)
         roofline.update({"kernel": kname if variant == "ell" else "k_st_" + dom[7:], "achieved": per_kernel[dom]["GBps"],
                          "frac": per_kernel[dom]["GBps"] / HBM_PEAK_GBS, "avg_launch_ms": per_kernel[dom]["avg_ms"],
                          "alg_bytes_per_launch": per_kernel[dom]["alg_bytes"]})
     roofline["per_kernel"] = per_kernel
+    if resident:
+        roofline["bound"] = "on-chip latency (one grid barrier + two L2 hand-offs per update), not HBM"
+        roofline["us_per_update_in_launch"] = per_kernel["resident"]["avg_ms"] * 1e3 / max(P, 1)
     del space
     return {"workload": workload, "description": desc, "updates_per_s": K / elapsed, "ms_per_step": ms_per_step, "steps": K,
-            "warmup": W, "defer_depth": depth, "schedule": "pipelined" if variant == "ell" else "ellstable", "roofline": roofline}
+            "warmup": W, "defer_depth": depth,
+            "schedule": ("resident (one launch per batch)" if resident else "pipelined") if variant == "ell" else "ellstable",
+            "roofline": roofline}
 
 
 def main() -> None:
@@ -543,7 +557,7 @@ def main() -> None:
     ap.add_argument("--schedule", choices=["pipelined", "two-pass"], default="pipelined",
                     help="pipelined: one pass over Q per update (shrink of cut k fused with the GEMV of cut k+1, "
                          "16*n^2 B); two-pass: GEMV pass + rank-1 pass per update (24*n^2 B). Same results.")
-    ap.add_argument("--defer", type=int, choices=[0, 1, 8, 16], default=0,
+    ap.add_argument("--defer", type=int, choices=[0, 1, 8, 16, 24], default=0,
                     help="0 (default): 16 where the lower-triangle schedule exists (unsharded n even >= 8192, symmetric "
                          "shards), else 8.  "
                          "8: record cuts and apply them to Q in batches of 8 (GEMV passes are read-only, "
@@ -652,8 +666,8 @@ def main() -> None:
     # alternatives measured after the main run, on the same handle: (schedule, depth)
     alts = []
     if C2 > 0:
-        for alt in (("pipelined", 16), ("pipelined", 8), ("pipelined", 1), ("two-pass", 8), ("two-pass", 1)):
-            if alt[1] == 16 and (sharded or not lower_ok or n < symv_min_n):
+        for alt in (("pipelined", 24), ("pipelined", 16), ("pipelined", 8), ("pipelined", 1), ("two-pass", 8), ("two-pass", 1)):
+            if alt[1] >= 16 and (sharded or not lower_ok or n < symv_min_n):
                 continue  # depth 16 exists on the lower-triangle schedule only
             if alt != (args.schedule, depth):
                 alts.append(alt)
@@ -835,7 +849,8 @@ def main() -> None:
     lower_apply = symv_mode and opt(pkg.capi.OPT_APPLY_LOWER) != 0
     alg = {"gemv": 8.0 * n2w, "rank1": 16.0 * n2w, "fused": 16.0 * n2w, "apply": (8.0 if lower_apply else 16.0) * n2w,
            "apply_gemv": 16.0 * n2w, "symv": 4.0 * n2w,
-           "stable_fwd": 8.0 * n * n, "stable_bwd": 4.0 * n * n, "stable_factor": 12.0 * n * n}
+           "stable_fwd": 8.0 * n * n, "stable_bwd": 4.0 * n * n, "stable_factor": 12.0 * n * n,
+           "resident": 8.0 * n2w}   # one launch per batch: park 4 n^2 + write back 4 n^2 (+ 8 n per cut)
     if variant != "ell":
         # EllStable: the factor update rewrites the strict upper triangle from itself (8*n^2; the scratch entry the
         # reference adds IS fl(U*w)) unless the scratch-reading tile kernel is forced; and it runs
@@ -863,9 +878,15 @@ def main() -> None:
     per_kernel = kernel_table(prof)
     # bytes one update moves under the schedule that was timed (each schedule has its OWN byte model;
     # nothing is credited against the 24*n^2 two-pass model)
+    resident_run = variant == "ell" and bool(prof) and prof.get("resident", (0.0, 0))[1] > 0
     if variant != "ell":
         fb = alg["stable_factor"] / (n * n)
         bytes_update, model = (12.0 + fb) * n * n, f"{12.0 + fb:g}*n^2 B per update (EllStable: fwd 8 + bwd 4 + factor {fb:g})"
+    elif resident_run:
+        bytes_update = 24.0 * n2w / K + 8.0 * n
+        model = (f"(24*n^2 per batch of {K} cuts: park 4 + write back 4 + mirror 16) / {K} + 8*n B per update -- the matrix lives in "
+                 "the register files for the whole batch (k_ell_resident): NOT HBM-bound, the update is two on-chip hand-offs "
+                 "(one grid barrier) long")
     else:
         bytes_update, model = byte_model("pipelined" if fused else "two-pass", depth, K)
     roofline = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None, "byte_model": model}
@@ -877,7 +898,7 @@ def main() -> None:
         cands = [k for k in per_kernel if k in alg]
         dom = max(cands, key=lambda k: per_kernel[k]["avg_ms"]) if cands else None
     if dom in per_kernel:
-        kname = {"symv": "k_symv", "apply": "k_sweep_apply", "apply_gemv": "k_sweep_apply"}.get(dom, "k_sweep:" + dom)
+        kname = {"symv": "k_symv", "apply": "k_sweep_apply", "apply_gemv": "k_sweep_apply", "resident": "k_ell_resident"}.get(dom, "k_sweep:" + dom)
         roofline.update({"kernel": kname if variant == "ell" else "k_st_" + dom[7:],
                          "achieved": per_kernel[dom]["GBps"], "frac": per_kernel[dom]["GBps"] / HBM_PEAK_GBS,
                          "alg_bytes_per_launch": per_kernel[dom]["alg_bytes"],
@@ -920,7 +941,8 @@ def main() -> None:
         "dtype": "f64",
         "data": "synthetic",
         "config": {"workload": args.workload, "n": n, "space": variant, "cuts": cutgen,
-                   "schedule": ("pipelined" if fused else "two-pass") if variant == "ell" else "ellstable",
+                   "schedule": (("resident (one launch per batch)" if resident_run else ("pipelined" if fused else "two-pass"))
+                                if variant == "ell" else "ellstable"),
                    "defer_depth": depth,
                    "description": desc,
                    "partition": (f"symmetric row shards x{world} (boundaries at n*sqrt(r/P), all-reduce)" if shard_sym

@@ -99,7 +99,7 @@ __device__ __forceinline__ void queue_bookkeeping(DevState* st, int status, doub
 // through exactly the roundings of the reference's one-update-at-a-time loop (src/ell.rs:117-128).
 // Per update: 8 n^2 (1 + 1/MAXPEND) + ... bytes instead of 16 n^2 (pipelined) or 24 n^2 (two-pass).
 // Unused slots hold c_j = 0 and v_j = 0, which makes every formula above an exact no-op for them.
-constexpr int MAXPEND = 16;  // capacity of the pending-update buffers; the depth in force (NP) is 8 or 16
+constexpr int MAXPEND = 24;  // capacity of the pending-update buffers; the depth in force (NP) is 8, 16 or 24
 
 typedef double double2_t __attribute__((ext_vector_type(2)));
 
@@ -734,7 +734,7 @@ constexpr int APL_TR = 16;
 
 // APL_RG = rows in flight per thread (measured at n = 16384, ms per pass: depth 8: RG 4 0.426, 8 0.404, 16 0.397;
 // depth 16: RG 4 0.409, 8 0.471, 16 1.57 (spills)).
-template <int NP, bool NT, int APL_RG = (NP == 16 ? 4 : 8)>
+template <int NP, bool NT, int APL_RG = (NP >= 16 ? 4 : 8)>
 __global__ __launch_bounds__(256) void k_apply_lower(double* __restrict__ Q, long long ld, long long n,
                                                      long long nrows, long long row0,
                                                      const double* __restrict__ pend,

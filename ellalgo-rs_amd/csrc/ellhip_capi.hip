@@ -384,7 +384,9 @@ int flush_pending(ellhip_space* s, const double* gvec, double* gv_out) {
 #define APL_GO(NPV, NTV)                                                                                        \
     hipLaunchKernelGGL((k_apply_lower<NPV, NTV>), dim3(grid), dim3(256), 0, s->stream, s->d_Q, s->ld, s->n, s->nrows, \
                        s->row0, (const double*)s->d_pend, (const double*)s->d_cpend, (const DevState*)s->d_st)
-            if (s->defer == 16) {  // 16 pending updates: the 16-row-tile kernel (coefficients in LDS)
+            if (s->defer == 24) {  // 24 / 16 pending updates: the 16-row-tile kernel (coefficients in LDS)
+                if (nt) APL_GO(24, true); else APL_GO(24, false);
+            } else if (s->defer == 16) {
                 if (nt) APL_GO(16, true); else APL_GO(16, false);
             } else if (s->apply_kernel == 1) {  // depth 8, same kernel (0.40 ms; ELLHIP_APPLY_KERNEL=0: k_sweep_apply, 0.44)
                 if (nt) APL_GO(8, true); else APL_GO(8, false);
@@ -397,7 +399,7 @@ int flush_pending(ellhip_space* s, const double* gvec, double* gv_out) {
             rc = 0;
             s->upper_stale = true;
         } else if (s->defer != 8) {
-            return fail(ELLHIP_E_STATE, "defer depth 16 needs the lower-triangle schedule");
+            return fail(ELLHIP_E_STATE, "defer depth 16 / 24 needs the lower-triangle schedule");
         } else if (gvec)
             rc = !even ? launch_apply_t<1, false, true>(s, gvec, gv_out)
                        : (nt ? launch_apply_t<2, true, true>(s, gvec, gv_out) : launch_apply_t<2, false, true>(s, gvec, gv_out));
@@ -627,7 +629,8 @@ int launch_symv_reduce(ellhip_space* s, const double* g_dev, double* y_out) {
     hipLaunchKernelGGL(k_symv_reduce<NPV>, dim3((unsigned)((s->n + 127) / 128)), dim3(256), 0, s->stream, s->n, s->row0, \
                        s->nrows, (long long)seg, (const double*)s->d_rowpart, (const double*)s->d_colpart, y_out,      \
                        s->d_st, g_dev, (const double*)s->d_pend, s->d_partial)
-    if (np == 16) REDUCE_GO(16);
+    if (np == 24) REDUCE_GO(24);
+    else if (np == 16) REDUCE_GO(16);
     else if (np == 8) REDUCE_GO(8);
     else REDUCE_GO(0);
 #undef REDUCE_GO
@@ -685,7 +688,7 @@ int do_cut(ellhip_space* s, const double* g_dev, const CutParams* cp_dev, CutPar
         hipLaunchKernelGGL(k_scalar_apply_def<NPV>, dim3(G), dim3(256), 0, s->stream, s->n, gt, s->d_xc, s->d_pend, \
                            s->d_cpend, (const double*)s->d_partial, s->d_st, calc, cp_dev, cp_val, s->npend,      \
                            queue_mode, qst, qtsq, npart, (const double*)nullptr)
-        if (s->defer == 16) { SCALAR_DEF(16); } else { SCALAR_DEF(8); }
+        if (s->defer == 24) { SCALAR_DEF(24); } else if (s->defer == 16) { SCALAR_DEF(16); } else { SCALAR_DEF(8); }
 #undef SCALAR_DEF
         HIPCHK(hipGetLastError());
         s->npend += 1;
@@ -1526,7 +1529,7 @@ int ellhip_set_no_defer_trick(ellhip_space* s, int flag) {
 int ellhip_set_defer_depth(ellhip_space* s, int depth) {
     if (!s) return fail(ELLHIP_E_INVALID, "NULL handle");
     if (s->variant != ELLHIP_SPACE_ELL) return fail(ELLHIP_E_INVALID, "deferred shrink exists on Ell only");
-    if (depth != 1 && depth != 8 && depth != 16) return fail(ELLHIP_E_INVALID, "defer depth must be 1, 8 or 16");
+    if (depth != 1 && depth != 8 && depth != 16 && depth != 24) return fail(ELLHIP_E_INVALID, "defer depth must be 1, 8, 16 or 24");
     if (s->shard_symmetric && depth == 1 && s->upper_stale)
         return fail(ELLHIP_E_STATE, "symmetric row shard: the rows are current up to their diagonal only");
     DeviceGuard guard(s->device);
@@ -1536,12 +1539,12 @@ int ellhip_set_defer_depth(ellhip_space* s, int depth) {
         rc = symv_alloc(s);
         if (rc) return rc;
     }
-    if (depth == 16) {
-        // 16 pending updates only fit the lower-triangle schedule (k_symv + k_apply_lower)
+    if (depth >= 16) {
+        // 16 / 24 pending updates only fit the lower-triangle schedule (k_symv + k_apply_lower)
         const bool lower_schedule = s->symv && s->apply_lower && (s->n % 2) == 0 && s->d_rowpart &&
                                     (s->sharded ? s->shard_symmetric : s->n >= s->symv_min_n);
         if (!lower_schedule)
-            return fail(ELLHIP_E_INVALID, "defer depth 16 needs the lower-triangle schedule: an unsharded handle with n "
+            return fail(ELLHIP_E_INVALID, "defer depth 16 / 24 needs the lower-triangle schedule: an unsharded handle with n "
                                           "even and >= 8192, or a symmetric row shard");
     }
     s->defer = depth;
@@ -1672,7 +1675,7 @@ int ellhip_set_option(ellhip_space* s, int key, int64_t value) {
                 rc = symv_alloc(s);  // (a lowered threshold may bring the lower-triangle schedule into reach)
                 if (rc) return rc;
             }
-            if (s->defer == 16) {  // depth 16 exists on the lower-triangle schedule only: fall back to 8 where it is gone
+            if (s->defer >= 16) {  // depth 16 / 24 exist on the lower-triangle schedule only: fall back to 8 where it is gone
                 const bool lower = s->symv && s->apply_lower && (s->n % 2) == 0 && s->d_rowpart &&
                                    (s->sharded ? s->shard_symmetric : s->n >= s->symv_min_n);
                 if (!lower) s->defer = 8;

@@ -214,7 +214,8 @@ int sharded_create_impl(ellhip_sharded** out, int64_t n, double kappa, const dou
     if (custom && (!ag || !ar)) return fail(ELLHIP_E_INVALID, "a host-supplied collective needs both callbacks");
     if (nccl_id && nccl_comm) return fail(ELLHIP_E_INVALID, "give either the unique id or a communicator, not both");
     if (nranks > 1 && !nccl_id && !nccl_comm && !custom) return fail(ELLHIP_E_INVALID, "more than one rank needs a communicator");
-    if (defer_depth != 1 && defer_depth != 8 && defer_depth != 16) return fail(ELLHIP_E_INVALID, "defer depth must be 1, 8 or 16");
+    if (defer_depth != 1 && defer_depth != 8 && defer_depth != 16 && defer_depth != 24)
+        return fail(ELLHIP_E_INVALID, "defer depth must be 1, 8, 16 or 24");
     if (partition == ELLHIP_SHARD_SYMMETRIC && defer_depth == 1)
         return fail(ELLHIP_E_INVALID, "symmetric row shards run the recorded schedule only (depth 8 or 16)");
     if (partition == ELLHIP_SHARD_SYMMETRIC && n < 512)

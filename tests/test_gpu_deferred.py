@@ -215,7 +215,7 @@ def test_symv_equals_full_gemv_to_rounding(gpu, monkeypatch):
 
 
 @pytest.mark.parametrize("n", [512, 1000, 2112, 4096])
-@pytest.mark.parametrize("depth", [8, 16])
+@pytest.mark.parametrize("depth", [8, 16, 24])
 def test_lower_triangle_schedule_depths_match_oracle(gpu, orc, n, depth, monkeypatch):
     """k_symv + k_apply_lower (16-row tiles) at depth 8 and 16, forced on at small sizes; get_mq in between
     exercises the mirror at every phase of the pending count."""
@@ -292,7 +292,7 @@ def test_default_depth_of_new_handles(gpu, monkeypatch):
     assert np.max(np.abs(a.xc() - b.xc())) <= 1e-12 * np.max(np.abs(b.xc()))
 
 
-@pytest.mark.parametrize("depth", [8, 16])
+@pytest.mark.parametrize("depth", [8, 16, 24])
 def test_observers_between_prime_and_cut_keep_the_primed_gradient_valid(gpu, orc, depth, monkeypatch):
     """A gradient that is primed but not yet cut carries y = Q_base*g for the base the recorded updates belong to.
     ellhip_flush / get_mq / clone in that window apply the recorded updates (Q_base changes), so the library must
@@ -405,7 +405,7 @@ def test_long_run_stays_inside_the_parity_tolerance(gpu, orc, depth, monkeypatch
     assert np.all(st == 0)
 
 
-@pytest.mark.parametrize("n,depth", [(40, 8), (640, 8), (640, 16)])
+@pytest.mark.parametrize("n,depth", [(40, 8), (640, 8), (640, 16), (640, 24)])
 def test_depth_switches_between_prime_and_cut_do_not_leak_dot_products(gpu, orc, n, depth, monkeypatch):
     """A prime on a recorded schedule leaves the scalar stage's dot products behind for the NEXT cut.  If the depth is
     switched to 1 before that cut, a fused pass primes the following gradient without any, and the depth is switched
@@ -466,7 +466,7 @@ def test_dot_products_beside_the_full_row_gemv_equal_the_separate_launch(gpu, n)
         assert np.array_equal(s.mq, ref.mq)
 
 
-@pytest.mark.parametrize("n,depth", [(1024, 8), (1024, 16), (2112, 16)])
+@pytest.mark.parametrize("n,depth", [(1024, 8), (1024, 16), (2112, 16), (2112, 24)])
 def test_dot_products_from_the_symv_reduction_agree_with_the_separate_launch(gpu, n, depth):
     """ELLHIP_OPT_FUSE_DOTS on the lower-triangle schedule: k_symv_reduce<NP> yields g . y and v_j . g beside y (partial
     sums per 128 columns); with the option off the separate k_scalar_dot_def launch forms them in its own shape.  The two

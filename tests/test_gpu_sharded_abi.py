@@ -81,7 +81,7 @@ def test_one_rank_equal_blocks_is_bit_identical_to_the_unsharded_engine(gpu, dep
     assert np.array_equal(ref.xc(), s.xc()) and ref.kappa == s.kappa and np.array_equal(ref.mq, s.mq_rows)
 
 
-@pytest.mark.parametrize("depth", [8, 16])
+@pytest.mark.parametrize("depth", [8, 16, 24])
 def test_one_rank_symmetric_shard_all_reduce(gpu, orc, depth):
     """Symmetric partition: lower-triangle GEMV on the local trapezoid, ncclAllReduce of the partial vector, lower-
     trapezoid apply passes; with one rank the trapezoid is the whole triangle."""

@@ -196,7 +196,7 @@ class Walk:
 @pytest.mark.parametrize("n", [40, 129, 640, 1024])
 def test_random_walks_match_oracle(gpu, orc, n, seed, monkeypatch):
     set_default("SYMV_MIN_N", 512)   # n = 640, 1024 run the lower-triangle schedule at depth 8 / 16
-    depths = (1, 8, 16) if (n >= 512 and n % 2 == 0) else (1, 8)
+    depths = (1, 8, 16, 24) if (n >= 512 and n % 2 == 0) else (1, 8)
     Walk(gpu, orc, n, 7000 + 31 * seed + n, depths).run(36)
 
 
@@ -221,7 +221,7 @@ class ShardWalk:
         self.g = ShardedEll.new_with_scalar(3.0, xc0, rank=0, world=1, exchange=lambda gt, row0, nrows: None,
                                             symmetric=symmetric)
         self.o = orc.OracleEll.new_with_scalar(3.0, xc0)
-        self.depths = (8, 16) if symmetric else (1, 8)
+        self.depths = (8, 16, 24) if symmetric else (1, 8)
         self.i = 0
         self.log = []
 

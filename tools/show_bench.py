@@ -20,6 +20,11 @@ for path in sys.argv[1:]:
         pk = {k: (round(v["avg_ms"], 4), round(v.get("GBps", 0))) for k, v in o["per_kernel"].items()}
         print(f'{"":18s} {o["schedule"][:9]:9s} d{o["defer_depth"]}        upd/s={o["updates_per_s"]:9.1f} ms={o["ms_per_step"]:.4f} '
               f'whole={o["whole_update"]["frac"]:.3f} {pk}')
+    for o in d.get("other_configs", []):
+        ro = o["roofline"]
+        pk = {k: (round(v["avg_ms"], 4), round(v.get("GBps", 0))) for k, v in ro.get("per_kernel", {}).items()}
+        print(f'  + {o["workload"]:18s} {o["schedule"][:9]:9s} d{o["defer_depth"]} steps={o["steps"]:4d} upd/s={o["updates_per_s"]:9.1f} ms={o["ms_per_step"]:.4f} '
+              f'dom={ro.get("kernel")} frac={ro.get("frac", 0):.3f} whole={ro["whole_update"]["frac"]:.3f} {pk}')
     if "host_call_path" in d:
         hp = d["host_call_path"]
         print(f'{"":18s} host-call path ' + " ".join(f"{k}={v:.1f}" for k, v in hp.items() if k.startswith("updates_per_s")), end="")
