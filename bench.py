@@ -570,6 +570,9 @@ def main() -> None:
     ap.add_argument("--other-configs", choices=["auto", "on", "off"], default="auto",
                     help="after the headline run, time the other BASELINE.json configurations briefly in the same process and "
                          "report them as `other_configs` (auto: with the default workload on one GPU)")
+    ap.add_argument("--opt", action="append", default=[], metavar="KEY=VALUE",
+                    help="ellhip_set_default_option before any handle is created, e.g. --opt APPLY_KERNEL=2 (A/B runs; keys: "
+                         "the ELLHIP_OPT_* names of include/ellhip.h without the prefix)")
     ap.add_argument("--all-configs", action="store_true",
                     help="run every BASELINE.json configuration that has a one-GPU form, one after the other (n4096-deep, "
                          "n16384-parallel, n32768-deep, n16384-ellstable), each as its own process with the same "
@@ -629,6 +632,9 @@ def main() -> None:
     from ellalgo_rs_amd import synth
 
     lib = pkg.capi.load()
+    for kv in args.opt:
+        key, _, val = kv.partition("=")
+        pkg.capi.set_default_option(getattr(pkg.capi, "OPT_" + key.strip().upper()), int(val))
     n, variant, cutgen, desc = WORKLOADS[args.workload]
     K, W, P = args.steps, args.warmup, args.profile_steps
     # EllStable does not shard (its triangular solves are sequential along the partitioned dimension): with N > 1
@@ -646,7 +652,7 @@ def main() -> None:
     lower_ok = n % 2 == 0 and opt(pkg.capi.OPT_SYMV) != 0 and opt(pkg.capi.OPT_APPLY_LOWER) != 0
     if depth == 0:  # auto: 16 pending updates per apply pass where the lower-triangle schedule runs, else 8
         if not sharded:
-            depth = 16 if (lower_ok and n >= symv_min_n) else 8
+            depth = 24 if (lower_ok and n >= symv_min_n) else 8
         else:
             sym = (n % 64 == 0 and n // 64 >= world and (float(n) * n / 2 / world) / (64 * 2048) >= 200
                    and os.environ.get("ELLHIP_SHARD_SYMMETRIC", "1") != "0")
@@ -950,6 +956,7 @@ def main() -> None:
                                 else (f"replicas only x{world} (independent search spaces, no data-path collective)"
                                       if replicas else "none"),
                    "q_bytes_per_gpu": 8.0 * n * n / (1 if replicas else world),
+                   **({"options": args.opt} if args.opt else {}),
                    **({"collective_issued_by": sharded_via} if sharded else {})},
         "roofline": roofline,
     }

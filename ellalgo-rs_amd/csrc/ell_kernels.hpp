@@ -786,6 +786,108 @@ __global__ __launch_bounds__(256) void k_apply_lower(double* __restrict__ Q, lon
     }
 }
 
+// ------------------------------------------------------------------------------ k_apply_mfma ---
+// The same lower-trapezoid apply pass on the FP64 matrix cores: the NP recorded updates are ONE rank-NP update
+//     Q[rows, cols] += A B,   A[r][k] = -(c_k v_k[r])  (16 x NP per wave),   B[k][c] = v_k[c]  (NP x 16 per tile),
+// NP / 4 v_mfma_f64_16x16x4_f64 per 16 x 16 tile.  Why: k_apply_lower keeps NP pending vectors (2 NP registers) AND
+// NP x rows-in-flight coefficients in registers -- 216 VGPRs at NP = 16 (two workgroups per CU), 256 + spills into the
+// accumulation file at NP = 24 (0.62 ms per pass against 0.40) -- so the depth could not grow; here the accumulators are
+// 4 doubles per tile and the operands one double each, whatever NP is.  The matrix pipe runs at the vector FMA rate
+// (64 cycles per instruction and SIMD): at NP = 24 about a fifth of it is used, the pass stays HBM-bound.
+// Mapping: workgroup = 64 rows (wave w: rows 16 w ..) x APM_COLS columns of the trapezoid; the pending vectors' 128-column
+// block is staged through LDS (double-buffered) and shared by the four waves; a lane loads 16-byte pairs (columns 2m,
+// 2m + 1 of four rows: the C layout of the f64 MFMA is col = lane & 15, row = (lane >> 4) + 4 i), the even columns feed
+// one tile, the odd ones a second.
+// Numerics: every element receives x + sum_k (-(c_k v_k[r])) v_k[c] as a chain of fused multiply-adds in recording
+// order (one rounding per update) where the reference and k_apply_lower round the product and the difference
+// separately (two): the results differ in the last bit per update and stay far inside the 1e-10 contract; the
+// coefficient c_k v_k[r] itself is rounded exactly as src/ell.rs:119 rounds r_qg.  Elements right of the diagonal inside
+// the diagonal 64-column block get the same expression (stale by contract, as in k_apply_lower).
+typedef double double4_t __attribute__((ext_vector_type(4)));
+constexpr int APM_ROWS = 64;
+constexpr int APM_COLS = 1024;
+
+template <int NP, bool NT>
+__global__ __launch_bounds__(256) void k_apply_mfma(double* __restrict__ Q, long long ld, long long n, long long nrows,
+                                                    long long row0, const double* __restrict__ pend,
+                                                    const double* __restrict__ cpend, const DevState* __restrict__ st) {
+    static_assert(NP % 8 == 0, "rank of the update: a multiple of 8 (k = 4 per MFMA, whole pairs per staging thread)");
+    constexpr int KS = NP / 4;
+    constexpr int SPT = NP / 8;               // 16-byte pairs of the pending vectors a thread stages per 64-column block
+    __shared__ double sh_v[2][NP][APM_ROWS];  // the pending vectors on a 64-column block (this one | the next)
+    (void)st;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long long strip = (long long)gridDim.x - 1 - blockIdx.x;  // last (longest) strips first
+    const long long lr0 = strip * APM_ROWS;
+    if (lr0 >= nrows) return;
+    const long long gr0 = row0 + lr0;                                     // first global row of the strip
+    const long long glast = (lr0 + APM_ROWS <= nrows ? lr0 + APM_ROWS : nrows) - 1 + row0;  // last global row
+    long long cend = (glast / 2 + 1) * 2;                                 // first column past the strip's diagonal (pair aligned)
+    if (cend > n) cend = n;
+    const long long c_begin = (long long)blockIdx.y * APM_COLS;
+    if (c_begin >= cend) return;
+    const long long c_stop = (c_begin + APM_COLS < cend) ? c_begin + APM_COLS : cend;
+    // A operand: A[row = lane & 15][k = lane >> 4] of k-step s = -(c_k v_k[row]), k = 4 s + (lane >> 4)
+    const long long arow = gr0 + 16 * wave + (lane & 15);
+    double a[KS];
+#pragma unroll
+    for (int sidx = 0; sidx < KS; ++sidx) {
+        const int k = 4 * sidx + (lane >> 4);
+        a[sidx] = (arow <= glast) ? -(cpend[k] * pend[(long long)k * n + arow]) : 0.0;  // r_qg of src/ell.rs:119, negated
+    }
+    // staging of the pending vectors' block [cb, cb + 64): NP x 32 pairs, SPT per thread -- requested into registers at
+    // the top of a step, parked in LDS after the step's MFMAs (their latency hides behind the step)
+    const int sk = tid >> 5, sj = (tid & 31) * 2;     // vector sk + 8 t, columns sj, sj + 1 of the block
+    auto fetch = [&](double2_t (&v)[SPT], long long cb) {
+#pragma unroll
+        for (int t = 0; t < SPT; ++t)
+            v[t] = (cb + sj < n) ? *reinterpret_cast<const double2_t*>(pend + (long long)(sk + 8 * t) * n + cb + sj) : double2_t{0.0, 0.0};
+    };
+    auto park = [&](int buf, const double2_t (&v)[SPT]) {
+#pragma unroll
+        for (int t = 0; t < SPT; ++t) *reinterpret_cast<double2_t*>(&sh_v[buf][sk + 8 * t][sj]) = v[t];
+    };
+    int buf = 0;
+    {
+        double2_t v0[SPT];
+        fetch(v0, c_begin);
+        park(0, v0);
+    }
+    __syncthreads();
+    double* rbase = Q + (lr0 + 16 * wave + (lane >> 4)) * ld + 2 * (lane & 15);  // this lane's pair of row (lane >> 4) of the wave
+    for (long long cb = c_begin; cb < c_stop; cb += APM_ROWS) {
+        const bool more = cb + APM_ROWS < c_stop;
+        double2_t vn[SPT];
+        if (more) fetch(vn, cb + APM_ROWS);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const long long c = cb + 32 * h + 2 * (lane & 15);
+            double2_t x[4];
+            bool on[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const long long grow = gr0 + 16 * wave + (lane >> 4) + 4 * i;
+                on[i] = grow <= glast && c < c_stop;
+                x[i] = on[i] ? ld_stream<NT, double2_t>(rbase + (long long)(4 * i) * ld + cb + 32 * h) : double2_t{0.0, 0.0};
+            }
+            double4_t ce = {x[0].x, x[1].x, x[2].x, x[3].x}, co = {x[0].y, x[1].y, x[2].y, x[3].y};
+#pragma unroll
+            for (int sidx = 0; sidx < KS; ++sidx) {
+                const double2_t b = *reinterpret_cast<const double2_t*>(&sh_v[buf][4 * sidx + (lane >> 4)][32 * h + 2 * (lane & 15)]);
+                ce = __builtin_amdgcn_mfma_f64_16x16x4f64(a[sidx], b.x, ce, 0, 0, 0);
+                co = __builtin_amdgcn_mfma_f64_16x16x4f64(a[sidx], b.y, co, 0, 0, 0);
+            }
+            const double oe[4] = {ce.x, ce.y, ce.z, ce.w}, oo[4] = {co.x, co.y, co.z, co.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (on[i]) *reinterpret_cast<double2_t*>(rbase + (long long)(4 * i) * ld + cb + 32 * h) = double2_t{oe[i], oo[i]};
+        }
+        if (more) park(buf ^ 1, vn);
+        __syncthreads();  // everybody is done with sh_v[buf]; sh_v[buf ^ 1] is complete
+        buf ^= 1;
+    }
+}
+
 // After a flush: forget the pending updates (unused slots must read as exact zeros).
 __global__ __launch_bounds__(256) void k_pend_reset(double* __restrict__ pend, double* __restrict__ cpend,
                                                     long long total, DevState* __restrict__ st) {

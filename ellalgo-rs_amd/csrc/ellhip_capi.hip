@@ -63,7 +63,7 @@ struct Defaults {
     int symv = 1;              // ELLHIP_OPT_SYMV
     long long symv_min_n = 8192;  // ELLHIP_OPT_SYMV_MIN_N
     int apply_lower = 1;       // ELLHIP_OPT_APPLY_LOWER
-    int apply_kernel = 1;      // ELLHIP_OPT_APPLY_KERNEL
+    int apply_kernel = -1;     // ELLHIP_OPT_APPLY_KERNEL (-1: by depth)
     int fuse_dots = 1;         // ELLHIP_OPT_FUSE_DOTS
     int resident = 1;          // ELLHIP_OPT_RESIDENT
     int stable_solve = 2;      // ELLHIP_OPT_STABLE_SOLVE
@@ -126,7 +126,7 @@ struct ellhip_space {
     int dots_np = 0;                 // > 0: d_partial holds dot products of the primed gradient for this depth: [ceil(n/128)][dots_np + 1]
                                      // from k_symv_reduce, or [scalar_groups(n)][...] WITHOUT the g.y column from k_sweep_gemv_dots
     bool dots_need_gy = false;       // the latter: k_scalar_apply_def forms g.y itself
-    int apply_kernel = 1;            // depth 8: 1 = k_apply_lower (16-row tiles, 0.40 ms at n = 16384), 0 = k_sweep_apply<LOWER> (0.44 ms)
+    int apply_kernel = -1;           // lower-triangle apply pass: 2 = k_apply_mfma, 1 = k_apply_lower, 0 = k_sweep_apply<LOWER> (depth 8); -1 = 2 at depth 24, else 1
     bool upper_stale = false;        // strict upper triangle of Q is out of date (see flush_pending)
     int defer = 1;                   // 1 = shrink Q at every cut; MAXPEND = record and apply in batches
     int npend = 0;                   // updates recorded since the last flush (host view, optimistic in queue mode)
@@ -384,11 +384,23 @@ int flush_pending(ellhip_space* s, const double* gvec, double* gv_out) {
 #define APL_GO(NPV, NTV)                                                                                        \
     hipLaunchKernelGGL((k_apply_lower<NPV, NTV>), dim3(grid), dim3(256), 0, s->stream, s->d_Q, s->ld, s->n, s->nrows, \
                        s->row0, (const double*)s->d_pend, (const double*)s->d_cpend, (const DevState*)s->d_st)
-            if (s->defer == 24) {  // 24 / 16 pending updates: the 16-row-tile kernel (coefficients in LDS)
+            // measured at n = 16384, ms per pass: k_apply_mfma 0.43-0.44 at any depth; k_apply_lower 0.40 at depth 8 / 16,
+            // 0.62 at depth 24 (its registers); k_sweep_apply<LOWER> 0.44 (depth 8)
+            const int apply_kernel = s->apply_kernel < 0 ? (s->defer == 24 ? 2 : 1) : s->apply_kernel;
+            if (apply_kernel == 2) {  // the rank-NP update on the FP64 matrix cores (k_apply_mfma)
+                const dim3 g2((unsigned)((s->nrows + APM_ROWS - 1) / APM_ROWS), (unsigned)((s->n + APM_COLS - 1) / APM_COLS));
+#define APM_GO(NPV, NTV)                                                                                              \
+    hipLaunchKernelGGL((k_apply_mfma<NPV, NTV>), g2, dim3(256), 0, s->stream, s->d_Q, s->ld, s->n, s->nrows, s->row0, \
+                       (const double*)s->d_pend, (const double*)s->d_cpend, (const DevState*)s->d_st)
+                if (s->defer == 24) { if (nt) APM_GO(24, true); else APM_GO(24, false); }
+                else if (s->defer == 16) { if (nt) APM_GO(16, true); else APM_GO(16, false); }
+                else { if (nt) APM_GO(8, true); else APM_GO(8, false); }
+#undef APM_GO
+            } else if (s->defer == 24) {  // 24 / 16 pending updates: the 16-row-tile kernel (coefficients in LDS)
                 if (nt) APL_GO(24, true); else APL_GO(24, false);
             } else if (s->defer == 16) {
                 if (nt) APL_GO(16, true); else APL_GO(16, false);
-            } else if (s->apply_kernel == 1) {  // depth 8, same kernel (0.40 ms; ELLHIP_APPLY_KERNEL=0: k_sweep_apply, 0.44)
+            } else if (apply_kernel == 1) {  // depth 8, same kernel (0.40 ms; ELLHIP_APPLY_KERNEL=0: k_sweep_apply, 0.44)
                 if (nt) APL_GO(8, true); else APL_GO(8, false);
             } else {
                 rc = nt ? launch_apply_t<2, true, false, true>(s, nullptr, nullptr)
@@ -1032,15 +1044,15 @@ int create_impl(ellhip_space** out, int variant, long long n, long long row0, lo
     if (hipStreamSynchronize(s->stream) != hipSuccess) return bail(fail(ELLHIP_E_HIP, "sync after upload"));
     rc = write_state(s);
     if (rc) return bail(rc);
-    // Default schedule of a new unsharded Ell handle: depth 16 wherever the lower-triangle schedule exists (even
-    // n >= 8192: 4.5 n^2 instead of 24 n^2 bytes per update, results within the parity tolerance of depth 1, Q made
-    // current for every observer), otherwise the reference's data flow (depth 1).  ELLHIP_AUTO_DEFER=0 keeps depth 1
-    // everywhere; ellhip_set_defer_depth overrides either way.  Row shards stay at 1 until their owner chooses.
+    // Default schedule of a new unsharded Ell handle: depth 24 wherever the lower-triangle schedule exists (even
+    // n >= 8192: 4.33 n^2 instead of 24 n^2 bytes per update, the recorded updates applied as one rank-24 update on the
+    // matrix cores; results within the parity tolerance of depth 1, Q made current for every observer), otherwise the
+    // reference's data flow (depth 1).  ELLHIP_OPT_AUTO_DEFER = 0 keeps depth 1 everywhere; ellhip_set_defer_depth overrides either way.  Row shards stay at 1 until their owner chooses.
     // Between 3072 and that size (and for odd n) depth 8 with full-row GEMVs is the faster one, for synchronous calls
     // and for queues alike (tools/depth_sweep.py: n = 4096: 15 800 vs 10 400 calls/s; below ~3000 depth 1 wins).
     if (variant == ELLHIP_SPACE_ELL && !sharded && g_defaults.auto_defer) {
         const bool lower = s->symv && s->apply_lower && (n % 2) == 0 && n >= s->symv_min_n;
-        const int depth = lower ? 16 : (n >= 3072 ? 8 : 1);
+        const int depth = lower ? 24 : (n >= 3072 ? 8 : 1);
         if (depth != 1) {
             rc = ellhip_set_defer_depth(s, depth);
             if (rc) return bail(rc);
@@ -1590,7 +1602,9 @@ int ellhip_set_shard_symmetric(ellhip_space* s, int flag) {
 namespace {
 int option_ok(int key, long long v) {
     switch (key) {
-        case ELLHIP_OPT_AUTO_DEFER: case ELLHIP_OPT_SYMV: case ELLHIP_OPT_APPLY_LOWER: case ELLHIP_OPT_APPLY_KERNEL:
+        case ELLHIP_OPT_APPLY_KERNEL:
+            return (v >= -1 && v <= 2) ? 0 : fail(ELLHIP_E_INVALID, "option value must be -1, 0, 1 or 2");
+        case ELLHIP_OPT_AUTO_DEFER: case ELLHIP_OPT_SYMV: case ELLHIP_OPT_APPLY_LOWER:
         case ELLHIP_OPT_FUSE_DOTS: case ELLHIP_OPT_RESIDENT:
             return (v == 0 || v == 1) ? 0 : fail(ELLHIP_E_INVALID, "option value must be 0 or 1");
         case ELLHIP_OPT_SYMV_MIN_N: return v >= 512 ? 0 : fail(ELLHIP_E_INVALID, "ELLHIP_OPT_SYMV_MIN_N must be >= 512");

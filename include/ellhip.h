@@ -155,7 +155,7 @@ int ellhip_commit(ellhip_space *s, const double *next_grad);
 
 /* ---- deferred shrink: 8 n^2 (1 + 1/8) bytes per update (Ell) -----------------------------------
  * depth = 1: Q is rewritten at every successful cut, exactly as src/ell.rs:117-128 does.  This is what a new handle
- * starts with, EXCEPT an unsharded Ell handle with n >= 3072: it starts at depth 16 when n is even and >= 8192 and
+ * starts with, EXCEPT an unsharded Ell handle with n >= 3072: it starts at depth 24 when n is even and >= 8192 and
  * at depth 8 otherwise (the fastest schedules at those sizes; same results to the parity tolerance).
  * ellhip_set_default_option(ELLHIP_OPT_AUTO_DEFER, 0) makes every later handle start at depth 1;
  * ellhip_set_defer_depth(h, 1) does it for one handle.
@@ -174,9 +174,13 @@ int ellhip_commit(ellhip_space *s, const double *next_grad);
  * before anything observes Q).  An equal-block row shard keeps the full-row passes, so its bits differ from an
  * unsharded handle's at depth 8 (both stay within the parity tolerance; shards agree with each other bit for
  * bit); a symmetric row shard (below) runs the lower-triangle schedule on its trapezoid.
- * depth = 16: the same with 16 recorded updates per apply pass (4.5 n^2 bytes per update); lower-triangle schedule
- * only (ELLHIP_E_INVALID otherwise).  The fastest schedule on MI355X where it exists (4300 vs 3960 updates/s at
- * n = 16384) and bench.py's default there. */
+ * depth = 16 / 24: the same with 16 / 24 recorded updates per apply pass ((4 + 8 / depth) n^2 bytes per update);
+ * lower-triangle schedule only (ELLHIP_E_INVALID otherwise).  Depth 24 is the fastest schedule on MI355X where it
+ * exists and what a new handle starts with there: its apply pass is ONE rank-24 update on the FP64 matrix cores
+ * (k_apply_mfma, 0.43 ms at n = 16384 whatever the depth; the vector kernel k_apply_lower needs 0.40 ms for 16 updates
+ * and 0.62 ms for 24).  On the matrix cores an element receives its updates as a chain of fused multiply-adds (one
+ * rounding per update where the reference has two): inside the 1e-10 contract, not the reference's rounding sequence;
+ * ELLHIP_OPT_APPLY_KERNEL = 1 selects the vector kernel and that sequence at any depth. */
 int ellhip_set_defer_depth(ellhip_space *s, int depth);
 int ellhip_defer_depth(const ellhip_space *s);
 /* Apply whatever the deferred schedule has recorded so far (and a shrink a pipelined cut left pending) now,
@@ -211,7 +215,10 @@ int ellhip_set_shard_symmetric(ellhip_space *s, int flag);
  *   ELLHIP_OPT_SYMV              0 / 1      1        Ell: lower-triangle GEMV on the recorded schedule (4 n^2 bytes)
  *   ELLHIP_OPT_SYMV_MIN_N        >= 512     8192     Ell: smallest n of an unsharded handle that takes it
  *   ELLHIP_OPT_APPLY_LOWER       0 / 1      1        Ell: apply passes touch the lower triangle only (8 n^2 bytes)
- *   ELLHIP_OPT_APPLY_KERNEL      0 / 1      1        Ell, depth 8: 1 = k_apply_lower (16-row tiles), 0 = k_sweep_apply
+ *   ELLHIP_OPT_APPLY_KERNEL      -1 .. 2    -1       Ell, lower-triangle apply pass (-1 = 2 at depth 24, else 1): 2 = k_apply_mfma (the recorded updates as ONE rank-NP
+ *                                                    update on the FP64 matrix cores: one rounding per update and element where the
+ *                                                    reference has two -- inside the 1e-10 contract, not bit-identical to 0 / 1),
+ *                                                    1 = k_apply_lower (16-row tiles, the reference's roundings), 0 = k_sweep_apply (depth 8)
  *   ELLHIP_OPT_FUSE_DOTS         0 / 1      1        Ell: the scalar stage's dot products come out of the GEMV's launch
  *   ELLHIP_OPT_RESIDENT          0 / 1      1        Ell: ellhip_queue_run / _run_fused of >= 4 cuts park the lower triangle in the
  *                                                    chip's register files and run the whole batch in ONE persistent launch

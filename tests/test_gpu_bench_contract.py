@@ -50,7 +50,7 @@ def test_headline_workload_contract():
     assert c["all_cores"]["threads"] >= 1 and "NOT the reference" in c["all_cores"]["note"]
     assert d["host_call_path"]["updates_per_s"] > 0
     assert r["traffic_measured_in_this_run"] is False and r["per_kernel"]["symv"]["avg_ms"] > 0
-    # 16 timed steps at depth 16 hold ONE apply pass: (16 * 4 n^2 + 1 * 8 n^2) / 16 = 4.5 n^2 per update
+    # 16 timed steps at depth 24 hold ONE apply pass (the flush at the end): (16 * 4 n^2 + 1 * 8 n^2) / 16 = 4.5 n^2 per update
     assert abs(r["whole_update"]["alg_bytes_per_gpu"] - 4.5 * 16384 ** 2) < 1.0
     # the default invocation carries BASELINE.json's other configurations in the same line
     oc = {o["workload"]: o for o in d["other_configs"]}
@@ -59,9 +59,9 @@ def test_headline_workload_contract():
         assert o["updates_per_s"] > 0 and abs(o["updates_per_s"] - 1e3 / o["ms_per_step"]) < 1e-6 * o["updates_per_s"]
         ro = o["roofline"]
         assert 0.0 < ro["frac"] < 1.0 and ro["kernel"] and 0.0 < ro["whole_update"]["frac"] < 1.0
-    assert oc["n32768-deep"]["defer_depth"] == 16 and oc["n4096-deep"]["defer_depth"] == 8
-    # 64 steps at depth 16: four apply passes, (64 * 4 + 4 * 8) / 64 = 4.5
-    assert abs(oc["n32768-deep"]["roofline"]["whole_update"]["alg_bytes"] - 4.5 * 32768 ** 2) < 1.0
+    assert oc["n32768-deep"]["defer_depth"] == 24 and oc["n4096-deep"]["defer_depth"] == 8
+    # 64 steps at depth 24: three apply passes, (64 * 4 + 3 * 8) / 64 = 4.375
+    assert abs(oc["n32768-deep"]["roofline"]["whole_update"]["alg_bytes"] - 4.375 * 32768 ** 2) < 1.0
 
 
 @pytest.mark.parametrize("workload,args", [("n4096-deep", ("--steps", "40", "--warmup", "8", "--compare-steps", "0")),

@@ -39,7 +39,7 @@ def _drive(gpu, orc, n, cuts, make_cut, seed):
     e1.defer_depth = 1
     ed = gpu.Ell.new_with_scalar(1.0, np.zeros(n))
     depth = ed.defer_depth
-    assert depth in (8, 16), depth          # what a new handle of this size starts with
+    assert depth in (8, 24), depth          # what a new handle of this size starts with
     worst = {"tsq1": 0.0, "tsqd": 0.0}
     state = {}
     for k in range(cuts):

@@ -267,7 +267,7 @@ def test_default_depth_of_new_handles(gpu, monkeypatch):
     assert gpu.Ell.new_with_scalar(1.0, np.zeros(4096)).defer_depth == 8      # 3072 <= n < 8192: full-row GEMVs, depth 8
     assert gpu.Ell.new_with_scalar(1.0, np.zeros(8191)).defer_depth == 8      # odd n: no 16-byte pairs, no lower schedule
     e = gpu.Ell.new_with_scalar(1.0, np.zeros(8192))
-    assert e.defer_depth == 16 and e.clone().defer_depth == 16
+    assert e.defer_depth == 24 and e.clone().defer_depth == 24
     e.defer_depth = 1
     assert e.defer_depth == 1 and e.clone().defer_depth == 1
     set_default("AUTO_DEFER", 0)
@@ -284,7 +284,7 @@ def test_default_depth_of_new_handles(gpu, monkeypatch):
     a = gpu.Ell.new_with_matrix(1.0, mq, np.zeros(n))
     b = gpu.Ell.new_with_matrix(1.0, mq, np.zeros(n))
     b.defer_depth = 1
-    assert a.defer_depth == 16
+    assert a.defer_depth == 24
     for i in range(3):
         assert int(a.update_bias_cut((grads[i], float(b0[i])))) == int(b.update_bias_cut((grads[i], float(b0[i])))) == 0
     qa, qb = a.mq, b.mq
@@ -504,3 +504,26 @@ def test_dot_products_from_the_symv_reduction_agree_with_the_separate_launch(gpu
         assert np.array_equal(s.mq, qd)
     assert np.max(np.abs(ref.xc() - direct.xc())) <= 1e-12 * np.max(np.abs(ref.xc()))
     assert np.max(np.abs(ref.mq - qd)) <= 1e-12 * np.max(np.abs(qd))
+
+
+@pytest.mark.parametrize("n,depth", [(512, 8), (1000, 16), (2112, 24), (4096 + 64, 24), (8192, 16)])
+def test_matrix_core_apply_pass_matches_the_oracle(gpu, orc, n, depth):
+    """ELLHIP_OPT_APPLY_KERNEL = 2: the recorded updates applied as one rank-NP update on the FP64 matrix cores
+    (k_apply_mfma).  One rounding per update and element instead of the reference's two, so it is compared with the
+    oracle (1e-10) and with k_apply_lower (to rounding), not bit for bit; ragged last strips and column blocks included."""
+    set_default("SYMV_MIN_N", 512)
+    set_default("RESIDENT", 0)
+    xc0 = np.linspace(-1.0, 1.0, n)
+    outs = []
+    for kern in (2, 1):
+        g = gpu.Ell.new_with_scalar(2.0, xc0)
+        g.defer_depth = depth
+        g.set_option(gpu.capi.OPT_APPLY_KERNEL, kern)
+        o = orc.OracleEll.new_with_scalar(2.0, xc0)
+        nsucc = run_mixed(g, o, 3 * depth + 5, seed=4100 + n + depth, check_every=depth + 3)
+        assert nsucc >= depth + 4
+        assert_state_close(g, o, what=f"apply kernel {kern} depth {depth} n={n}")
+        outs.append((g.mq, g.xc(), g.kappa))
+    assert np.max(np.abs(outs[0][0] - outs[1][0])) <= 1e-12 * np.max(np.abs(outs[1][0]))
+    assert np.array_equal(outs[0][0], outs[0][0].T)
+    assert np.max(np.abs(outs[0][1] - outs[1][1])) <= 1e-12 * np.max(np.abs(outs[1][1]))

@@ -128,18 +128,18 @@ def _close_in_blocks(qg, qo, tol, what):
 
 
 def test_ell_default_schedule_matches_oracle_at_full_size(gpu, orc):
-    """The timed configuration itself (n = 16384, parallel cuts, depth 16, lower-triangle GEMV + lower-trapezoid
-    apply, pipelined queue) against the CPU oracle on the same 18 cuts -- one apply pass at cut 16, two cuts
-    still recorded when the state is read.  Whole state to the north-star tolerance.
+    """The timed configuration itself (n = 16384, parallel cuts, depth 24 = lower-triangle GEMV + the recorded
+    updates applied as one rank-24 update on the matrix cores, pipelined queue) against the CPU oracle on the same 28
+    cuts -- one apply pass at cut 24, four cuts still recorded when the state is read.  Whole state to the north-star tolerance.
     (The checker is the oracle's row-parallel loop `update_rowwise_mt`, used here for speed only: the reference's loop
     order takes seconds per update at this size; tests/test_oracle_pins.py ties it bit for bit to the reference loop
     at n = 37, 257 and 2048.)"""
     from ellalgo_rs_amd import synth
     from util import TOL
-    k = 18
+    k = 28
     kinds, grads, b0, b1 = synth.parallel_cuts(N, k)
     e = gpu.Ell.new_with_scalar(1.0, np.zeros(N))
-    assert e.defer_depth == 16          # what a new handle of this size starts with
+    assert e.defer_depth == 24          # what a new handle of this size starts with
     e.queue_upload(kinds, grads, b0, b1)
     e.queue_run(0, k, fused=True)
     st, ts = e.queue_results()

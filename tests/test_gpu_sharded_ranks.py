@@ -15,6 +15,7 @@ CASES = [
     # (n, P, partition, depth)
     (192, 2, EQUAL, 1), (192, 3, EQUAL, 8), (2048, 2, EQUAL, 1), (2048, 2, EQUAL, 8), (3072, 3, EQUAL, 8), (4096, 2, EQUAL, 8),
     (512, 2, SYMMETRIC, 8), (2048, 2, SYMMETRIC, 8), (2048, 3, SYMMETRIC, 16), (4096, 2, SYMMETRIC, 16), (4096, 3, SYMMETRIC, 8),
+    (2048, 2, SYMMETRIC, 24), (4096, 3, SYMMETRIC, 24),
 ]
 
 
