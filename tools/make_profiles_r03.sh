@@ -24,4 +24,5 @@ echo "n4096 done"
 cd $R
 python tools/pmc_summary.py $O/default_stats $O/n16384_fetch $O/n16384_write $O/summary_n16384 bench_n16384 n16384-parallel || true
 python tools/pmc_summary.py $O/n4096_stats $O/n4096_fetch $O/n4096_write $O/summary_n4096 bench_n4096 n4096-deep || true
+python tools/trace_by_grid.py $O/default_stats $O/bench_default_kernel_stats_by_grid.csv || true
 python tools/show_bench.py $O/bench_default.json | cut -c1-300
