@@ -412,7 +412,21 @@ def cpu_baseline(n: int, variant: str, kinds, grads, b0, b1, budget_s: float = 2
     }
 
 
-def ell_bytes_per_update(n2w: float, sched: str, dep: int, steps: int, symv_mode: bool, lower_apply: bool, sharded: bool = False):
+def gemv_passes(steps: int, dep: int, lookahead: int) -> int:
+    """Passes over Q_base a pipelined queue run of `steps` cuts makes at depth `dep` when up to `lookahead` consecutive
+    queued cuts share one pass (ELLHIP_OPT_LOOKAHEAD; csrc/ellhip_capi.hip queue_run_multi: a group ends at the apply pass
+    and at the end of the run)."""
+    i = npend = passes = 0
+    while i < steps:
+        g = min(lookahead, steps - i, dep - npend)
+        passes += 1
+        i += g
+        npend = (npend + g) % dep
+    return passes
+
+
+def ell_bytes_per_update(n2w: float, sched: str, dep: int, steps: int, symv_mode: bool, lower_apply: bool, sharded: bool = False,
+                         lookahead: int = 1):
     """Algorithmic bytes ONE update moves per GPU-share under a schedule / depth IN A TIMED REGION OF `steps` UPDATES
     that starts and ends with nothing recorded (bench.py flushes on both sides), and the model's description.  A
     deferred schedule runs ceil(steps / depth) apply passes inside such a region -- 20 steps at depth 16 hold two -- so
@@ -422,6 +436,15 @@ def ell_bytes_per_update(n2w: float, sched: str, dep: int, steps: int, symv_mode
             return 16.0 * n2w, "16*n^2 B/update (rank-1 pass of cut k fused with the GEMV of cut k+1)"
         return 24.0 * n2w, "24*n^2 B/update (GEMV pass 8 + rank-1 pass 16; SURVEY 8d)"
     passes = -(-steps // dep)
+    if symv_mode and lower_apply and sched == "pipelined" and lookahead > 1 and not sharded:
+        gp = gemv_passes(steps, dep, lookahead)
+        per = (4.0 * gp + 8.0 * passes) / steps
+        return per * n2w, (f"{per:.4g}*n^2 B/update = ({gp} passes over the lower triangle of 4*n^2, each forming the products of up to "
+                           f"{lookahead} QUEUED cuts at once + {passes} lower-triangle apply passes of 8*n^2) / {steps} updates "
+                           f"(deferred shrink, depth {dep}, lookahead {lookahead}: only a queue knows the next gradients -- a live "
+                           f"cutting-plane loop runs lookahead 1, see host_call_path; steady state "
+                           f"{(4.0 * -(-dep // lookahead) + 8.0) / dep:.4g}*n^2; the partial sums the passes hand to the "
+                           "reductions, 2.2 n^2 / 64 per vector written and read, are not counted)")
     if symv_mode and lower_apply:
         per = 4.0 + 8.0 * passes / steps
         return per * n2w, (f"{per:g}*n^2 B/update = ({steps} lower-triangle GEMV passes of 4*n^2 + {passes} lower-triangle apply "
@@ -445,6 +468,13 @@ def ell_bytes_per_update(n2w: float, sched: str, dep: int, steps: int, symv_mode
 # the BASELINE.json configurations besides the headline one, with the brief (steps, warmup, profile steps) they are run
 # at inside the default invocation so that the driver's one line carries all of them
 BRIEF_CONFIGS = [("n4096-deep", 200, 20, 40), ("n32768-deep", 64, 16, 16), ("n16384-ellstable", 48, 8, 16)]
+
+
+def symv_kernel_name(pkg, space, symv_mode: bool, n: int, fused: bool = True) -> str:
+    look = space.get_option(pkg.capi.OPT_LOOKAHEAD) if (symv_mode and fused and hasattr(space, "get_option")) else 1
+    if look > 3 and n % 64 == 0:
+        return "k_symm_mfma"
+    return "k_symv_multi" if look > 1 else "k_symv"
 
 
 def brief_config(pkg, synth, torch, workload: str, K: int, W: int, P: int, device: int) -> dict:
@@ -490,6 +520,7 @@ def brief_config(pkg, synth, torch, workload: str, K: int, W: int, P: int, devic
     alg = {"gemv": 8.0 * n2, "rank1": 16.0 * n2, "fused": 16.0 * n2, "apply": (8.0 if lower_apply else 16.0) * n2,
            "apply_gemv": 16.0 * n2, "symv": 4.0 * n2, "stable_fwd": 8.0 * n2, "stable_bwd": 4.0 * n2, "stable_factor": 12.0 * n2}
     resident = variant == "ell" and prof.get("resident", (0.0, 0))[1] > 0
+    look = space.get_option(pkg.capi.OPT_LOOKAHEAD) if (variant == "ell" and symv_mode) else 1
     if variant != "ell":
         fb = 8.0 if space.get_option(pkg.capi.OPT_STABLE_FACTOR) != 0 else 12.0
         alg["stable_factor"] = fb * n2
@@ -505,7 +536,7 @@ def brief_config(pkg, synth, torch, workload: str, K: int, W: int, P: int, devic
                  "the register files for the whole batch (k_ell_resident): NOT HBM-bound, the update is two on-chip hand-offs "
                  "(one grid barrier) long")
     else:
-        bytes_update, model = ell_bytes_per_update(n2, "pipelined", depth, K, symv_mode, lower_apply)
+        bytes_update, model = ell_bytes_per_update(n2, "pipelined", depth, K, symv_mode, lower_apply, False, look)
     per_kernel = {}
     for name, (ms, cnt) in prof.items():
         if cnt:
@@ -521,7 +552,8 @@ def brief_config(pkg, synth, torch, workload: str, K: int, W: int, P: int, devic
     upd_gbps = bytes_update / (ms_per_step * 1e-3) / 1e9
     roofline = {"whole_update": {"alg_bytes": bytes_update, "GBps": upd_gbps, "frac": upd_gbps / HBM_PEAK_GBS, "byte_model": model}}
     if dom:
-        kname = {"symv": "k_symv", "apply": "k_apply_lower", "gemv": "k_sweep_gemv_dots", "resident": "k_ell_resident"}.get(dom, dom)
+        kname = {"symv": symv_kernel_name(pkg, space, symv_mode, n), "apply": "k_apply_mfma", "gemv": "k_sweep_gemv_dots",
+                 "resident": "k_ell_resident"}.get(dom, dom)
         roofline.update({"kernel": kname if variant == "ell" else "k_st_" + dom[7:], "achieved": per_kernel[dom]["GBps"],
                          "frac": per_kernel[dom]["GBps"] / HBM_PEAK_GBS, "avg_launch_ms": per_kernel[dom]["avg_ms"],
                          "alg_bytes_per_launch": per_kernel[dom]["alg_bytes"]})
@@ -532,6 +564,7 @@ def brief_config(pkg, synth, torch, workload: str, K: int, W: int, P: int, devic
     del space
     return {"workload": workload, "description": desc, "updates_per_s": K / elapsed, "ms_per_step": ms_per_step, "steps": K,
             "warmup": W, "defer_depth": depth,
+            **({"lookahead": look} if (variant == "ell" and not resident and look > 1) else {}),
             "schedule": ("resident (one launch per batch)" if resident else "pipelined") if variant == "ell" else "ellstable",
             "roofline": roofline}
 
@@ -866,8 +899,12 @@ def main() -> None:
         if prof and prof.get("stable_factor", (0.0, 0))[1] == 0:
             alg["stable_bwd"] = 4.0 * n * n + alg["stable_factor"]
 
+    lookahead = 1
+    if variant == "ell" and symv_mode and not sharded:
+        lookahead = space.get_option(pkg.capi.OPT_LOOKAHEAD)
+
     def byte_model(sched, dep, steps):
-        return ell_bytes_per_update(n2w, sched, dep, steps, symv_mode, lower_apply, sharded)
+        return ell_bytes_per_update(n2w, sched, dep, steps, symv_mode, lower_apply, sharded, lookahead)
 
     def kernel_table(pr):
         tab = {}
@@ -904,7 +941,9 @@ def main() -> None:
         cands = [k for k in per_kernel if k in alg]
         dom = max(cands, key=lambda k: per_kernel[k]["avg_ms"]) if cands else None
     if dom in per_kernel:
-        kname = {"symv": "k_symv", "apply": "k_sweep_apply", "apply_gemv": "k_sweep_apply", "resident": "k_ell_resident"}.get(dom, "k_sweep:" + dom)
+        kname = {"symv": ("k_symm_mfma" if lookahead > 3 and n % 64 == 0 else "k_symv_multi") if (lookahead > 1 and fused) else "k_symv",
+                 "apply": "k_apply_mfma" if depth == 24 else "k_apply_lower", "apply_gemv": "k_sweep_apply",
+                 "resident": "k_ell_resident"}.get(dom, "k_sweep:" + dom)
         roofline.update({"kernel": kname if variant == "ell" else "k_st_" + dom[7:],
                          "achieved": per_kernel[dom]["GBps"], "frac": per_kernel[dom]["GBps"] / HBM_PEAK_GBS,
                          "alg_bytes_per_launch": per_kernel[dom]["alg_bytes"],
@@ -950,6 +989,10 @@ def main() -> None:
                    "schedule": (("resident (one launch per batch)" if resident_run else ("pipelined" if fused else "two-pass"))
                                 if variant == "ell" else "ellstable"),
                    "defer_depth": depth,
+                   **({"lookahead": lookahead,
+                       "lookahead_note": "products of up to `lookahead` consecutive QUEUED cuts per pass over Q (ELLHIP_OPT_LOOKAHEAD); "
+                                         "a live cutting-plane loop cannot look ahead: see host_call_path and other_schedules"}
+                      if (variant == "ell" and fused and lookahead > 1 and not resident_run) else {}),
                    "description": desc,
                    "partition": (f"symmetric row shards x{world} (boundaries at n*sqrt(r/P), all-reduce)" if shard_sym
                                  else f"row-block x{world} (all-gather)") if sharded

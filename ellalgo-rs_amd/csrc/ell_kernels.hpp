@@ -427,6 +427,118 @@ __global__ __launch_bounds__(256) void k_symv(const double* __restrict__ Q, long
                                        (long long)blockIdx.y, red);
 }
 
+// ------------------------------------------------------------------------------ k_symv_multi ---
+// The lower-triangle GEMV for LV queued gradients in ONE pass over Q_base: Y = Q_base [g_0 ... g_{LV-1}].  On the
+// recorded schedule the products of the next cuts all refer to the same Q_base (the cuts in between are recorded, not
+// applied; the scalar stage corrects each y with them), and the queue holds the gradients already, so a group of LV
+// cuts costs one read of the lower triangle instead of LV: (4 / LV) n^2 bytes per update.  Per vector the arithmetic
+// is k_symv's, operation for operation (same tile, same thread-to-element map, same order of every sum), and vector l
+// writes its own set of partial sums (rowpart + l * rowpart_stride, colpart + l * colpart_stride) for k_symv_reduce:
+// every y_l is bit-identical to what k_symv yields for g_l alone.  The vector ALU and the registers (LV column sums and
+// LV gradient pairs per column pair stay live over the tile) carry this to LV = 3 (0.25 ms per pass at n = 16384,
+// against 0.19 for one vector; LV = 4: 0.39); larger groups go to the matrix cores (k_symm_mfma).  Tried and dropped
+// (tools/experiments/symv_multi.hip, profiles/r03/symv_multi_*): next row group's loads issued ahead from a second
+// register buffer, and all RW * LV row sums of a row group through one halving butterfly (bit-identical, 10 shuffles
+// instead of 48) -- the extra live registers cost more than they bought.
+template <int RW, bool NT, int SEG, int LV>
+__global__ __launch_bounds__(256) void k_symv_multi(const double* __restrict__ Q, long long ld, long long n,
+                                                    long long row0, long long nrows, const double* __restrict__ g,
+                                                    long long g_stride, double* __restrict__ rowpart,
+                                                    double* __restrict__ colpart, long long rowpart_stride,
+                                                    long long colpart_stride, const DevState* __restrict__ st) {
+    __shared__ double red[LV][4][SYMV_H];
+    if (st->halted) return;
+    constexpr int SYMV_NCH = SEG / 512;
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const long long I = (long long)gridDim.x - 1 - blockIdx.x, J = (long long)blockIdx.y;
+    const long long r0 = row0 + I * SYMV_H;
+    const long long c0 = J * SEG;
+    const long long rend = row0 + nrows;
+    if (r0 >= rend || c0 > r0 + SYMV_H - 1) return;
+    const long long rlast = (r0 + SYMV_H - 1 < rend - 1) ? r0 + SYMV_H - 1 : rend - 1;
+    Q -= row0 * ld;
+    const bool full = c0 + SEG - 1 < r0;
+
+    long long ck[SYMV_NCH];
+    double2_t gc[LV][SYMV_NCH], accc[LV][SYMV_NCH];
+#pragma unroll
+    for (int k = 0; k < SYMV_NCH; ++k) {
+        ck[k] = c0 + 512 * k + 2 * (long long)threadIdx.x;
+        const bool in = ck[k] <= rlast;
+#pragma unroll
+        for (int l = 0; l < LV; ++l) {
+            gc[l][k] = in ? *reinterpret_cast<const double2_t*>(g + l * g_stride + ck[k]) : double2_t{0.0, 0.0};
+            accc[l][k] = double2_t{0.0, 0.0};
+        }
+    }
+    for (int rg = 0; rg < SYMV_H / RW; ++rg) {
+        double accr[LV][RW];
+        double gr[LV][RW];
+        long long rr[RW];
+        double2_t q[RW][SYMV_NCH];
+#pragma unroll
+        for (int r = 0; r < RW; ++r) {
+            rr[r] = r0 + rg * RW + r;
+            const bool rv = rr[r] < rend;
+#pragma unroll
+            for (int l = 0; l < LV; ++l) {
+                gr[l][r] = rv ? g[l * g_stride + rr[r]] : 0.0;
+                accr[l][r] = 0.0;
+            }
+            const double* row = Q + (rv ? rr[r] : rend - 1) * ld;
+#pragma unroll
+            for (int k = 0; k < SYMV_NCH; ++k) {
+                if (rv && (full || ck[k] <= rr[r])) q[r][k] = ld_stream<NT, double2_t>(row + ck[k]);
+                else q[r][k] = double2_t{0.0, 0.0};
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < RW; ++r) {
+#pragma unroll
+            for (int k = 0; k < SYMV_NCH; ++k) {
+                double qx = q[r][k].x, qy = q[r][k].y;
+                if (!full) {
+                    if (ck[k] + 1 > rr[r]) qy = 0.0;
+                }
+                const double cx = (full || ck[k] < rr[r]) ? qx : 0.0;
+                const double cy = (full || ck[k] + 1 < rr[r]) ? qy : 0.0;
+#pragma unroll
+                for (int l = 0; l < LV; ++l) {
+                    accr[l][r] += qx * gc[l][k].x;
+                    accr[l][r] += qy * gc[l][k].y;
+                    accc[l][k].x += cx * gr[l][r];
+                    accc[l][k].y += cy * gr[l][r];
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < RW; ++r) {
+#pragma unroll
+            for (int l = 0; l < LV; ++l) {
+                const double sum = wave_allreduce_sum(accr[l][r]);
+                if (lane == 0) red[l][wave][rg * RW + r] = sum;
+            }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < SYMV_H && r0 + threadIdx.x < rend) {
+        const int r = threadIdx.x;
+#pragma unroll
+        for (int l = 0; l < LV; ++l) {
+            const double v = ((red[l][0][r] + red[l][1][r]) + red[l][2][r]) + red[l][3][r];
+            rowpart[l * rowpart_stride + J * n + r0 + r] = v;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < SYMV_NCH; ++k)
+        if (ck[k] <= rlast) {
+#pragma unroll
+            for (int l = 0; l < LV; ++l)
+                *reinterpret_cast<double2_t*>(colpart + l * colpart_stride + I * n + ck[k]) = accc[l][k];
+        }
+}
+
 // y[i] = sum_{J <= i/SEG} rowpart[J][i] + sum_{I >= i/H} colpart[I][i]   (fixed order)
 // One workgroup per 128 columns: lane = column pair (16-byte loads, 1 KiB per wave-instruction), wave w
 // takes the strips I0 + w, I0 + w + 4, ...; the four wave sums are combined as ((w0+w1)+w2)+w3.
@@ -885,6 +997,119 @@ __global__ __launch_bounds__(256) void k_apply_mfma(double* __restrict__ Q, long
         if (more) park(buf ^ 1, vn);
         __syncthreads();  // everybody is done with sh_v[buf]; sh_v[buf ^ 1] is complete
         buf ^= 1;
+    }
+}
+
+// ------------------------------------------------------------------------------- k_symm_mfma ---
+// The lower-triangle product for up to 16 queued gradients at once on the FP64 matrix cores: Y = Q_base G, G = n x 16
+// (k_pack_grads lays the group's gradients out as gT[c][v], zero-padded to 16 columns).  k_symv_multi runs out of
+// vector ALU and registers near four gradients (every element costs 4 LV operations and LV live column sums); the
+// matrix pipe does a 16 x 16 x 4 block product in 16 cycles, so sixteen gradients ride on the time one pass over the
+// triangle takes from HBM anyway: (4 / 16) n^2 bytes per update.
+// Tile = 64 rows x SYMV_SEG columns (k_symv's grid); wave w takes the 16-column blocks w, w + 4, ... over all 64 rows.
+// Per block the wave loads 16 registers N[j] = Q[r0 + 4 j + (lane >> 4)][cb + (lane & 15)] (4 rows x 128 contiguous
+// bytes per instruction), which IS the B operand of the column product (contraction over rows):
+//     Dc[v][c] += sum_r gT[r][v] Q[r][c]            A = gT rows (lane & 15 = v, lane >> 4 = r), 16 MFMAs
+// and, transposed through the wave's private LDS patch (pitch 17: the reads of 16 rows at one column hit 16 banks),
+// the B operand of the row product (contraction over columns):
+//     Dr[j'][v][r] += sum_c gT[c][v] Q[r][c]        A = gT columns, 16 MFMAs
+// Dc leaves as colpart_v[I][c] per block, Dr is added over the four waves as ((w0 + w1) + w2) + w3 and leaves as
+// rowpart_v[J][r]: the partial sums k_symv_reduce expects.  Numerics: the MFMA sums four products per instruction in
+// its own association and fuses the multiply-add; y differs from k_symv's by a few ulp (inside the 1e-10 contract, not
+// bit-identical to the vector-ALU kernels).  Requires n % 64 == 0, unsharded.
+constexpr int SMM_NV = 16;
+constexpr int SMM_PITCH = 17;
+
+__global__ __launch_bounds__(256) void k_pack_grads(const double* __restrict__ g, long long g_stride, int lv, long long n,
+                                                    double* __restrict__ gT) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;  // element of gT: c = i / 16, v = i % 16
+    if (i >= n * SMM_NV) return;
+    const long long c = i / SMM_NV;
+    const int v = (int)(i % SMM_NV);
+    gT[i] = v < lv ? g[(long long)v * g_stride + c] : 0.0;
+}
+
+template <bool NT, int SEG>
+__global__ __launch_bounds__(256) void k_symm_mfma(const double* __restrict__ Q, long long ld, long long n,
+                                                   const double* __restrict__ gT, int lv, double* __restrict__ rowpart,
+                                                   double* __restrict__ colpart, long long rowpart_stride,
+                                                   long long colpart_stride, const DevState* __restrict__ st) {
+    __shared__ double sh[4][SYMV_H * SMM_PITCH];
+    if (st->halted) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lr = lane >> 4, lc = lane & 15;
+    const long long I = (long long)gridDim.x - 1 - blockIdx.x, J = (long long)blockIdx.y;
+    const long long r0 = I * SYMV_H;
+    const long long c0 = J * SEG;
+    if (r0 >= n || c0 > r0 + SYMV_H - 1) return;
+    const bool full = c0 + SEG - 1 < r0;
+    // A operand of the column product: gT rows of the strip
+    double gr[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) gr[j] = gT[(r0 + 4 * j + lr) * SMM_NV + lc];
+    double4_t dr[4];
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) dr[jj] = double4_t{0.0, 0.0, 0.0, 0.0};
+    // blocks at or left of the strip's diagonal
+    const long long cend = (c0 + SEG < r0 + SYMV_H) ? c0 + SEG : r0 + SYMV_H;  // first column past the tile's part
+    const int nblk = (int)((cend - c0) / 16);
+    double* mysh = sh[wave];
+    const double* qbase = Q + (r0 + lr) * ld + lc;
+    for (int b = wave; b < nblk; b += 4) {
+        const long long cb = c0 + 16 * (long long)b;
+        double x[16], gc[4];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) x[j] = ld_stream<NT, double>(qbase + (long long)(4 * j) * ld + cb);
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) gc[kb] = gT[(cb + 4 * kb + lr) * SMM_NV + lc];
+        const bool diag = !full && cb + 15 >= r0;  // some element of the block is on or right of the diagonal
+        double4_t dc = {0.0, 0.0, 0.0, 0.0};
+        if (diag) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const long long r = r0 + 4 * j + lr, c = cb + lc;
+                const double below = (c < r) ? x[j] : 0.0;   // column sums: strictly below the diagonal
+                dc = __builtin_amdgcn_mfma_f64_16x16x4f64(gr[j], below, dc, 0, 0, 0);
+                x[j] = (c <= r) ? x[j] : 0.0;                // row sums: the diagonal counts once, here
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) dc = __builtin_amdgcn_mfma_f64_16x16x4f64(gr[j], x[j], dc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < 16; ++j) mysh[(4 * j + lr) * SMM_PITCH + lc] = x[j];
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) {
+                const double t = mysh[(16 * jj + lc) * SMM_PITCH + 4 * kb + lr];
+                dr[jj] = __builtin_amdgcn_mfma_f64_16x16x4f64(gc[kb], t, dr[jj], 0, 0, 0);
+            }
+        const double o[4] = {dc.x, dc.y, dc.z, dc.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int v = lr + 4 * i;
+            if (v < lv) colpart[(long long)v * colpart_stride + I * n + cb + lc] = o[i];
+        }
+    }
+    // row sums of the four waves, in wave order
+    __syncthreads();
+    double* red = &sh[0][0];  // [wave][jj][i][lane]: 4 * 16 * 64 doubles = 32 KiB of the 34 KiB
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+        const double o[4] = {dr[jj].x, dr[jj].y, dr[jj].z, dr[jj].w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) red[((wave * 4 + jj) * 4 + i) * 64 + lane] = o[i];
+    }
+    __syncthreads();
+    // thread (wave, lane) takes row group jj = wave: rows 16 wave + lc, vectors lr + 4 i
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int v = lr + 4 * i;
+        const int jj = wave;
+        const double s0 = red[((0 * 4 + jj) * 4 + i) * 64 + lane], s1 = red[((1 * 4 + jj) * 4 + i) * 64 + lane];
+        const double s2 = red[((2 * 4 + jj) * 4 + i) * 64 + lane], s3 = red[((3 * 4 + jj) * 4 + i) * 64 + lane];
+        if (v < lv) rowpart[(long long)v * rowpart_stride + J * n + r0 + 16 * jj + lc] = ((s0 + s1) + s2) + s3;
     }
 }
 

@@ -66,6 +66,8 @@ struct Defaults {
     int apply_kernel = -1;     // ELLHIP_OPT_APPLY_KERNEL (-1: by depth)
     int fuse_dots = 1;         // ELLHIP_OPT_FUSE_DOTS
     int resident = 1;          // ELLHIP_OPT_RESIDENT
+    int overlap = 1;           // ELLHIP_OPT_OVERLAP
+    int lookahead = 12;        // ELLHIP_OPT_LOOKAHEAD
     int stable_solve = 2;      // ELLHIP_OPT_STABLE_SOLVE
     int stable_factor = 2;     // ELLHIP_OPT_STABLE_FACTOR
     int pad = -1;              // ELLHIP_OPT_PAD: extra doubles per row of Q; -1 = by size (create_impl)
@@ -110,6 +112,21 @@ struct ellhip_space {
     double* d_cpend = nullptr;       // deferred mode: their coefficients sigma/omega
     double* d_rowpart = nullptr;     // symmetric GEMV: per-segment row partial sums  [n/SYMV_SEG][n]
     double* d_colpart = nullptr;     // symmetric GEMV: per-strip column partial sums [n/SYMV_H][n]
+    // pipelined queue runs on the lower-triangle schedule (ELLHIP_OPT_OVERLAP): the next cut's GEMV is issued on a second
+    // stream beside this cut's reduction + scalar stage, into the other of two sets of partial sums
+    int overlap = 1;
+    double* d_rowpart2 = nullptr;
+    double* d_colpart2 = nullptr;
+    int part_set = 0;                // the set the primed gradient's GEMV wrote / writes (see rowpart_of)
+    hipStream_t symv_stream = nullptr;
+    // ... and with the GEMVs of up to `lookahead` consecutive queued cuts computed in ONE pass over Q_base (k_symv_multi,
+    // ELLHIP_OPT_LOOKAHEAD): vector l of a group writes partial-sum set 2 + l (slices of one allocation)
+    int lookahead = 12;
+    double* d_rowpart_m = nullptr;   // [MULTI_MAX][nsegs][n]
+    double* d_colpart_m = nullptr;   // [MULTI_MAX][nstrips][n]
+    double* d_gT = nullptr;          // [n][16]: a group's gradients side by side (operand layout of k_symm_mfma)
+    hipEvent_t ev_symv = nullptr;    // the GEMV issued ahead has finished
+    hipEvent_t ev_red[2] = {nullptr, nullptr};  // set k is free again (its reduction, and every apply pass before, are done)
     int symv = 1;                    // allow the lower-triangle GEMV in deferred mode (ELLHIP_SYMV=0 disables)
     int symv_rw = 2;
     long long symv_min_n = 8192;     // below this the full-row pass is faster (few, small triangle tiles)
@@ -264,6 +281,8 @@ void pick_shape(ellhip_space* s) {
     s->apply_lower = g_defaults.apply_lower;
     s->apply_kernel = g_defaults.apply_kernel;
     s->fuse_dots = g_defaults.fuse_dots;
+    s->overlap = g_defaults.overlap;
+    s->lookahead = g_defaults.lookahead;
     s->resident = g_defaults.resident;
     s->stable_solve = g_defaults.stable_solve;
     s->stable_factor = g_defaults.stable_factor;
@@ -594,32 +613,48 @@ int symv_alloc(ellhip_space* s) {
     return 0;
 }
 
+// partial-sum sets of the lower-triangle GEMV: 0 = the handle's own, 1 = the second set of overlapped queue runs,
+// 2 + l = vector l of a k_symv_multi group
+constexpr int MULTI_MAX = 16;  // = SMM_NV
+constexpr int MULTI_VALU_MAX = 3;  // largest group k_symv_multi takes (vector ALU, bit-identical to k_symv)
+size_t rowpart_elems(const ellhip_space* s) { return (size_t)((s->n + s->symv_seg - 1) / s->symv_seg) * (size_t)s->n; }
+size_t colpart_elems(const ellhip_space* s) { return (size_t)((s->nrows + SYMV_H - 1) / SYMV_H) * (size_t)s->n; }
+double* rowpart_of(const ellhip_space* s, int set) {
+    return set == 0 ? s->d_rowpart : set == 1 ? s->d_rowpart2 : s->d_rowpart_m + (size_t)(set - 2) * rowpart_elems(s);
+}
+double* colpart_of(const ellhip_space* s, int set) {
+    return set == 0 ? s->d_colpart : set == 1 ? s->d_colpart2 : s->d_colpart_m + (size_t)(set - 2) * colpart_elems(s);
+}
+
 template <int RW, int SEG>
-void symv_go(ellhip_space* s, const double* g_dev, unsigned nstrips, unsigned nsegs, bool nt) {
+void symv_go(ellhip_space* s, const double* g_dev, unsigned nstrips, unsigned nsegs, bool nt, hipStream_t st, int set) {
+    double* rowpart = rowpart_of(s, set);
+    double* colpart = colpart_of(s, set);
     if (nt)
-        hipLaunchKernelGGL((k_symv<RW, true, 0, SEG>), dim3(nstrips, nsegs), dim3(256), 0, s->stream, (const double*)s->d_Q,
-                           s->ld, s->n, s->row0, s->nrows, g_dev, s->d_rowpart, s->d_colpart, s->d_st);
+        hipLaunchKernelGGL((k_symv<RW, true, 0, SEG>), dim3(nstrips, nsegs), dim3(256), 0, st, (const double*)s->d_Q,
+                           s->ld, s->n, s->row0, s->nrows, g_dev, rowpart, colpart, s->d_st);
     else
-        hipLaunchKernelGGL((k_symv<RW, false, 0, SEG>), dim3(nstrips, nsegs), dim3(256), 0, s->stream, (const double*)s->d_Q,
-                           s->ld, s->n, s->row0, s->nrows, g_dev, s->d_rowpart, s->d_colpart, s->d_st);
+        hipLaunchKernelGGL((k_symv<RW, false, 0, SEG>), dim3(nstrips, nsegs), dim3(256), 0, st, (const double*)s->d_Q,
+                           s->ld, s->n, s->row0, s->nrows, g_dev, rowpart, colpart, s->d_st);
 }
 
 int launch_symv_reduce(ellhip_space* s, const double* g_dev, double* y_out);
-int launch_symv(ellhip_space* s, const double* g_dev, double* y_out) {
+// the tiles alone, on `st`, into partial-sum set `set`
+int launch_symv_tiles(ellhip_space* s, const double* g_dev, hipStream_t st, int set) {
     const int seg = s->symv_seg;
     {
-        ProfScope ps(s, CLS_SYMV);
+        ProfScope ps(s, CLS_SYMV, st);
         const unsigned nstrips = (unsigned)((s->nrows + SYMV_H - 1) / SYMV_H);  // local strips
         const unsigned nsegs = (unsigned)((s->n + seg - 1) / seg);
         const bool nt = s->sh_gemv.nt != 0;
         if (seg == SYMV_SEG_SMALL) {
-            symv_go<8, SYMV_SEG_SMALL>(s, g_dev, nstrips, nsegs, nt);  // narrow segments: 8 rows x 1 chunk in flight
+            symv_go<8, SYMV_SEG_SMALL>(s, g_dev, nstrips, nsegs, nt, st, set);  // narrow segments: 8 rows x 1 chunk in flight
         } else if (seg == SYMV_SEG) {
             switch (s->symv_rw) {
-                case 1: symv_go<1, SYMV_SEG>(s, g_dev, nstrips, nsegs, nt); break;
-                case 2: symv_go<2, SYMV_SEG>(s, g_dev, nstrips, nsegs, nt); break;
-                case 4: symv_go<4, SYMV_SEG>(s, g_dev, nstrips, nsegs, nt); break;
-                case 8: symv_go<8, SYMV_SEG>(s, g_dev, nstrips, nsegs, nt); break;
+                case 1: symv_go<1, SYMV_SEG>(s, g_dev, nstrips, nsegs, nt, st, set); break;
+                case 2: symv_go<2, SYMV_SEG>(s, g_dev, nstrips, nsegs, nt, st, set); break;
+                case 4: symv_go<4, SYMV_SEG>(s, g_dev, nstrips, nsegs, nt, st, set); break;
+                case 8: symv_go<8, SYMV_SEG>(s, g_dev, nstrips, nsegs, nt, st, set); break;
                 default: return fail(ELLHIP_E_INVALID, "unsupported rows-in-flight of the lower-triangle GEMV (1, 2, 4, 8)");
             }
         } else {
@@ -627,6 +662,11 @@ int launch_symv(ellhip_space* s, const double* g_dev, double* y_out) {
         }
         HIPCHK(hipGetLastError());
     }
+    return 0;
+}
+int launch_symv(ellhip_space* s, const double* g_dev, double* y_out) {
+    int rc = launch_symv_tiles(s, g_dev, s->stream, s->part_set);
+    if (rc) return rc;
     return launch_symv_reduce(s, g_dev, y_out);
 }
 
@@ -639,7 +679,8 @@ int launch_symv_reduce(ellhip_space* s, const double* g_dev, double* y_out) {
     const int np = (!s->sharded && s->fuse_dots) ? s->defer : 0;
 #define REDUCE_GO(NPV)                                                                                                \
     hipLaunchKernelGGL(k_symv_reduce<NPV>, dim3((unsigned)((s->n + 127) / 128)), dim3(256), 0, s->stream, s->n, s->row0, \
-                       s->nrows, (long long)seg, (const double*)s->d_rowpart, (const double*)s->d_colpart, y_out,      \
+                       s->nrows, (long long)seg, (const double*)rowpart_of(s, s->part_set),                          \
+                       (const double*)colpart_of(s, s->part_set), y_out,                                               \
                        s->d_st, g_dev, (const double*)s->d_pend, s->d_partial)
     if (np == 24) REDUCE_GO(24);
     else if (np == 16) REDUCE_GO(16);
@@ -1123,6 +1164,198 @@ int queue_commit_impl(ellhip_space* s, long long index, long long next) {
 }
 
 
+// ---- pipelined queue runs with the next GEMV issued ahead (ELLHIP_OPT_OVERLAP) ---------------------------------------
+// On the recorded schedule y = Q_base * g of the NEXT queued cut does not depend on the cut being taken (Q_base only
+// changes in an apply pass; the scalar stage corrects y with the recorded updates afterwards), and the queue holds the
+// next gradient already.  So k_symv of cut i+1 goes to a second, low-priority stream BEFORE the scalar stage of cut i is
+// enqueued, into the other set of partial sums; its reduction (which also forms the dot products with the vector cut i
+// records) follows on the main stream once both are done.  The 27 us of reduction + scalar stage per cut then run beside
+// the 190 us GEMV instead of between two of them.  Same kernels, same operands, same order of every sum: bit-identical
+// to the serial issue order.  Not across an apply pass (the GEMV after it reads the matrix it writes), not on shards
+// (their collective sits between the GEMV and the scalar stage), not while profiling events would be recorded out of
+// order -- ProfScope takes the stream a kernel is launched on.
+bool overlap_ok(const ellhip_space* s) {
+    return s->overlap && s->variant == ELLHIP_SPACE_ELL && !s->sharded && symv_ok(s);
+}
+
+int overlap_setup(ellhip_space* s) {
+    if (s->symv_stream) return 0;
+    const size_t nsegs = (size_t)((s->n + s->symv_seg - 1) / s->symv_seg), nstrips = (size_t)((s->nrows + SYMV_H - 1) / SYMV_H);
+    HIPCHK(hipMalloc(&s->d_rowpart2, nsegs * (size_t)s->n * sizeof(double)));
+    HIPCHK(hipMalloc(&s->d_colpart2, nstrips * (size_t)s->n * sizeof(double)));
+    HIPCHK(hipMemsetAsync(s->d_rowpart2, 0, nsegs * (size_t)s->n * sizeof(double), s->stream));
+    HIPCHK(hipMemsetAsync(s->d_colpart2, 0, nstrips * (size_t)s->n * sizeof(double), s->stream));
+    int least = 0, greatest = 0;
+    HIPCHK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+    HIPCHK(hipEventCreateWithFlags(&s->ev_symv, hipEventDisableTiming));
+    for (int k = 0; k < 2; ++k) HIPCHK(hipEventCreateWithFlags(&s->ev_red[k], hipEventDisableTiming));
+    // lowest priority: the short reduction / scalar kernels of the main stream get the CU slots the GEMV's workgroups free
+    HIPCHK(hipStreamCreateWithPriority(&s->symv_stream, hipStreamNonBlocking, least));
+    return 0;
+}
+
+int queue_run_overlapped(ellhip_space* s, long long first, long long count) {
+    int rc = overlap_setup(s);
+    if (rc) return rc;
+    // everything enqueued so far (apply passes of direct updates, an earlier run's reductions) precedes the first GEMV
+    // issued ahead
+    for (int k = 0; k < 2; ++k) HIPCHK(hipEventRecord(s->ev_red[k], s->stream));
+    for (long long i = first; i < first + count; ++i) {
+        const bool was_primed = s->primed && s->primed_qindex == i;
+        rc = queue_prime_impl(s, i);  // (only the first cut of a run pays its GEMV on the main stream)
+        if (rc) return rc;
+        if (!was_primed)  // that reduction reads the current set: the GEMV after next may only overwrite it afterwards
+            for (int k = 0; k < 2; ++k) HIPCHK(hipEventRecord(s->ev_red[k], s->stream));
+        const long long next = (i + 1 < s->qk) ? i + 1 : -1;
+        // this cut becomes recorded update number npend; when that fills the slots an apply pass follows it, and the
+        // next GEMV has to read what that pass writes
+        const bool ahead = next >= 0 && symv_ok(s) && s->npend + 1 < s->defer;
+        const int set = s->part_set ^ 1;
+        if (ahead) {
+            HIPCHK(hipStreamWaitEvent(s->symv_stream, s->ev_red[set], 0));
+            rc = launch_symv_tiles(s, qgrad(s, next), s->symv_stream, set);
+            if (rc) return rc;
+            HIPCHK(hipEventRecord(s->ev_symv, s->symv_stream));
+        }
+        rc = queue_cut_impl(s, i);
+        if (rc) return rc;
+        if (!ahead) {
+            rc = queue_commit_impl(s, i, next);  // apply pass if due, then GEMV + reduction on the main stream
+            if (rc) return rc;
+            for (int k = 0; k < 2; ++k) HIPCHK(hipEventRecord(s->ev_red[k], s->stream));
+            continue;
+        }
+        // what queue_commit_impl does on this schedule when no apply pass is due, with the GEMV already in flight
+        s->shrink_pending = false;
+        s->dots_np = 0;
+        s->dots_need_gy = false;
+        HIPCHK(hipStreamWaitEvent(s->stream, s->ev_symv, 0));
+        s->part_set = set;
+        rc = launch_symv_reduce(s, qgrad(s, next), s->d_gt[s->cur ^ 1]);
+        if (rc) return rc;
+        HIPCHK(hipEventRecord(s->ev_red[set], s->stream));
+        s->cur ^= 1;
+        s->primed = true;
+        s->g_cur = qgrad(s, next);
+        s->primed_qindex = next;
+    }
+    return 0;
+}
+
+// ---- pipelined queue runs with several cuts' GEMVs in one pass over Q_base (ELLHIP_OPT_LOOKAHEAD) ---------------------
+// The same observation taken further: between two apply passes EVERY queued cut's y = Q_base g refers to the same
+// matrix, so the products of a group of L consecutive queued cuts are formed in ONE pass over the lower triangle
+// (k_symv_multi: each element loaded once, used for L gradients) -- (4 / L) n^2 bytes per update instead of 4 n^2.
+// The reductions and scalar stages then run cut by cut as before (cut l's correction needs the vector cut l - 1
+// recorded).  A group never reaches across an apply pass or the end of the run; a cut that arrives primed (by an
+// earlier call) is taken by itself first.  Two kernels:
+//   lookahead <= 3   k_symv_multi on the vector ALU: per vector k_symv's arithmetic, bit-identical results;
+//   lookahead >  3   k_symm_mfma on the FP64 matrix cores (n a multiple of 64): up to 16 gradients in the time of ONE
+//                    pass; y differs from k_symv's by a few ulp (own association, fused multiply-add) -- inside the
+//                    contract's 1e-10, not bit-identical to the other schedules.
+bool multi_ok(const ellhip_space* s) {
+    return s->lookahead > 1 && s->variant == ELLHIP_SPACE_ELL && !s->sharded && symv_ok(s);
+}
+bool multi_mfma(const ellhip_space* s) { return s->lookahead > MULTI_VALU_MAX && (s->n % 64) == 0; }
+
+int multi_setup(ellhip_space* s) {
+    if (s->d_rowpart_m) return 0;
+    HIPCHK(hipMalloc(&s->d_rowpart_m, (size_t)MULTI_MAX * rowpart_elems(s) * sizeof(double)));
+    HIPCHK(hipMalloc(&s->d_colpart_m, (size_t)MULTI_MAX * colpart_elems(s) * sizeof(double)));
+    HIPCHK(hipMemsetAsync(s->d_rowpart_m, 0, (size_t)MULTI_MAX * rowpart_elems(s) * sizeof(double), s->stream));
+    HIPCHK(hipMemsetAsync(s->d_colpart_m, 0, (size_t)MULTI_MAX * colpart_elems(s) * sizeof(double), s->stream));
+    HIPCHK(hipMalloc(&s->d_gT, (size_t)s->n * SMM_NV * sizeof(double)));
+    return 0;
+}
+
+template <int SEG>
+void symm_mfma_go(ellhip_space* s, const double* g_dev, int lv) {
+    const unsigned nstrips = (unsigned)((s->nrows + SYMV_H - 1) / SYMV_H);
+    const unsigned nsegs = (unsigned)((s->n + SEG - 1) / SEG);
+    hipLaunchKernelGGL(k_pack_grads, dim3((unsigned)((s->n * SMM_NV + 255) / 256)), dim3(256), 0, s->stream, g_dev, s->n, lv,
+                       s->n, s->d_gT);
+    if (s->sh_gemv.nt != 0)
+        hipLaunchKernelGGL((k_symm_mfma<true, SEG>), dim3(nstrips, nsegs), dim3(256), 0, s->stream, (const double*)s->d_Q,
+                           s->ld, s->n, (const double*)s->d_gT, lv, s->d_rowpart_m, s->d_colpart_m,
+                           (long long)rowpart_elems(s), (long long)colpart_elems(s), (const DevState*)s->d_st);
+    else
+        hipLaunchKernelGGL((k_symm_mfma<false, SEG>), dim3(nstrips, nsegs), dim3(256), 0, s->stream, (const double*)s->d_Q,
+                           s->ld, s->n, (const double*)s->d_gT, lv, s->d_rowpart_m, s->d_colpart_m,
+                           (long long)rowpart_elems(s), (long long)colpart_elems(s), (const DevState*)s->d_st);
+}
+
+// (the thread-to-element map, and with it the bits, follow the handle's segment width and are independent of the rows
+// in flight: k_symv<8, .., 512> of the narrow segments and k_symv_multi<2, .., 512, LV> give the same sums)
+template <int SEG, int LV>
+void symv_multi_go(ellhip_space* s, const double* g_dev) {
+    const unsigned nstrips = (unsigned)((s->nrows + SYMV_H - 1) / SYMV_H);
+    const unsigned nsegs = (unsigned)((s->n + SEG - 1) / SEG);
+    if (s->sh_gemv.nt != 0)
+        hipLaunchKernelGGL((k_symv_multi<2, true, SEG, LV>), dim3(nstrips, nsegs), dim3(256), 0, s->stream,
+                           (const double*)s->d_Q, s->ld, s->n, s->row0, s->nrows, g_dev, s->n, s->d_rowpart_m, s->d_colpart_m,
+                           (long long)rowpart_elems(s), (long long)colpart_elems(s), (const DevState*)s->d_st);
+    else
+        hipLaunchKernelGGL((k_symv_multi<2, false, SEG, LV>), dim3(nstrips, nsegs), dim3(256), 0, s->stream,
+                           (const double*)s->d_Q, s->ld, s->n, s->row0, s->nrows, g_dev, s->n, s->d_rowpart_m, s->d_colpart_m,
+                           (long long)rowpart_elems(s), (long long)colpart_elems(s), (const DevState*)s->d_st);
+}
+
+int queue_run_multi(ellhip_space* s, long long first, long long count) {
+    int rc = multi_setup(s);
+    if (rc) return rc;
+    const long long end = first + count;
+    long long i = first;
+    while (i < end) {
+        long long g = 1;
+        if (!(s->primed && s->primed_qindex == i)) {
+            rc = ensure_committed(s);
+            if (rc) return rc;
+            const long long room = (long long)s->defer - s->npend;  // cuts that can still be recorded before the apply pass
+            const long long cap = multi_mfma(s) ? MULTI_MAX : MULTI_VALU_MAX;
+            g = std::min<long long>(std::min<long long>(s->lookahead, cap), std::min(end - i, room));
+        }
+        if (g <= 1) {  // a cut primed earlier, the last one before an apply pass, the last one of the run
+            rc = queue_prime_impl(s, i);
+            if (!rc) rc = queue_cut_impl(s, i);
+            if (!rc) rc = queue_commit_impl(s, i, -1);
+            if (rc) return rc;
+            i += 1;
+            continue;
+        }
+        {
+            ProfScope ps(s, CLS_SYMV);
+            const bool wide = s->symv_seg == SYMV_SEG;
+            if (multi_mfma(s)) {
+                if (wide) symm_mfma_go<SYMV_SEG>(s, qgrad(s, i), (int)g);
+                else symm_mfma_go<SYMV_SEG_SMALL>(s, qgrad(s, i), (int)g);
+            } else if (g == 2) {
+                if (wide) symv_multi_go<SYMV_SEG, 2>(s, qgrad(s, i));
+                else symv_multi_go<SYMV_SEG_SMALL, 2>(s, qgrad(s, i));
+            } else {
+                if (wide) symv_multi_go<SYMV_SEG, 3>(s, qgrad(s, i));
+                else symv_multi_go<SYMV_SEG_SMALL, 3>(s, qgrad(s, i));
+            }
+            HIPCHK(hipGetLastError());
+        }
+        for (long long l = 0; l < g; ++l) {
+            s->part_set = 2 + (int)l;
+            s->dots_np = 0;
+            s->dots_need_gy = false;
+            rc = launch_symv_reduce(s, qgrad(s, i + l), s->d_gt[s->cur]);
+            s->part_set = 0;
+            if (rc) return rc;
+            s->primed = true;
+            s->g_cur = qgrad(s, i + l);
+            s->primed_qindex = i + l;
+            rc = queue_cut_impl(s, i + l);
+            if (!rc) rc = queue_commit_impl(s, i + l, -1);  // (the apply pass when this cut fills the slots)
+            if (rc) return rc;
+        }
+        i += g;
+    }
+    return 0;
+}
+
 // ---- queue runs with the matrix parked on-chip (resident_kernels.hpp) ------------------------------------------------
 // Chosen for a run of at least RS_MIN_COUNT queued cuts of an unsharded Ell handle whose lower triangle fits the
 // register files: R = the smallest super-tile edge with no more super-tiles than the device has CUs, and one workgroup
@@ -1273,6 +1506,15 @@ void ellhip_destroy(ellhip_space* s) {
     if (s->d_rs_bar) (void)hipFree(s->d_rs_bar);
     if (s->d_rowpart) (void)hipFree(s->d_rowpart);
     if (s->d_colpart) (void)hipFree(s->d_colpart);
+    if (s->d_rowpart2) (void)hipFree(s->d_rowpart2);
+    if (s->d_colpart2) (void)hipFree(s->d_colpart2);
+    if (s->d_rowpart_m) (void)hipFree(s->d_rowpart_m);
+    if (s->d_colpart_m) (void)hipFree(s->d_colpart_m);
+    if (s->d_gT) (void)hipFree(s->d_gT);
+    if (s->ev_symv) (void)hipEventDestroy(s->ev_symv);
+    for (int k = 0; k < 2; ++k)
+        if (s->ev_red[k]) (void)hipEventDestroy(s->ev_red[k]);
+    if (s->symv_stream) (void)hipStreamDestroy(s->symv_stream);
     if (s->d_flags) (void)hipFree(s->d_flags);
     if (s->d_st) (void)hipFree(s->d_st);
     if (s->h_result) (void)hipHostFree(s->h_result);
@@ -1314,6 +1556,8 @@ int ellhip_clone(const ellhip_space* src_c, ellhip_space** out) {
     s->apply_lower = src->apply_lower;
     s->apply_kernel = src->apply_kernel;
     s->fuse_dots = src->fuse_dots;
+    s->overlap = src->overlap;
+    s->lookahead = src->lookahead;
     s->resident = src->resident;
     s->shard_symmetric = src->shard_symmetric;
     s->upper_stale = src->upper_stale;
@@ -1605,8 +1849,9 @@ int option_ok(int key, long long v) {
         case ELLHIP_OPT_APPLY_KERNEL:
             return (v >= -1 && v <= 2) ? 0 : fail(ELLHIP_E_INVALID, "option value must be -1, 0, 1 or 2");
         case ELLHIP_OPT_AUTO_DEFER: case ELLHIP_OPT_SYMV: case ELLHIP_OPT_APPLY_LOWER:
-        case ELLHIP_OPT_FUSE_DOTS: case ELLHIP_OPT_RESIDENT:
+        case ELLHIP_OPT_FUSE_DOTS: case ELLHIP_OPT_RESIDENT: case ELLHIP_OPT_OVERLAP:
             return (v == 0 || v == 1) ? 0 : fail(ELLHIP_E_INVALID, "option value must be 0 or 1");
+        case ELLHIP_OPT_LOOKAHEAD: return (v >= 1 && v <= 16) ? 0 : fail(ELLHIP_E_INVALID, "ELLHIP_OPT_LOOKAHEAD: 1 .. 16");
         case ELLHIP_OPT_SYMV_MIN_N: return v >= 512 ? 0 : fail(ELLHIP_E_INVALID, "ELLHIP_OPT_SYMV_MIN_N must be >= 512");
         case ELLHIP_OPT_STABLE_SOLVE: case ELLHIP_OPT_STABLE_FACTOR:
             return (v >= 0 && v <= 2) ? 0 : fail(ELLHIP_E_INVALID, "option value must be 0, 1 or 2");
@@ -1631,6 +1876,8 @@ int ellhip_set_default_option(int key, int64_t value) {
         case ELLHIP_OPT_APPLY_KERNEL: g_defaults.apply_kernel = (int)value; break;
         case ELLHIP_OPT_FUSE_DOTS: g_defaults.fuse_dots = (int)value; break;
         case ELLHIP_OPT_RESIDENT: g_defaults.resident = (int)value; break;
+        case ELLHIP_OPT_OVERLAP: g_defaults.overlap = (int)value; break;
+        case ELLHIP_OPT_LOOKAHEAD: g_defaults.lookahead = (int)value; break;
         case ELLHIP_OPT_STABLE_SOLVE: g_defaults.stable_solve = (int)value; break;
         case ELLHIP_OPT_STABLE_FACTOR: g_defaults.stable_factor = (int)value; break;
         case ELLHIP_OPT_PAD: g_defaults.pad = (int)value; break;
@@ -1651,6 +1898,8 @@ int ellhip_default_option(int key, int64_t* value) {
         case ELLHIP_OPT_APPLY_KERNEL: *value = g_defaults.apply_kernel; break;
         case ELLHIP_OPT_FUSE_DOTS: *value = g_defaults.fuse_dots; break;
         case ELLHIP_OPT_RESIDENT: *value = g_defaults.resident; break;
+        case ELLHIP_OPT_OVERLAP: *value = g_defaults.overlap; break;
+        case ELLHIP_OPT_LOOKAHEAD: *value = g_defaults.lookahead; break;
         case ELLHIP_OPT_STABLE_SOLVE: *value = g_defaults.stable_solve; break;
         case ELLHIP_OPT_STABLE_FACTOR: *value = g_defaults.stable_factor; break;
         case ELLHIP_OPT_PAD: *value = g_defaults.pad; break;
@@ -1670,9 +1919,12 @@ int ellhip_set_option(ellhip_space* s, int key, int64_t value) {
     const bool ell = s->variant == ELLHIP_SPACE_ELL;
     switch (key) {
         case ELLHIP_OPT_SYMV: case ELLHIP_OPT_SYMV_MIN_N: case ELLHIP_OPT_APPLY_LOWER: case ELLHIP_OPT_APPLY_KERNEL:
-        case ELLHIP_OPT_RESIDENT:
+        case ELLHIP_OPT_RESIDENT: case ELLHIP_OPT_OVERLAP: case ELLHIP_OPT_LOOKAHEAD:
             if (!ell) return fail(ELLHIP_E_INVALID, "this option exists on Ell only");
-            s->resident = (int)value;  // (chosen per queue run: nothing recorded depends on it)
+            // (chosen per queue run: nothing recorded depends on them)
+            if (key == ELLHIP_OPT_RESIDENT) s->resident = (int)value;
+            else if (key == ELLHIP_OPT_OVERLAP) s->overlap = (int)value;
+            else s->lookahead = (int)value;
             return 0;
         case ELLHIP_OPT_FUSE_DOTS: {
             if (!ell) return fail(ELLHIP_E_INVALID, "this option exists on Ell only");
@@ -1715,6 +1967,8 @@ int ellhip_get_option(const ellhip_space* s, int key, int64_t* value) {
         case ELLHIP_OPT_APPLY_KERNEL: *value = s->apply_kernel; break;
         case ELLHIP_OPT_FUSE_DOTS: *value = s->fuse_dots; break;
         case ELLHIP_OPT_RESIDENT: *value = s->resident; break;
+        case ELLHIP_OPT_OVERLAP: *value = s->overlap; break;
+        case ELLHIP_OPT_LOOKAHEAD: *value = s->lookahead; break;
         case ELLHIP_OPT_STABLE_SOLVE: *value = s->stable_solve; break;
         case ELLHIP_OPT_STABLE_FACTOR: *value = s->stable_factor; break;
         case ELLHIP_OPT_PAD: *value = s->ld - s->n; break;
@@ -1843,6 +2097,8 @@ int ellhip_queue_run_fused(ellhip_space* s, int64_t first, int64_t count) {
     if (!s || first < 0 || count < 0 || first + count > s->qk) return fail(ELLHIP_E_INVALID, "queue range");
     DeviceGuard guard(s->device);
     if (resident_ok(s, count)) return resident_run(s, first, count);
+    if (multi_ok(s)) return queue_run_multi(s, first, count);
+    if (overlap_ok(s)) return queue_run_overlapped(s, first, count);
     for (int64_t i = first; i < first + count; ++i) {
         int rc = queue_prime_impl(s, i);  // (pipelined form: only the first cut of a run pays a separate GEMV pass)
         if (!rc) rc = queue_cut_impl(s, i);

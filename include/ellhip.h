@@ -224,6 +224,19 @@ int ellhip_set_shard_symmetric(ellhip_space *s, int flag);
  *                                                    chip's register files and run the whole batch in ONE persistent launch
  *                                                    (n <= 4224 on a 256-CU device: 9 us instead of 39 us per update at
  *                                                    n = 4096); 0 = always the streamed schedules
+ *   ELLHIP_OPT_OVERLAP           0 / 1      1        Ell, ellhip_queue_run_fused on the lower-triangle schedule: the NEXT queued
+ *                                                    cut's GEMV (it reads Q_base, which the cut being taken does not change) is
+ *                                                    issued on a second stream beside this cut's reduction + scalar stage;
+ *                                                    bit-identical to 0 (same kernels, operands and summation order)
+ *   ELLHIP_OPT_LOOKAHEAD         1 .. 16    12       Ell, ellhip_queue_run_fused on the lower-triangle schedule: the GEMVs of up to
+ *                                                    this many consecutive QUEUED cuts are formed in one pass over Q_base
+ *                                                    (they all refer to the same matrix until the next apply pass):
+ *                                                    (4 / L) n^2 bytes per update instead of 4 n^2.  L <= 3: vector-ALU
+ *                                                    kernel, bit-identical to 1; L > 3 (n a multiple of 64): FP64 matrix
+ *                                                    cores, y differs by a few ulp from the other schedules (own
+ *                                                    association; inside the 1e-10 contract).  Only a queue knows the
+ *                                                    next gradients: ellhip_update and the prime / cut / commit calls are
+ *                                                    unaffected
  *   ELLHIP_OPT_STABLE_SOLVE      0 / 1 / 2  2        EllStable: 0 = one launch per 128-block (no in-launch waits),
  *                                                    1 = persistent solves, 2 = persistent + helper workgroups
  *   ELLHIP_OPT_STABLE_FACTOR     0 / 1 / 2  2        EllStable factor update: 0 = tile kernel reading the scratch
@@ -251,6 +264,8 @@ int ellhip_set_shard_symmetric(ellhip_space *s, int flag);
 #define ELLHIP_OPT_LP_WIDE 11
 #define ELLHIP_OPT_BATCH_THREADS 12
 #define ELLHIP_OPT_RESIDENT 13
+#define ELLHIP_OPT_OVERLAP 14
+#define ELLHIP_OPT_LOOKAHEAD 15
 int ellhip_set_option(ellhip_space *s, int key, int64_t value);
 int ellhip_get_option(const ellhip_space *s, int key, int64_t *value);
 int ellhip_set_default_option(int key, int64_t value);

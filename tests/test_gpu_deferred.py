@@ -473,6 +473,7 @@ def test_dot_products_from_the_symv_reduction_agree_with_the_separate_launch(gpu
     associate the dot products differently, so they agree to rounding (1e-13), not to the bit; the drivers of ONE form
     (direct updates, two-pass queue, pipelined queue, with a failing cut) agree bit for bit."""
     set_default("RESIDENT", 0)   # the STREAMED schedules are compared bit for bit here; the resident queue run sums Q g in its own shape (test_gpu_resident.py)
+    set_default("LOOKAHEAD", 3)  # ... and groups of up to 3 queued cuts keep k_symv's arithmetic (the matrix-core groups of the default, 12, agree to rounding: test_gpu_overlap.py)
     from ellalgo_rs_amd import synth
     set_default("SYMV_MIN_N", 512)
     k = 37
