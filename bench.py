@@ -482,6 +482,12 @@ def brief_config(pkg, synth, torch, workload: str, K: int, W: int, P: int, devic
     new handle of that size starts with; recorded updates flushed on both sides of the timed region), reduced to the
     figures `other_configs` carries."""
     n, variant, cutgen, desc = WORKLOADS[workload]
+    # The previous workload's handle has just been destroyed: the driver's housekeeping for gigabytes of freed device memory
+    # runs in the background for a while and stalls whatever synchronizes meanwhile (measured on this pool: 75-85 ms added
+    # to ONE later stream synchronization within ~100 ms of the hipFree calls, tools/probe_brief.py; the GPU timeline of the
+    # same run shows the kernels back to back).  Let it finish outside the timed regions.
+    torch.cuda.synchronize()
+    time.sleep(0.5)
     t_gen = time.perf_counter()
     kinds, grads, b0, b1 = (synth.parallel_cuts if cutgen == "parallel" else synth.deep_cuts)(n, W + K + P)
     if variant == "ell":
@@ -521,6 +527,8 @@ def brief_config(pkg, synth, torch, workload: str, K: int, W: int, P: int, devic
            "apply_gemv": 16.0 * n2, "symv": 4.0 * n2, "stable_fwd": 8.0 * n2, "stable_bwd": 4.0 * n2, "stable_factor": 12.0 * n2}
     resident = variant == "ell" and prof.get("resident", (0.0, 0))[1] > 0
     look = space.get_option(pkg.capi.OPT_LOOKAHEAD) if (variant == "ell" and symv_mode) else 1
+    qd = space.get_option(pkg.capi.OPT_QUEUE_DEPTH) if (variant == "ell" and symv_mode) else 0
+    dep_eff = qd if (variant == "ell" and symv_mode and lower_apply and look > 3 and n % 64 == 0 and depth == 24 and qd > depth) else depth
     if variant != "ell":
         fb = 8.0 if space.get_option(pkg.capi.OPT_STABLE_FACTOR) != 0 else 12.0
         alg["stable_factor"] = fb * n2
@@ -536,7 +544,7 @@ def brief_config(pkg, synth, torch, workload: str, K: int, W: int, P: int, devic
                  "the register files for the whole batch (k_ell_resident): NOT HBM-bound, the update is two on-chip hand-offs "
                  "(one grid barrier) long")
     else:
-        bytes_update, model = ell_bytes_per_update(n2, "pipelined", depth, K, symv_mode, lower_apply, False, look)
+        bytes_update, model = ell_bytes_per_update(n2, "pipelined", dep_eff, K, symv_mode, lower_apply, False, look)
     per_kernel = {}
     for name, (ms, cnt) in prof.items():
         if cnt:
@@ -564,7 +572,7 @@ def brief_config(pkg, synth, torch, workload: str, K: int, W: int, P: int, devic
     del space
     return {"workload": workload, "description": desc, "updates_per_s": K / elapsed, "ms_per_step": ms_per_step, "steps": K,
             "warmup": W, "defer_depth": depth,
-            **({"lookahead": look} if (variant == "ell" and not resident and look > 1) else {}),
+            **({"lookahead": look, "queue_depth": dep_eff} if (variant == "ell" and not resident and look > 1) else {}),
             "schedule": ("resident (one launch per batch)" if resident else "pipelined") if variant == "ell" else "ellstable",
             "roofline": roofline}
 
@@ -899,12 +907,19 @@ def main() -> None:
         if prof and prof.get("stable_factor", (0.0, 0))[1] == 0:
             alg["stable_bwd"] = 4.0 * n * n + alg["stable_factor"]
 
-    lookahead = 1
+    lookahead, queue_depth = 1, 0
     if variant == "ell" and symv_mode and not sharded:
         lookahead = space.get_option(pkg.capi.OPT_LOOKAHEAD)
+        queue_depth = space.get_option(pkg.capi.OPT_QUEUE_DEPTH)
+
+    def eff_depth(sched, dep):
+        """Recorded updates per apply pass: inside a pipelined queue run on the group stage (lookahead > 3, n % 64 == 0) a
+        depth-24 handle lets them pile up to ELLHIP_OPT_QUEUE_DEPTH."""
+        deep = sched == "pipelined" and dep == 24 and lookahead > 3 and n % 64 == 0 and lower_apply and queue_depth > dep
+        return queue_depth if deep else dep
 
     def byte_model(sched, dep, steps):
-        return ell_bytes_per_update(n2w, sched, dep, steps, symv_mode, lower_apply, sharded, lookahead)
+        return ell_bytes_per_update(n2w, sched, eff_depth(sched, dep), steps, symv_mode, lower_apply, sharded, lookahead)
 
     def kernel_table(pr):
         tab = {}
@@ -989,7 +1004,7 @@ def main() -> None:
                    "schedule": (("resident (one launch per batch)" if resident_run else ("pipelined" if fused else "two-pass"))
                                 if variant == "ell" else "ellstable"),
                    "defer_depth": depth,
-                   **({"lookahead": lookahead,
+                   **({"lookahead": lookahead, "queue_depth": eff_depth("pipelined", depth),
                        "lookahead_note": "products of up to `lookahead` consecutive QUEUED cuts per pass over Q (ELLHIP_OPT_LOOKAHEAD); "
                                          "a live cutting-plane loop cannot look ahead: see host_call_path and other_schedules"}
                       if (variant == "ell" and fused and lookahead > 1 and not resident_run) else {}),

@@ -99,7 +99,8 @@ __device__ __forceinline__ void queue_bookkeeping(DevState* st, int status, doub
 // through exactly the roundings of the reference's one-update-at-a-time loop (src/ell.rs:117-128).
 // Per update: 8 n^2 (1 + 1/MAXPEND) + ... bytes instead of 16 n^2 (pipelined) or 24 n^2 (two-pass).
 // Unused slots hold c_j = 0 and v_j = 0, which makes every formula above an exact no-op for them.
-constexpr int MAXPEND = 24;  // capacity of the pending-update buffers; the depth in force (NP) is 8, 16 or 24
+constexpr int MAXPEND = 48;  // capacity of the pending-update buffers; the depth in force (NP) is 8, 16 or 24 (48: only inside
+                             // a queue run whose cuts go through the group stage, ELLHIP_OPT_QUEUE_DEPTH)
 
 typedef double double2_t __attribute__((ext_vector_type(2)));
 

@@ -28,6 +28,7 @@
 #include "ell_kernels.hpp"
 #include "ellstable_kernels.hpp"
 #include "resident_kernels.hpp"
+#include "group_kernels.hpp"
 
 using namespace ellhip;
 
@@ -67,7 +68,8 @@ struct Defaults {
     int fuse_dots = 1;         // ELLHIP_OPT_FUSE_DOTS
     int resident = 1;          // ELLHIP_OPT_RESIDENT
     int overlap = 1;           // ELLHIP_OPT_OVERLAP
-    int lookahead = 12;        // ELLHIP_OPT_LOOKAHEAD
+    int lookahead = 16;        // ELLHIP_OPT_LOOKAHEAD
+    int queue_depth = 48;      // ELLHIP_OPT_QUEUE_DEPTH
     int stable_solve = 2;      // ELLHIP_OPT_STABLE_SOLVE
     int stable_factor = 2;     // ELLHIP_OPT_STABLE_FACTOR
     int pad = -1;              // ELLHIP_OPT_PAD: extra doubles per row of Q; -1 = by size (create_impl)
@@ -121,10 +123,17 @@ struct ellhip_space {
     hipStream_t symv_stream = nullptr;
     // ... and with the GEMVs of up to `lookahead` consecutive queued cuts computed in ONE pass over Q_base (k_symv_multi,
     // ELLHIP_OPT_LOOKAHEAD): vector l of a group writes partial-sum set 2 + l (slices of one allocation)
-    int lookahead = 12;
+    int lookahead = 16;
+    int queue_depth = 48;            // recorded updates a queue run on the group stage lets pile up before an apply pass (0: the handle's depth)
     double* d_rowpart_m = nullptr;   // [MULTI_MAX][nsegs][n]
     double* d_colpart_m = nullptr;   // [MULTI_MAX][nstrips][n]
     double* d_gT = nullptr;          // [n][16]: a group's gradients side by side (operand layout of k_symm_mfma)
+    // ... and the group's scalar stage (group_kernels.hpp)
+    double* d_grpY = nullptr;        // [GRP_MAX][n]: y_l = Q_base g_l of the group's cuts
+    double* d_gpart = nullptr;       // [GRP_MAX][ceil(n/128)][MAXPEND + 1]
+    double* d_cpart = nullptr;       // [ceil(n/128)][GRP_MAX * GRP_MAX]
+    double* d_gsums = nullptr;       // [GRP_MAX][MAXPEND + 1] + [GRP_MAX][GRP_MAX]: their sums over the blocks
+    GroupOut* d_gout = nullptr;
     hipEvent_t ev_symv = nullptr;    // the GEMV issued ahead has finished
     hipEvent_t ev_red[2] = {nullptr, nullptr};  // set k is free again (its reduction, and every apply pass before, are done)
     int symv = 1;                    // allow the lower-triangle GEMV in deferred mode (ELLHIP_SYMV=0 disables)
@@ -283,6 +292,7 @@ void pick_shape(ellhip_space* s) {
     s->fuse_dots = g_defaults.fuse_dots;
     s->overlap = g_defaults.overlap;
     s->lookahead = g_defaults.lookahead;
+    s->queue_depth = g_defaults.queue_depth;
     s->resident = g_defaults.resident;
     s->stable_solve = g_defaults.stable_solve;
     s->stable_factor = g_defaults.stable_factor;
@@ -405,13 +415,16 @@ int flush_pending(ellhip_space* s, const double* gvec, double* gv_out) {
                        s->row0, (const double*)s->d_pend, (const double*)s->d_cpend, (const DevState*)s->d_st)
             // measured at n = 16384, ms per pass: k_apply_mfma 0.43-0.44 at any depth; k_apply_lower 0.40 at depth 8 / 16,
             // 0.62 at depth 24 (its registers); k_sweep_apply<LOWER> 0.44 (depth 8)
-            const int apply_kernel = s->apply_kernel < 0 ? (s->defer == 24 ? 2 : 1) : s->apply_kernel;
+            // (more recorded than the handle's depth: a queue run on the group stage let them pile up to 48, queue_run_multi)
+            const bool deep = s->npend > s->defer;
+            const int apply_kernel = deep ? 2 : (s->apply_kernel < 0 ? (s->defer == 24 ? 2 : 1) : s->apply_kernel);
             if (apply_kernel == 2) {  // the rank-NP update on the FP64 matrix cores (k_apply_mfma)
                 const dim3 g2((unsigned)((s->nrows + APM_ROWS - 1) / APM_ROWS), (unsigned)((s->n + APM_COLS - 1) / APM_COLS));
 #define APM_GO(NPV, NTV)                                                                                              \
     hipLaunchKernelGGL((k_apply_mfma<NPV, NTV>), g2, dim3(256), 0, s->stream, s->d_Q, s->ld, s->n, s->nrows, s->row0, \
                        (const double*)s->d_pend, (const double*)s->d_cpend, (const DevState*)s->d_st)
-                if (s->defer == 24) { if (nt) APM_GO(24, true); else APM_GO(24, false); }
+                if (deep) { if (nt) APM_GO(48, true); else APM_GO(48, false); }
+                else if (s->defer == 24) { if (nt) APM_GO(24, true); else APM_GO(24, false); }
                 else if (s->defer == 16) { if (nt) APM_GO(16, true); else APM_GO(16, false); }
                 else { if (nt) APM_GO(8, true); else APM_GO(8, false); }
 #undef APM_GO
@@ -443,7 +456,7 @@ int flush_pending(ellhip_space* s, const double* gvec, double* gv_out) {
         s->dir ^= 1;
     }
     hipLaunchKernelGGL(k_pend_reset, dim3(64), dim3(256), 0, s->stream, s->d_pend, s->d_cpend,
-                       (long long)s->defer * s->n, s->d_st);
+                       (long long)(s->npend > s->defer ? MAXPEND : s->defer) * s->n, s->d_st);
     HIPCHK(hipGetLastError());
     s->npend = 0;
     return 0;
@@ -1265,6 +1278,40 @@ int multi_setup(ellhip_space* s) {
     HIPCHK(hipMemsetAsync(s->d_rowpart_m, 0, (size_t)MULTI_MAX * rowpart_elems(s) * sizeof(double), s->stream));
     HIPCHK(hipMemsetAsync(s->d_colpart_m, 0, (size_t)MULTI_MAX * colpart_elems(s) * sizeof(double), s->stream));
     HIPCHK(hipMalloc(&s->d_gT, (size_t)s->n * SMM_NV * sizeof(double)));
+    const size_t nb = (size_t)((s->n + 127) / 128);
+    HIPCHK(hipMalloc(&s->d_grpY, (size_t)GRP_MAX * (size_t)s->n * sizeof(double)));
+    HIPCHK(hipMalloc(&s->d_gpart, (size_t)GRP_MAX * nb * (MAXPEND + 1) * sizeof(double)));
+    HIPCHK(hipMalloc(&s->d_cpart, nb * GRP_MAX * GRP_MAX * sizeof(double)));
+    HIPCHK(hipMalloc(&s->d_gout, sizeof(GroupOut)));
+    HIPCHK(hipMalloc(&s->d_gsums, (size_t)(GRP_MAX * (MAXPEND + 1) + GRP_MAX * GRP_MAX) * sizeof(double)));
+    HIPCHK(hipMemsetAsync(s->d_gout, 0, sizeof(GroupOut), s->stream));
+    return 0;
+}
+
+// the scalar stage of a group whose products sit in the partial-sum sets 2 .. 2 + g - 1 (group_kernels.hpp)
+template <int NP>
+int group_stage_go(ellhip_space* s, long long i, int g) {
+    const unsigned nb = (unsigned)((s->n + 127) / 128);
+    const double* grads = qgrad(s, i);
+    {
+        ProfScope ps(s, CLS_SYMV_REDUCE);
+        hipLaunchKernelGGL(k_group_reduce<NP>, dim3(nb, (unsigned)g), dim3(256), 0, s->stream, s->n, (long long)s->symv_seg,
+                           (const double*)s->d_rowpart_m, (const double*)s->d_colpart_m, (long long)rowpart_elems(s),
+                           (long long)colpart_elems(s), s->d_grpY, grads, s->n, (const double*)s->d_pend, s->d_gpart,
+                           (const DevState*)s->d_st);
+        HIPCHK(hipGetLastError());
+    }
+    ProfScope ps(s, CLS_SCALAR);
+    hipLaunchKernelGGL(k_group_gram, dim3(nb), dim3(256), 0, s->stream, s->n, g, (const double*)s->d_grpY, grads, s->n,
+                       s->d_cpart, (const DevState*)s->d_st);
+    hipLaunchKernelGGL(k_group_sums<NP>, dim3((unsigned)g + 1), dim3(256), 0, s->stream, g, (int)nb, (const double*)s->d_gpart,
+                       (const double*)s->d_cpart, s->d_gsums, (const DevState*)s->d_st);
+    hipLaunchKernelGGL(k_group_scalar<NP>, dim3(1), dim3(64), 0, s->stream, g, (const double*)s->d_gsums, s->d_cpend, s->d_st,
+                       EllCalcDev::make(s->n, s->use_parallel_cut), (const CutParams*)(s->d_qparams + i), s->npend,
+                       s->d_qstatus + i, s->d_qtsq + i, s->d_gout);
+    hipLaunchKernelGGL(k_group_apply<NP>, dim3((unsigned)((s->n + 255) / 256)), dim3(256), 0, s->stream, s->n, g,
+                       (const double*)s->d_grpY, s->d_pend, s->d_xc, s->npend, (const GroupOut*)s->d_gout);
+    HIPCHK(hipGetLastError());
     return 0;
 }
 
@@ -1304,17 +1351,26 @@ int queue_run_multi(ellhip_space* s, long long first, long long count) {
     int rc = multi_setup(s);
     if (rc) return rc;
     const long long end = first + count;
+    // Inside this run the group stage may let more updates pile up than the handle's depth (its kernels are sized for
+    // MAXPEND = 48; the per-cut kernels of every other path for the depth): half as many apply passes.  Whatever leaves
+    // this function has fewer recorded than the depth again.
+    const bool deep_ok = multi_mfma(s) && s->defer == 24 && s->apply_lower && s->queue_depth > s->defer;
+    const int qdepth = deep_ok ? s->queue_depth : s->defer;
     long long i = first;
     while (i < end) {
         long long g = 1;
         if (!(s->primed && s->primed_qindex == i)) {
             rc = ensure_committed(s);
             if (rc) return rc;
-            const long long room = (long long)s->defer - s->npend;  // cuts that can still be recorded before the apply pass
+            const long long room = (long long)qdepth - s->npend;  // cuts that can still be recorded before the apply pass
             const long long cap = multi_mfma(s) ? MULTI_MAX : MULTI_VALU_MAX;
             g = std::min<long long>(std::min<long long>(s->lookahead, cap), std::min(end - i, room));
         }
         if (g <= 1) {  // a cut primed earlier, the last one before an apply pass, the last one of the run
+            if (s->npend >= s->defer) {  // (the per-cut kernels hold `depth` recorded updates)
+                rc = flush_pending(s, nullptr, nullptr);
+                if (rc) return rc;
+            }
             rc = queue_prime_impl(s, i);
             if (!rc) rc = queue_cut_impl(s, i);
             if (!rc) rc = queue_commit_impl(s, i, -1);
@@ -1337,6 +1393,25 @@ int queue_run_multi(ellhip_space* s, long long first, long long count) {
             }
             HIPCHK(hipGetLastError());
         }
+        if (multi_mfma(s)) {
+            // the whole group's scalar stage: the cuts' omegas and coefficients from dot products that exist when the group
+            // starts, then the vectors in one elementwise pass
+            drop_prime(s);
+            s->dots_np = 0;
+            rc = qdepth == 48 ? group_stage_go<48>(s, i, (int)g)
+               : s->defer == 24 ? group_stage_go<24>(s, i, (int)g)
+               : s->defer == 16 ? group_stage_go<16>(s, i, (int)g) : group_stage_go<8>(s, i, (int)g);
+            if (rc) return rc;
+            s->npend += (int)g;       // (optimistic, as after every queue cut: ellhip_queue_results settles it after a halt)
+            s->scalars_stale = true;
+            s->shrink_pending = false;
+            if (s->npend >= qdepth) {
+                rc = flush_pending(s, nullptr, nullptr);
+                if (rc) return rc;
+            }
+            i += g;
+            continue;
+        }
         for (long long l = 0; l < g; ++l) {
             s->part_set = 2 + (int)l;
             s->dots_np = 0;
@@ -1353,6 +1428,7 @@ int queue_run_multi(ellhip_space* s, long long first, long long count) {
         }
         i += g;
     }
+    if (s->npend >= s->defer) return flush_pending(s, nullptr, nullptr);
     return 0;
 }
 
@@ -1511,6 +1587,11 @@ void ellhip_destroy(ellhip_space* s) {
     if (s->d_rowpart_m) (void)hipFree(s->d_rowpart_m);
     if (s->d_colpart_m) (void)hipFree(s->d_colpart_m);
     if (s->d_gT) (void)hipFree(s->d_gT);
+    if (s->d_grpY) (void)hipFree(s->d_grpY);
+    if (s->d_gpart) (void)hipFree(s->d_gpart);
+    if (s->d_cpart) (void)hipFree(s->d_cpart);
+    if (s->d_gout) (void)hipFree(s->d_gout);
+    if (s->d_gsums) (void)hipFree(s->d_gsums);
     if (s->ev_symv) (void)hipEventDestroy(s->ev_symv);
     for (int k = 0; k < 2; ++k)
         if (s->ev_red[k]) (void)hipEventDestroy(s->ev_red[k]);
@@ -1558,6 +1639,7 @@ int ellhip_clone(const ellhip_space* src_c, ellhip_space** out) {
     s->fuse_dots = src->fuse_dots;
     s->overlap = src->overlap;
     s->lookahead = src->lookahead;
+    s->queue_depth = src->queue_depth;
     s->resident = src->resident;
     s->shard_symmetric = src->shard_symmetric;
     s->upper_stale = src->upper_stale;
@@ -1852,6 +1934,7 @@ int option_ok(int key, long long v) {
         case ELLHIP_OPT_FUSE_DOTS: case ELLHIP_OPT_RESIDENT: case ELLHIP_OPT_OVERLAP:
             return (v == 0 || v == 1) ? 0 : fail(ELLHIP_E_INVALID, "option value must be 0 or 1");
         case ELLHIP_OPT_LOOKAHEAD: return (v >= 1 && v <= 16) ? 0 : fail(ELLHIP_E_INVALID, "ELLHIP_OPT_LOOKAHEAD: 1 .. 16");
+        case ELLHIP_OPT_QUEUE_DEPTH: return (v == 0 || v == 48) ? 0 : fail(ELLHIP_E_INVALID, "ELLHIP_OPT_QUEUE_DEPTH: 0 or 48");
         case ELLHIP_OPT_SYMV_MIN_N: return v >= 512 ? 0 : fail(ELLHIP_E_INVALID, "ELLHIP_OPT_SYMV_MIN_N must be >= 512");
         case ELLHIP_OPT_STABLE_SOLVE: case ELLHIP_OPT_STABLE_FACTOR:
             return (v >= 0 && v <= 2) ? 0 : fail(ELLHIP_E_INVALID, "option value must be 0, 1 or 2");
@@ -1878,6 +1961,7 @@ int ellhip_set_default_option(int key, int64_t value) {
         case ELLHIP_OPT_RESIDENT: g_defaults.resident = (int)value; break;
         case ELLHIP_OPT_OVERLAP: g_defaults.overlap = (int)value; break;
         case ELLHIP_OPT_LOOKAHEAD: g_defaults.lookahead = (int)value; break;
+        case ELLHIP_OPT_QUEUE_DEPTH: g_defaults.queue_depth = (int)value; break;
         case ELLHIP_OPT_STABLE_SOLVE: g_defaults.stable_solve = (int)value; break;
         case ELLHIP_OPT_STABLE_FACTOR: g_defaults.stable_factor = (int)value; break;
         case ELLHIP_OPT_PAD: g_defaults.pad = (int)value; break;
@@ -1900,6 +1984,7 @@ int ellhip_default_option(int key, int64_t* value) {
         case ELLHIP_OPT_RESIDENT: *value = g_defaults.resident; break;
         case ELLHIP_OPT_OVERLAP: *value = g_defaults.overlap; break;
         case ELLHIP_OPT_LOOKAHEAD: *value = g_defaults.lookahead; break;
+        case ELLHIP_OPT_QUEUE_DEPTH: *value = g_defaults.queue_depth; break;
         case ELLHIP_OPT_STABLE_SOLVE: *value = g_defaults.stable_solve; break;
         case ELLHIP_OPT_STABLE_FACTOR: *value = g_defaults.stable_factor; break;
         case ELLHIP_OPT_PAD: *value = g_defaults.pad; break;
@@ -1919,12 +2004,13 @@ int ellhip_set_option(ellhip_space* s, int key, int64_t value) {
     const bool ell = s->variant == ELLHIP_SPACE_ELL;
     switch (key) {
         case ELLHIP_OPT_SYMV: case ELLHIP_OPT_SYMV_MIN_N: case ELLHIP_OPT_APPLY_LOWER: case ELLHIP_OPT_APPLY_KERNEL:
-        case ELLHIP_OPT_RESIDENT: case ELLHIP_OPT_OVERLAP: case ELLHIP_OPT_LOOKAHEAD:
+        case ELLHIP_OPT_RESIDENT: case ELLHIP_OPT_OVERLAP: case ELLHIP_OPT_LOOKAHEAD: case ELLHIP_OPT_QUEUE_DEPTH:
             if (!ell) return fail(ELLHIP_E_INVALID, "this option exists on Ell only");
             // (chosen per queue run: nothing recorded depends on them)
             if (key == ELLHIP_OPT_RESIDENT) s->resident = (int)value;
             else if (key == ELLHIP_OPT_OVERLAP) s->overlap = (int)value;
-            else s->lookahead = (int)value;
+            else if (key == ELLHIP_OPT_LOOKAHEAD) s->lookahead = (int)value;
+            else s->queue_depth = (int)value;
             return 0;
         case ELLHIP_OPT_FUSE_DOTS: {
             if (!ell) return fail(ELLHIP_E_INVALID, "this option exists on Ell only");
@@ -1969,6 +2055,7 @@ int ellhip_get_option(const ellhip_space* s, int key, int64_t* value) {
         case ELLHIP_OPT_RESIDENT: *value = s->resident; break;
         case ELLHIP_OPT_OVERLAP: *value = s->overlap; break;
         case ELLHIP_OPT_LOOKAHEAD: *value = s->lookahead; break;
+        case ELLHIP_OPT_QUEUE_DEPTH: *value = s->queue_depth; break;
         case ELLHIP_OPT_STABLE_SOLVE: *value = s->stable_solve; break;
         case ELLHIP_OPT_STABLE_FACTOR: *value = s->stable_factor; break;
         case ELLHIP_OPT_PAD: *value = s->ld - s->n; break;

@@ -1,0 +1,256 @@
+// group_kernels.hpp -- the scalar stage of a GROUP of queued cuts whose products y_l = Q_base g_l came out of one pass
+// (k_symm_mfma, ELLHIP_OPT_LOOKAHEAD > 3): three n-parallel launches and one small serial one per group instead of a
+// reduction and a scalar stage per cut.
+//
+// What Ell::update_core needs per cut (src/ell.rs:97-137 on the recorded schedule, ell_kernels.hpp "Deferred rank-1
+// updates"):   gt_l = y_l - sum_j (c_j d_jl) v_j,   omega_l = g_l.y_l - sum_j c_j d_jl^2,   d_jl = v_j . g_l
+// over the vectors v_j recorded before cut l -- including the ones the group itself records, v_m = gt_m (m < l), which is
+// what chains the cuts: cut l's dot products wait for cut l - 1's vector.  But those dot products are linear in what is
+// known up front:
+//     v_m . g_l = y_m . g_l - sum_{j before m} (c_j d_jm) (v_j . g_l)
+// so with   A_l  = g_l . y_l,   B_jl = v_j . g_l (j recorded before the group),   C_ml = y_m . g_l (m < l)
+// (all n-length dot products of vectors that exist when the group starts: k_group_reduce, k_group_gram) the whole chain
+// of omegas, EllCalc coefficients and correction factors is O(G^2 NP) scalar work (k_group_scalar, one workgroup), and
+// the vectors follow in one elementwise pass (k_group_apply).  The matrix-core products differ from the vector-ALU
+// schedules by a few ulp already; this stage adds the rounding of the recurrence above (same size: every term is a dot
+// product of the same vectors), far inside the 1e-10 contract and not bit-identical to the per-cut stage.
+#pragma once
+
+#include "ell_kernels.hpp"
+
+namespace ellhip {
+
+constexpr int GRP_MAX = 16;  // cuts per group (= SMM_NV)
+
+struct GroupOut {
+    double cd[GRP_MAX][MAXPEND];  // cd[l][j] = c_j d_jl: the correction factors of cut l (0 for empty slots)
+    double roo[GRP_MAX];          // rho / omega of cut l (src/ell.rs:112)
+    int nok;                      // cuts of the group that succeeded (all of them unless the queue halted inside)
+};
+
+// y_l for every cut of the group (grid.y = l) + the dot products with what was recorded before the group: the body of
+// k_symv_reduce<NP>, G of them in one launch.  gpart[l][b][0] = slice of g_l.y_l, [1 + j] = slice of v_j.g_l.
+template <int NP>
+__global__ __launch_bounds__(256) void k_group_reduce(long long n, long long seg, const double* __restrict__ rowpart,
+                                                      const double* __restrict__ colpart, long long rowpart_stride,
+                                                      long long colpart_stride, double* __restrict__ Y,
+                                                      const double* __restrict__ g, long long g_stride,
+                                                      const double* __restrict__ pend, double* __restrict__ gpart,
+                                                      const DevState* __restrict__ st) {
+    __shared__ double2_t part[4][64];
+    if (st->halted) return;
+    const long long l = blockIdx.y, nb = gridDim.x;
+    symv_reduce_block<NP, false>((long long)blockIdx.x, n, 0, n, seg, rowpart + l * rowpart_stride, colpart + l * colpart_stride,
+                                 Y + l * n, g + l * g_stride, pend, gpart + l * nb * (NP + 1), part);
+}
+
+// cpart[b][m][l] = slice (128 columns) of y_m . g_l, m < l
+__global__ __launch_bounds__(256) void k_group_gram(long long n, int G, const double* __restrict__ Y,
+                                                    const double* __restrict__ g, long long g_stride,
+                                                    double* __restrict__ cpart, const DevState* __restrict__ st) {
+    __shared__ double sy[GRP_MAX][128];
+    __shared__ double sg[GRP_MAX][129];  // (odd pitch: the threads of one m read 16 different l at the same column)
+    if (st->halted) return;
+    const int tid = threadIdx.x;
+    const long long base = (long long)blockIdx.x * 128;
+    for (int idx = tid; idx < G * 128; idx += 256) {
+        const int l = idx >> 7, c = idx & 127;
+        const long long i = base + c;
+        sy[l][c] = i < n ? Y[(long long)l * n + i] : 0.0;
+        sg[l][c] = i < n ? g[(long long)l * g_stride + i] : 0.0;
+    }
+    __syncthreads();
+    for (int t = tid; t < G * G; t += 256) {
+        const int m = t / G, l = t - m * G;
+        double s = 0.0;
+        if (m < l) {
+#pragma unroll 8
+            for (int c = 0; c < 128; ++c) s += sy[m][c] * sg[l][c];
+        }
+        cpart[(long long)blockIdx.x * (GRP_MAX * GRP_MAX) + m * GRP_MAX + l] = s;
+    }
+}
+
+// Column sums of the slices: workgroup l < G adds gpart[l][0 .. nb)[0 .. NP] (contiguous: coalesced), workgroup G adds
+// cpart[0 .. nb)[m][l'].  sums: [G][NP + 1] then [GRP_MAX][GRP_MAX].  Thread (c, q) adds rows q, q + R, ... of column c in
+// ascending order, the R partial sums are combined in index order.
+template <int NP>
+__global__ __launch_bounds__(256) void k_group_sums(int G, int nb, const double* __restrict__ gpart,
+                                                    const double* __restrict__ cpart, double* __restrict__ sums,
+                                                    const DevState* __restrict__ st) {
+    __shared__ double red[256];
+    if (st->halted) return;
+    const int tid = threadIdx.x;
+    const int l = blockIdx.x;
+    if (l < G) {
+        constexpr int W = NP + 1;
+        constexpr int R = 256 / W;  // row classes (NP = 48: 5, 24: 10, 16: 15, 8: 28)
+        const double* p = gpart + (long long)l * nb * W;
+        const int c = tid % W, q = tid / W;
+        double a = 0.0;
+        if (q < R)
+            for (int b = q; b < nb; b += R) a += p[(long long)b * W + c];
+        red[tid] = a;
+        __syncthreads();
+        if (tid < W) {
+            double sum = red[tid];
+            for (int r = 1; r < R; ++r) sum += red[r * W + tid];
+            sums[l * W + tid] = sum;
+        }
+    } else {  // the Gram slices: 256 columns (m, l'), one per thread, rows in ascending order, four running sums
+        const double* p = cpart + tid;
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+        int b = 0;
+        for (; b + 3 < nb; b += 4) {
+            const double v0 = p[(long long)b * 256], v1 = p[(long long)(b + 1) * 256];
+            const double v2 = p[(long long)(b + 2) * 256], v3 = p[(long long)(b + 3) * 256];
+            a0 += v0, a1 += v1, a2 += v2, a3 += v3;
+        }
+        for (; b < nb; ++b) a0 += p[(long long)b * 256];
+        sums[G * (NP + 1) + tid] = (a0 + a1) + (a2 + a3);
+    }
+}
+
+// One wave: cut by cut omega, EllCalc (src/ell_calc.rs:627-931 through EllCalcDev::dispatch), the correction factors and
+// the dot products of the vector the cut records with the gradients still to come.  Lane j looks after recorded slot j
+// (NP + GRP_MAX <= 64).  Queue semantics as k_scalar_apply_def: the first cut that is not Success halts the queue,
+// every later one reports ELLHIP_UNKNOWN (src/cutting_plane.rs:222,308).
+template <int NP>
+__global__ __launch_bounds__(64) void k_group_scalar(int G, const double* __restrict__ sums, double* __restrict__ cpend,
+                                                     DevState* __restrict__ st, EllCalcDev calc,
+                                                     const CutParams* __restrict__ cp_dev, int slot0,
+                                                     int* __restrict__ q_status, double* __restrict__ q_tsq,
+                                                     GroupOut* __restrict__ out) {
+    static_assert(NP + GRP_MAX <= 64, "one lane per recorded slot");
+    __shared__ double A[GRP_MAX];
+    __shared__ double B[NP][GRP_MAX];
+    __shared__ double C[GRP_MAX][GRP_MAX];
+    __shared__ double D[GRP_MAX][GRP_MAX];
+    __shared__ double bc[4];  // roo, cnew, kappa | status in s_status
+    __shared__ int s_status, s_halt;
+    const int lane = threadIdx.x;
+    const bool was_halted = st->halted != 0;
+    if (!was_halted) {
+        for (int k = lane; k < G * (NP + 1); k += 64) {
+            const int l = k / (NP + 1), c = k - l * (NP + 1);
+            if (c == 0) A[l] = sums[k];
+            else B[c - 1][l] = sums[k];
+        }
+        for (int k = lane; k < GRP_MAX * GRP_MAX; k += 64) C[k / GRP_MAX][k % GRP_MAX] = sums[G * (NP + 1) + k];
+    }
+    double cc = (lane < NP && !was_halted) ? cpend[lane] : 0.0;  // c_j of this lane's slot
+    if (lane == 0) {
+        s_halt = was_halted ? 1 : 0;
+        s_status = ST_SUCCESS;
+    }
+    __syncthreads();
+    double kappa = st->kappa;
+    int nok = 0;
+    for (int l = 0; l < G; ++l) {
+        const int slot = slot0 + l;  // every earlier cut of the group succeeded, or the queue has halted
+        if (s_halt) {
+            if (lane == 0) {
+                q_status[l] = ST_UNKNOWN;
+                q_tsq[l] = st->tsq;
+            }
+            continue;  // (s_halt is not written again: uniform)
+        }
+        // d_jl of this lane's slot, its correction factor, and omega = g.y - sum_j c_j d_jl^2
+        const double dj = lane < slot0 ? B[lane < NP ? lane : 0][l] : (lane < slot ? D[lane - slot0][l] : 0.0);
+        const double cd = (lane < slot) ? cc * dj : 0.0;
+        if (lane < MAXPEND) out->cd[l][lane] = cd;
+        const double omega = A[l] - wave_allreduce_sum(cd * dj);
+        if (lane == 0) {
+            const double tsq = kappa * omega;  // src/ell.rs:105
+            Coef cf;
+            const CutParams cp = cp_dev[l];
+            const int status = calc.dispatch(cp.kind, cp.b0, cp.has_b1, cp.b1, tsq, cf);  // :106
+            st->tsq = tsq;
+            st->omega = omega;
+            st->status = status;
+            if (status == ST_SUCCESS) {
+                const double roo = cf.rho / omega;     // :112
+                const double cnew = cf.sigma / omega;  // :117
+                out->roo[l] = roo;
+                st->rho_over_omega = roo;
+                st->ratio = cnew;
+                const double knew = kappa * cf.delta;  // :130
+                st->kappa = knew;
+                st->scale = 1.0;
+                st->apply = 1;
+                cpend[slot] = cnew;
+                st->npend = slot + 1;
+                bc[1] = cnew;
+                bc[2] = knew;
+            } else {
+                st->apply = 0;  // :107-109
+            }
+            queue_bookkeeping(st, status, tsq, 1);
+            q_status[l] = status;
+            q_tsq[l] = tsq;
+            s_status = status;
+            s_halt = st->halted;
+        }
+        __syncthreads();
+        if (s_status == ST_SUCCESS) {
+            nok = l + 1;
+            kappa = bc[2];
+            if (lane == slot) cc = bc[1];
+            // v_l . g_t = y_l . g_t - sum_j cd_j (v_j . g_t) for the cuts t still to come: one wave sum per t
+            for (int t = l + 1; t < G; ++t) {
+                const double djt = lane < slot0 ? B[lane < NP ? lane : 0][t] : (lane < slot ? D[lane - slot0][t] : 0.0);
+                const double sum = wave_allreduce_sum(cd * djt);
+                if (lane == 0) D[l][t] = C[l][t] - sum;
+            }
+        }
+        __syncthreads();
+    }
+    if (lane == 0) out->nok = nok;
+}
+
+// The vectors: v_m = y_m - sum_j cd[m][j] v_j in slot order (the recorded ones first, then the group's own), recorded
+// into slot slot0 + m, and xc -= (rho / omega)_m v_m (src/ell.rs:113-115), element by element.
+template <int NP>
+__global__ __launch_bounds__(256) void k_group_apply(long long n, int G, const double* __restrict__ Y,
+                                                     double* __restrict__ pend, double* __restrict__ xc, int slot0,
+                                                     const GroupOut* __restrict__ out) {
+    __shared__ double s_cd[GRP_MAX][MAXPEND];
+    __shared__ double s_roo[GRP_MAX];
+    const int tid = threadIdx.x;
+    const int nok = out->nok;
+    if (nok == 0) return;
+    for (int k = tid; k < GRP_MAX * MAXPEND; k += 256) s_cd[k / MAXPEND][k % MAXPEND] = out->cd[k / MAXPEND][k % MAXPEND];
+    if (tid < GRP_MAX) s_roo[tid] = out->roo[tid];
+    __syncthreads();
+    const long long i = (long long)blockIdx.x * 256 + tid;
+    if (i >= n) return;
+    double pold[NP];
+#pragma unroll
+    for (int j = 0; j < NP; ++j) pold[j] = (j < slot0) ? pend[(long long)j * n + i] : 0.0;
+    double ym[GRP_MAX];
+#pragma unroll
+    for (int m = 0; m < GRP_MAX; ++m) ym[m] = (m < nok) ? Y[(long long)m * n + i] : 0.0;
+    double x = xc[i];
+    double vnew[GRP_MAX];
+#pragma unroll
+    for (int m = 0; m < GRP_MAX; ++m) {
+        if (m < nok) {
+            double v = ym[m];
+#pragma unroll
+            for (int j = 0; j < NP; ++j)
+                if (j < slot0) v = v - s_cd[m][j] * pold[j];
+#pragma unroll
+            for (int mm = 0; mm < GRP_MAX; ++mm)
+                if (mm < m) v = v - s_cd[m][slot0 + mm] * vnew[mm];
+            vnew[m] = v;
+            pend[(long long)(slot0 + m) * n + i] = v;
+            x = x - s_roo[m] * v;
+        } else {
+            vnew[m] = 0.0;
+        }
+    }
+    xc[i] = x;
+    (void)G;
+}
+
+}  // namespace ellhip

@@ -228,7 +228,7 @@ int ellhip_set_shard_symmetric(ellhip_space *s, int flag);
  *                                                    cut's GEMV (it reads Q_base, which the cut being taken does not change) is
  *                                                    issued on a second stream beside this cut's reduction + scalar stage;
  *                                                    bit-identical to 0 (same kernels, operands and summation order)
- *   ELLHIP_OPT_LOOKAHEAD         1 .. 16    12       Ell, ellhip_queue_run_fused on the lower-triangle schedule: the GEMVs of up to
+ *   ELLHIP_OPT_LOOKAHEAD         1 .. 16    16       Ell, ellhip_queue_run_fused on the lower-triangle schedule: the GEMVs of up to
  *                                                    this many consecutive QUEUED cuts are formed in one pass over Q_base
  *                                                    (they all refer to the same matrix until the next apply pass):
  *                                                    (4 / L) n^2 bytes per update instead of 4 n^2.  L <= 3: vector-ALU
@@ -237,6 +237,11 @@ int ellhip_set_shard_symmetric(ellhip_space *s, int flag);
  *                                                    association; inside the 1e-10 contract).  Only a queue knows the
  *                                                    next gradients: ellhip_update and the prime / cut / commit calls are
  *                                                    unaffected
+ *   ELLHIP_OPT_QUEUE_DEPTH       0 / 48     48       Ell, depth 24, LOOKAHEAD > 3: inside one ellhip_queue_run_fused call the
+ *                                                    recorded updates may pile up to 48 before an apply pass (the group
+ *                                                    stage is sized for it): half as many apply passes; on return fewer
+ *                                                    than the handle's depth are left, as everywhere else.  0: never
+ *                                                    more than the handle's depth
  *   ELLHIP_OPT_STABLE_SOLVE      0 / 1 / 2  2        EllStable: 0 = one launch per 128-block (no in-launch waits),
  *                                                    1 = persistent solves, 2 = persistent + helper workgroups
  *   ELLHIP_OPT_STABLE_FACTOR     0 / 1 / 2  2        EllStable factor update: 0 = tile kernel reading the scratch
@@ -266,6 +271,7 @@ int ellhip_set_shard_symmetric(ellhip_space *s, int flag);
 #define ELLHIP_OPT_RESIDENT 13
 #define ELLHIP_OPT_OVERLAP 14
 #define ELLHIP_OPT_LOOKAHEAD 15
+#define ELLHIP_OPT_QUEUE_DEPTH 16
 int ellhip_set_option(ellhip_space *s, int key, int64_t value);
 int ellhip_get_option(const ellhip_space *s, int key, int64_t *value);
 int ellhip_set_default_option(int key, int64_t value);

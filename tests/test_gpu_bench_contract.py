@@ -43,16 +43,16 @@ def test_headline_workload_contract():
     assert d["config"]["workload"] == "n16384-parallel" and d["scaling"] == "strong"
     assert abs(d["value"] - 1e3 / d["ms_per_step"]) < 1e-6 * d["value"]
     r = d["roofline"]
-    assert r["kernel"] == "k_symm_mfma" and r["traffic"] and 0.3 < r["frac"] < 1.0 and d["config"]["lookahead"] == 12
+    assert r["kernel"] == "k_symm_mfma" and r["traffic"] and 0.3 < r["frac"] < 1.0 and d["config"]["lookahead"] == 16 and d["config"]["queue_depth"] == 48
     assert abs(r["alg_bytes_per_launch"] - 4.0 * 16384 ** 2) < 1.0     # lower triangle: 4 n^2 bytes
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] == 1 and c["unit"] == "updates/s" and c["value"] > 0 and c["sample"]
     assert c["all_cores"]["threads"] >= 1 and "NOT the reference" in c["all_cores"]["note"]
     assert d["host_call_path"]["updates_per_s"] > 0
     assert r["traffic_measured_in_this_run"] is False and r["per_kernel"]["symv"]["avg_ms"] > 0
-    # 16 timed steps at depth 24, lookahead 12: two passes over Q (groups of 12 and 4) and ONE apply pass (the flush at the
-    # end): (2 * 4 n^2 + 1 * 8 n^2) / 16 = 1.0 n^2 per update
-    assert abs(r["whole_update"]["alg_bytes_per_gpu"] - 1.0 * 16384 ** 2) < 1.0
+    # 16 timed steps, lookahead 16: ONE pass over Q (a group of 16) and ONE apply pass (the flush at the end):
+    # (1 * 4 n^2 + 1 * 8 n^2) / 16 = 0.75 n^2 per update
+    assert abs(r["whole_update"]["alg_bytes_per_gpu"] - 0.75 * 16384 ** 2) < 1.0
     # the default invocation carries BASELINE.json's other configurations in the same line
     oc = {o["workload"]: o for o in d["other_configs"]}
     assert set(oc) == {"n4096-deep", "n32768-deep", "n16384-ellstable"}
@@ -61,8 +61,8 @@ def test_headline_workload_contract():
         ro = o["roofline"]
         assert 0.0 < ro["frac"] < 1.0 and ro["kernel"] and 0.0 < ro["whole_update"]["frac"] < 1.0
     assert oc["n32768-deep"]["defer_depth"] == 24 and oc["n4096-deep"]["defer_depth"] == 8
-    # 64 steps at depth 24, lookahead 12: groups 12 12 | 12 12 | 12 4 and three apply passes, (6 * 4 + 3 * 8) / 64 = 0.75
-    assert abs(oc["n32768-deep"]["roofline"]["whole_update"]["alg_bytes"] - 0.75 * 32768 ** 2) < 1.0
+    # 64 steps, lookahead 16, up to 48 recorded inside a run: groups 16 16 16 | 16 and two apply passes, (4 * 4 + 2 * 8) / 64
+    assert abs(oc["n32768-deep"]["roofline"]["whole_update"]["alg_bytes"] - 0.5 * 32768 ** 2) < 1.0
 
 
 @pytest.mark.parametrize("workload,args", [("n4096-deep", ("--steps", "40", "--warmup", "8", "--compare-steps", "0")),

@@ -1,9 +1,11 @@
 """GPU: pipelined queue runs on the lower-triangle schedule that use what a QUEUE knows -- the next gradients.
 The GEMV y = Q_base g of a queued cut reads a matrix the cuts before it do not change until the next apply pass (recorded
 schedule: src/ell.rs:117-128 is deferred), so
-  * ELLHIP_OPT_LOOKAHEAD = L (default 12; csrc/ellhip_capi.hip queue_run_multi): the products of L consecutive queued cuts
+  * ELLHIP_OPT_LOOKAHEAD = L (default 16; csrc/ellhip_capi.hip queue_run_multi): the products of L consecutive queued cuts
     are formed in ONE pass over the lower triangle -- L <= 3 on the vector ALU (k_symv_multi, per vector k_symv's
-    arithmetic), L > 3 on the FP64 matrix cores (k_symm_mfma, n a multiple of 64; own association: a few ulp);
+    arithmetic), L > 3 on the FP64 matrix cores (k_symm_mfma, n a multiple of 64; own association: a few ulp) with the
+    group's scalar stage in four launches (group_kernels.hpp) and, at depth 24, up to ELLHIP_OPT_QUEUE_DEPTH = 48
+    recorded updates per apply pass inside a run;
   * ELLHIP_OPT_OVERLAP (default 1, used where LOOKAHEAD is 1; queue_run_overlapped): the next cut's GEMV is issued on a
     second stream beside this cut's reduction + scalar stage.
 The vector-ALU forms are bit-identical to the serial order (LOOKAHEAD 1, OVERLAP 0), the matrix-core form agrees with it to
@@ -22,7 +24,8 @@ def _beta(b0, b1, i):
     return (b0[i], None if np.isnan(b1[i]) else b1[i])
 
 
-MODES = [(0, 1), (1, 1), (0, 2), (1, 3), (0, 4), (1, 12), (0, 16)]   # (OVERLAP, LOOKAHEAD); the first is the serial reference
+# (OVERLAP, LOOKAHEAD, QUEUE_DEPTH); the first is the serial reference
+MODES = [(0, 1, 0), (1, 1, 48), (0, 2, 0), (1, 3, 48), (0, 4, 0), (1, 12, 0), (0, 12, 48), (0, 16, 48)]
 EXACT = 4                                                            # the first four: bit-identical to one another
 RTOL = 1e-12                                                         # the matrix-core groups against them
 
@@ -39,6 +42,7 @@ def _drive(gpu, n, depth, mode, kinds, grads, b0, b1, pieces, direct=(), flush_a
     e.defer_depth = depth
     e.set_option(gpu.capi.OPT_OVERLAP, mode[0])
     e.set_option(gpu.capi.OPT_LOOKAHEAD, mode[1])
+    e.set_option(gpu.capi.OPT_QUEUE_DEPTH, mode[2])
     e.queue_upload(kinds, grads, b0, b1)
     for a, c in pieces:
         if a in direct:      # a synchronous update of cut a between two runs (the run then starts at a + 1)
@@ -107,13 +111,13 @@ def test_failing_cut_halts_the_overlapped_run(gpu, orc, depth):
 
 
 def test_overlapped_run_at_the_default_size_and_depth(gpu):
-    """n = 8192: the smallest size that takes the lower-triangle schedule (depth 24, groups of 12 on the matrix cores) by
+    """n = 8192: the smallest size that takes the lower-triangle schedule (depth 24, groups of 16 on the matrix cores) by
     itself; a clone taken between two runs continues serially and must stay equal to 1e-12."""
     from ellalgo_rs_amd import synth
     n, k = 8192, 60
     kinds, grads, b0, b1 = synth.parallel_cuts(n, k)
     e = gpu.Ell.new_with_scalar(1.0, np.zeros(n))
-    assert e.defer_depth == 24 and e.get_option(gpu.capi.OPT_OVERLAP) == 1 and e.get_option(gpu.capi.OPT_LOOKAHEAD) == 12
+    assert e.defer_depth == 24 and e.get_option(gpu.capi.OPT_OVERLAP) == 1 and e.get_option(gpu.capi.OPT_LOOKAHEAD) == 16
     e.profile_enable(True)
     e.queue_upload(kinds, grads, b0, b1)
     e.queue_run(0, 31, fused=True)
@@ -129,6 +133,6 @@ def test_overlapped_run_at_the_default_size_and_depth(gpu):
     assert _same(ts_e[31:], ts_c[31:], False) and _same(e.xc(), c.xc(), False) and _same([e.kappa], [c.kappa], False)
     assert _same(e.mq, c.mq, False)
     prof = e.profile_read()
-    # one reduction per cut, one pass over Q per group of up to twelve cuts (a run's end and an apply pass close a
-    # group early): (12, 12 | 7) + (12, 12 | 5)
-    assert prof["symv_reduce"][1] == 60 and prof["symv"][1] == 6
+    # one pass over Q and one batched reduction per group of up to sixteen cuts (a run's end closes a group early):
+    # (16, 15) + (16, 13); both runs end with more than 24 recorded and apply them before they return
+    assert prof["symv_reduce"][1] == 4 and prof["symv"][1] == 4 and prof["apply"][1] == 2
