@@ -477,6 +477,7 @@ def test_pipelined_nonsymmetric_input(gpu, orc):
 @pytest.mark.parametrize("n", [384, 8192])
 def test_queue_fused_is_bit_identical_to_queue(gpu, n):
     set_default("RESIDENT", 0)   # the STREAMED schedules are compared bit for bit here; the resident queue run sums Q g in its own shape (test_gpu_resident.py)
+    set_default("LOOKAHEAD", 3)  # ... and the matrix-core groups of the default lookahead theirs (test_gpu_overlap.py); up to 3 queued cuts per pass keep k_symv's arithmetic
     from ellalgo_rs_amd import synth
     k = 10
     kinds, grads, b0, b1 = synth.parallel_cuts(n, k)
