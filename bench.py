@@ -718,7 +718,7 @@ def main() -> None:
                 continue  # depth 16 exists on the lower-triangle schedule only
             if alt != (args.schedule, depth):
                 alts.append(alt)
-    total = W + K + P + 2 * C2 * len(alts) + H
+    total = W + K + 2 * P + 2 * C2 * len(alts) + H
     if sharded and n % world and not shard_sym:
         raise SystemExit(f"n={n} is not divisible by {world} ranks")
 
@@ -780,7 +780,7 @@ def main() -> None:
             space = ShardedEll.new_with_scalar(1.0, np.zeros(n), device=local_rank, symmetric=shard_sym,
                                               defer_depth=depth if shard_sym else 8)
             sharded_via = "torch.distributed"
-    nq = W + K + P + 2 * C2 * len(alts)
+    nq = W + K + 2 * P + 2 * C2 * len(alts)
     if variant == "ell" and not shard_sym:   # always explicit: a new unsharded handle may start at depth 16 by itself
         space.set_defer_depth(depth) if sharded else setattr(space, "defer_depth", depth)
     space.queue_upload(kinds[:nq], grads[:nq], b0[:nq], b1[:nq])
@@ -822,10 +822,23 @@ def main() -> None:
         space.synchronize()
         prof = space.profile_read()
         space.profile_enable(False)
+    # ... and the same kernels one at a time: with ELLHIP_OPT_OVERLAP the next group's products run on a second stream
+    # beside this group's stage, which stretches both (they share the CUs and HBM); the isolated durations say what each
+    # kernel does by itself.  `roofline.frac` stays the as-run figure (what rocprofv3 sees for this command).
+    prof_iso = None
+    if P > 0 and variant == "ell" and not sharded and fused and space.get_option(pkg.capi.OPT_OVERLAP) != 0 \
+            and space.get_option(pkg.capi.OPT_LOOKAHEAD) > 3 and n % 64 == 0:
+        space.set_option(pkg.capi.OPT_OVERLAP, 0)
+        space.profile_enable(True)
+        run(W + K + P, P)
+        space.synchronize()
+        prof_iso = space.profile_read()
+        space.profile_enable(False)
+        space.set_option(pkg.capi.OPT_OVERLAP, 1)
 
     # ---- the other schedules / depths on the same handle, for comparison (timed the same way + per-kernel events)
     others = []
-    pos = W + K + P
+    pos = W + K + 2 * P
     for (alt_sched, alt_depth) in alts:
         alt_fused = alt_sched == "pipelined"
         space.set_defer_depth(alt_depth) if sharded else setattr(space, "defer_depth", alt_depth)
@@ -976,6 +989,13 @@ def main() -> None:
         pass
     upd_gbps = bytes_update / (ms_per_step * 1e-3) / 1e9
     roofline["per_kernel"] = per_kernel
+    if prof_iso:
+        iso = kernel_table(prof_iso)
+        roofline["per_kernel_isolated"] = iso
+        if dom in iso and "GBps" in iso[dom]:
+            roofline["isolated"] = {"kernel": roofline.get("kernel"), "avg_launch_ms": iso[dom]["avg_ms"], "achieved": iso[dom]["GBps"],
+                                    "frac": iso[dom]["GBps"] / HBM_PEAK_GBS,
+                                    "note": "the same kernel with nothing running beside it (ELLHIP_OPT_OVERLAP = 0 for these launches only)"}
     roofline["whole_update"] = {"alg_bytes_per_gpu": bytes_update, "GBps_per_gpu": upd_gbps,
                                 "frac": upd_gbps / HBM_PEAK_GBS}
     if "achieved" not in roofline:

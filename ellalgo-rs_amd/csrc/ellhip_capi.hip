@@ -1191,19 +1191,27 @@ bool overlap_ok(const ellhip_space* s) {
     return s->overlap && s->variant == ELLHIP_SPACE_ELL && !s->sharded && symv_ok(s);
 }
 
-int overlap_setup(ellhip_space* s) {
+// the second stream and its events (overlapped queue runs: queue_run_overlapped, the group runs of queue_run_multi)
+int side_setup(ellhip_space* s) {
     if (s->symv_stream) return 0;
-    const size_t nsegs = (size_t)((s->n + s->symv_seg - 1) / s->symv_seg), nstrips = (size_t)((s->nrows + SYMV_H - 1) / SYMV_H);
-    HIPCHK(hipMalloc(&s->d_rowpart2, nsegs * (size_t)s->n * sizeof(double)));
-    HIPCHK(hipMalloc(&s->d_colpart2, nstrips * (size_t)s->n * sizeof(double)));
-    HIPCHK(hipMemsetAsync(s->d_rowpart2, 0, nsegs * (size_t)s->n * sizeof(double), s->stream));
-    HIPCHK(hipMemsetAsync(s->d_colpart2, 0, nstrips * (size_t)s->n * sizeof(double), s->stream));
     int least = 0, greatest = 0;
     HIPCHK(hipDeviceGetStreamPriorityRange(&least, &greatest));
     HIPCHK(hipEventCreateWithFlags(&s->ev_symv, hipEventDisableTiming));
     for (int k = 0; k < 2; ++k) HIPCHK(hipEventCreateWithFlags(&s->ev_red[k], hipEventDisableTiming));
     // lowest priority: the short reduction / scalar kernels of the main stream get the CU slots the GEMV's workgroups free
     HIPCHK(hipStreamCreateWithPriority(&s->symv_stream, hipStreamNonBlocking, least));
+    return 0;
+}
+
+int overlap_setup(ellhip_space* s) {
+    if (s->d_rowpart2) return 0;
+    int rc = side_setup(s);
+    if (rc) return rc;
+    const size_t nsegs = (size_t)((s->n + s->symv_seg - 1) / s->symv_seg), nstrips = (size_t)((s->nrows + SYMV_H - 1) / SYMV_H);
+    HIPCHK(hipMalloc(&s->d_rowpart2, nsegs * (size_t)s->n * sizeof(double)));
+    HIPCHK(hipMalloc(&s->d_colpart2, nstrips * (size_t)s->n * sizeof(double)));
+    HIPCHK(hipMemsetAsync(s->d_rowpart2, 0, nsegs * (size_t)s->n * sizeof(double), s->stream));
+    HIPCHK(hipMemsetAsync(s->d_colpart2, 0, nstrips * (size_t)s->n * sizeof(double), s->stream));
     return 0;
 }
 
@@ -1273,11 +1281,13 @@ bool multi_mfma(const ellhip_space* s) { return s->lookahead > MULTI_VALU_MAX &&
 
 int multi_setup(ellhip_space* s) {
     if (s->d_rowpart_m) return 0;
-    HIPCHK(hipMalloc(&s->d_rowpart_m, (size_t)MULTI_MAX * rowpart_elems(s) * sizeof(double)));
-    HIPCHK(hipMalloc(&s->d_colpart_m, (size_t)MULTI_MAX * colpart_elems(s) * sizeof(double)));
-    HIPCHK(hipMemsetAsync(s->d_rowpart_m, 0, (size_t)MULTI_MAX * rowpart_elems(s) * sizeof(double), s->stream));
-    HIPCHK(hipMemsetAsync(s->d_colpart_m, 0, (size_t)MULTI_MAX * colpart_elems(s) * sizeof(double), s->stream));
-    HIPCHK(hipMalloc(&s->d_gT, (size_t)s->n * SMM_NV * sizeof(double)));
+    // two halves of MULTI_MAX sets each (and of the packed gradients): the next group's products are formed on the second
+    // stream while this group's stage reads the other half
+    HIPCHK(hipMalloc(&s->d_rowpart_m, (size_t)2 * MULTI_MAX * rowpart_elems(s) * sizeof(double)));
+    HIPCHK(hipMalloc(&s->d_colpart_m, (size_t)2 * MULTI_MAX * colpart_elems(s) * sizeof(double)));
+    HIPCHK(hipMemsetAsync(s->d_rowpart_m, 0, (size_t)2 * MULTI_MAX * rowpart_elems(s) * sizeof(double), s->stream));
+    HIPCHK(hipMemsetAsync(s->d_colpart_m, 0, (size_t)2 * MULTI_MAX * colpart_elems(s) * sizeof(double), s->stream));
+    HIPCHK(hipMalloc(&s->d_gT, (size_t)2 * s->n * SMM_NV * sizeof(double)));
     const size_t nb = (size_t)((s->n + 127) / 128);
     HIPCHK(hipMalloc(&s->d_grpY, (size_t)GRP_MAX * (size_t)s->n * sizeof(double)));
     HIPCHK(hipMalloc(&s->d_gpart, (size_t)GRP_MAX * nb * (MAXPEND + 1) * sizeof(double)));
@@ -1290,17 +1300,19 @@ int multi_setup(ellhip_space* s) {
 
 // the scalar stage of a group whose products sit in the partial-sum sets 2 .. 2 + g - 1 (group_kernels.hpp)
 template <int NP>
-int group_stage_go(ellhip_space* s, long long i, int g) {
+int group_stage_go(ellhip_space* s, long long i, int g, int half, hipEvent_t sets_free) {
     const unsigned nb = (unsigned)((s->n + 127) / 128);
     const double* grads = qgrad(s, i);
     {
         ProfScope ps(s, CLS_SYMV_REDUCE);
         hipLaunchKernelGGL(k_group_reduce<NP>, dim3(nb, (unsigned)g), dim3(256), 0, s->stream, s->n, (long long)s->symv_seg,
-                           (const double*)s->d_rowpart_m, (const double*)s->d_colpart_m, (long long)rowpart_elems(s),
-                           (long long)colpart_elems(s), s->d_grpY, grads, s->n, (const double*)s->d_pend, s->d_gpart,
-                           (const DevState*)s->d_st);
+                           (const double*)(s->d_rowpart_m + (size_t)half * MULTI_MAX * rowpart_elems(s)),
+                           (const double*)(s->d_colpart_m + (size_t)half * MULTI_MAX * colpart_elems(s)),
+                           (long long)rowpart_elems(s), (long long)colpart_elems(s), s->d_grpY, grads, s->n,
+                           (const double*)s->d_pend, s->d_gpart, (const DevState*)s->d_st);
         HIPCHK(hipGetLastError());
     }
+    if (sets_free) HIPCHK(hipEventRecord(sets_free, s->stream));  // (the reduction is the only reader of the partial-sum sets)
     ProfScope ps(s, CLS_SCALAR);
     hipLaunchKernelGGL(k_group_gram, dim3(nb), dim3(256), 0, s->stream, s->n, g, (const double*)s->d_grpY, grads, s->n,
                        s->d_cpart, (const DevState*)s->d_st);
@@ -1316,19 +1328,28 @@ int group_stage_go(ellhip_space* s, long long i, int g) {
 }
 
 template <int SEG>
-void symm_mfma_go(ellhip_space* s, const double* g_dev, int lv) {
+void symm_mfma_go(ellhip_space* s, const double* g_dev, int lv, hipStream_t st, int half) {
     const unsigned nstrips = (unsigned)((s->nrows + SYMV_H - 1) / SYMV_H);
     const unsigned nsegs = (unsigned)((s->n + SEG - 1) / SEG);
-    hipLaunchKernelGGL(k_pack_grads, dim3((unsigned)((s->n * SMM_NV + 255) / 256)), dim3(256), 0, s->stream, g_dev, s->n, lv,
-                       s->n, s->d_gT);
+    double* gT = s->d_gT + (size_t)half * (size_t)s->n * SMM_NV;
+    double* rowp = s->d_rowpart_m + (size_t)half * MULTI_MAX * rowpart_elems(s);
+    double* colp = s->d_colpart_m + (size_t)half * MULTI_MAX * colpart_elems(s);
+    hipLaunchKernelGGL(k_pack_grads, dim3((unsigned)((s->n * SMM_NV + 255) / 256)), dim3(256), 0, st, g_dev, s->n, lv, s->n, gT);
     if (s->sh_gemv.nt != 0)
-        hipLaunchKernelGGL((k_symm_mfma<true, SEG>), dim3(nstrips, nsegs), dim3(256), 0, s->stream, (const double*)s->d_Q,
-                           s->ld, s->n, (const double*)s->d_gT, lv, s->d_rowpart_m, s->d_colpart_m,
-                           (long long)rowpart_elems(s), (long long)colpart_elems(s), (const DevState*)s->d_st);
+        hipLaunchKernelGGL((k_symm_mfma<true, SEG>), dim3(nstrips, nsegs), dim3(256), 0, st, (const double*)s->d_Q, s->ld, s->n,
+                           (const double*)gT, lv, rowp, colp, (long long)rowpart_elems(s), (long long)colpart_elems(s),
+                           (const DevState*)s->d_st);
     else
-        hipLaunchKernelGGL((k_symm_mfma<false, SEG>), dim3(nstrips, nsegs), dim3(256), 0, s->stream, (const double*)s->d_Q,
-                           s->ld, s->n, (const double*)s->d_gT, lv, s->d_rowpart_m, s->d_colpart_m,
-                           (long long)rowpart_elems(s), (long long)colpart_elems(s), (const DevState*)s->d_st);
+        hipLaunchKernelGGL((k_symm_mfma<false, SEG>), dim3(nstrips, nsegs), dim3(256), 0, st, (const double*)s->d_Q, s->ld, s->n,
+                           (const double*)gT, lv, rowp, colp, (long long)rowpart_elems(s), (long long)colpart_elems(s),
+                           (const DevState*)s->d_st);
+}
+int symm_go(ellhip_space* s, const double* g_dev, int lv, hipStream_t st, int half) {
+    ProfScope ps(s, CLS_SYMV, st);
+    if (s->symv_seg == SYMV_SEG) symm_mfma_go<SYMV_SEG>(s, g_dev, lv, st, half);
+    else symm_mfma_go<SYMV_SEG_SMALL>(s, g_dev, lv, st, half);
+    HIPCHK(hipGetLastError());
+    return 0;
 }
 
 // (the thread-to-element map, and with it the bits, follow the handle's segment width and are independent of the rows
@@ -1356,6 +1377,15 @@ int queue_run_multi(ellhip_space* s, long long first, long long count) {
     // this function has fewer recorded than the depth again.
     const bool deep_ok = multi_mfma(s) && s->defer == 24 && s->apply_lower && s->queue_depth > s->defer;
     const int qdepth = deep_ok ? s->queue_depth : s->defer;
+    const bool use_side = multi_mfma(s) && s->overlap != 0;
+    if (use_side) {
+        rc = side_setup(s);
+        if (rc) return rc;
+        // everything enqueued so far (apply passes, an earlier run's reductions) precedes the first products issued ahead
+        for (int k = 0; k < 2; ++k) HIPCHK(hipEventRecord(s->ev_red[k], s->stream));
+    }
+    int half = 0;                       // the half of the partial-sum sets the current group's products are in
+    long long ahead_i = -1, ahead_g = 0;  // the group whose products are in flight on the second stream
     long long i = first;
     while (i < end) {
         long long g = 1;
@@ -1378,29 +1408,36 @@ int queue_run_multi(ellhip_space* s, long long first, long long count) {
             i += 1;
             continue;
         }
-        {
-            ProfScope ps(s, CLS_SYMV);
-            const bool wide = s->symv_seg == SYMV_SEG;
-            if (multi_mfma(s)) {
-                if (wide) symm_mfma_go<SYMV_SEG>(s, qgrad(s, i), (int)g);
-                else symm_mfma_go<SYMV_SEG_SMALL>(s, qgrad(s, i), (int)g);
-            } else if (g == 2) {
-                if (wide) symv_multi_go<SYMV_SEG, 2>(s, qgrad(s, i));
-                else symv_multi_go<SYMV_SEG_SMALL, 2>(s, qgrad(s, i));
-            } else {
-                if (wide) symv_multi_go<SYMV_SEG, 3>(s, qgrad(s, i));
-                else symv_multi_go<SYMV_SEG_SMALL, 3>(s, qgrad(s, i));
-            }
-            HIPCHK(hipGetLastError());
-        }
         if (multi_mfma(s)) {
+            const long long cap = MULTI_MAX;
+            if (!(ahead_i == i && ahead_g == g)) {  // this group's products are not in flight yet
+                rc = symm_go(s, qgrad(s, i), (int)g, s->stream, half);
+                if (rc) return rc;
+            } else {
+                HIPCHK(hipStreamWaitEvent(s->stream, s->ev_symv, 0));
+            }
+            ahead_i = -1;
+            // the NEXT group's products on the second stream beside this group's stage -- when there is one inside this run
+            // and no apply pass comes first (it would read the matrix that pass writes)
+            const long long i2 = i + g, room2 = (long long)qdepth - (s->npend + g);
+            const long long g2 = (i2 < end && room2 > 0)
+                                     ? std::min<long long>(std::min<long long>(s->lookahead, cap), std::min(end - i2, room2)) : 0;
+            if (use_side && g2 >= 2) {
+                HIPCHK(hipStreamWaitEvent(s->symv_stream, s->ev_red[half ^ 1], 0));
+                rc = symm_go(s, qgrad(s, i2), (int)g2, s->symv_stream, half ^ 1);
+                if (rc) return rc;
+                HIPCHK(hipEventRecord(s->ev_symv, s->symv_stream));
+                ahead_i = i2;
+                ahead_g = g2;
+            }
             // the whole group's scalar stage: the cuts' omegas and coefficients from dot products that exist when the group
             // starts, then the vectors in one elementwise pass
             drop_prime(s);
             s->dots_np = 0;
-            rc = qdepth == 48 ? group_stage_go<48>(s, i, (int)g)
-               : s->defer == 24 ? group_stage_go<24>(s, i, (int)g)
-               : s->defer == 16 ? group_stage_go<16>(s, i, (int)g) : group_stage_go<8>(s, i, (int)g);
+            hipEvent_t ev = use_side ? s->ev_red[half] : nullptr;
+            rc = qdepth == 48 ? group_stage_go<48>(s, i, (int)g, half, ev)
+               : s->defer == 24 ? group_stage_go<24>(s, i, (int)g, half, ev)
+               : s->defer == 16 ? group_stage_go<16>(s, i, (int)g, half, ev) : group_stage_go<8>(s, i, (int)g, half, ev);
             if (rc) return rc;
             s->npend += (int)g;       // (optimistic, as after every queue cut: ellhip_queue_results settles it after a halt)
             s->scalars_stale = true;
@@ -1408,9 +1445,24 @@ int queue_run_multi(ellhip_space* s, long long first, long long count) {
             if (s->npend >= qdepth) {
                 rc = flush_pending(s, nullptr, nullptr);
                 if (rc) return rc;
+                if (use_side)
+                    for (int k = 0; k < 2; ++k) HIPCHK(hipEventRecord(s->ev_red[k], s->stream));
             }
+            if (ahead_i >= 0) half ^= 1;
             i += g;
             continue;
+        }
+        {
+            ProfScope ps(s, CLS_SYMV);
+            const bool wide = s->symv_seg == SYMV_SEG;
+            if (g == 2) {
+                if (wide) symv_multi_go<SYMV_SEG, 2>(s, qgrad(s, i));
+                else symv_multi_go<SYMV_SEG_SMALL, 2>(s, qgrad(s, i));
+            } else {
+                if (wide) symv_multi_go<SYMV_SEG, 3>(s, qgrad(s, i));
+                else symv_multi_go<SYMV_SEG_SMALL, 3>(s, qgrad(s, i));
+            }
+            HIPCHK(hipGetLastError());
         }
         for (long long l = 0; l < g; ++l) {
             s->part_set = 2 + (int)l;

@@ -43,13 +43,16 @@ def test_headline_workload_contract():
     assert d["config"]["workload"] == "n16384-parallel" and d["scaling"] == "strong"
     assert abs(d["value"] - 1e3 / d["ms_per_step"]) < 1e-6 * d["value"]
     r = d["roofline"]
-    assert r["kernel"] == "k_symm_mfma" and r["traffic"] and 0.3 < r["frac"] < 1.0 and d["config"]["lookahead"] == 16 and d["config"]["queue_depth"] == 48
+    assert r["kernel"] == "k_symm_mfma" and r["traffic"] and 0.2 < r["frac"] < 1.0 and d["config"]["lookahead"] == 16 and d["config"]["queue_depth"] == 48
     assert abs(r["alg_bytes_per_launch"] - 4.0 * 16384 ** 2) < 1.0     # lower triangle: 4 n^2 bytes
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] == 1 and c["unit"] == "updates/s" and c["value"] > 0 and c["sample"]
     assert c["all_cores"]["threads"] >= 1 and "NOT the reference" in c["all_cores"]["note"]
     assert d["host_call_path"]["updates_per_s"] > 0
     assert r["traffic_measured_in_this_run"] is False and r["per_kernel"]["symv"]["avg_ms"] > 0
+    # the as-run figure (the next group's products overlap this group's stage) and the kernel by itself
+    assert r["isolated"]["kernel"] == "k_symm_mfma" and 0.3 < r["isolated"]["frac"] < 1.0
+    assert r["per_kernel_isolated"]["symv"]["avg_ms"] > 0
     # 16 timed steps, lookahead 16: ONE pass over Q (a group of 16) and ONE apply pass (the flush at the end):
     # (1 * 4 n^2 + 1 * 8 n^2) / 16 = 0.75 n^2 per update
     assert abs(r["whole_update"]["alg_bytes_per_gpu"] - 0.75 * 16384 ** 2) < 1.0
