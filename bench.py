@@ -718,7 +718,9 @@ def main() -> None:
                 continue  # depth 16 exists on the lower-triangle schedule only
             if alt != (args.schedule, depth):
                 alts.append(alt)
-    total = W + K + 2 * P + 2 * C2 * len(alts) + H
+    # (a second profiled region, kernels one at a time, where the default run overlaps them: see prof_iso below)
+    P_iso = P if (variant == "ell" and not sharded and args.schedule == "pipelined" and n % 64 == 0 and n >= symv_min_n and lower_ok) else 0
+    total = W + K + P + P_iso + 2 * C2 * len(alts) + H
     if sharded and n % world and not shard_sym:
         raise SystemExit(f"n={n} is not divisible by {world} ranks")
 
@@ -780,7 +782,7 @@ def main() -> None:
             space = ShardedEll.new_with_scalar(1.0, np.zeros(n), device=local_rank, symmetric=shard_sym,
                                               defer_depth=depth if shard_sym else 8)
             sharded_via = "torch.distributed"
-    nq = W + K + 2 * P + 2 * C2 * len(alts)
+    nq = W + K + P + P_iso + 2 * C2 * len(alts)
     if variant == "ell" and not shard_sym:   # always explicit: a new unsharded handle may start at depth 16 by itself
         space.set_defer_depth(depth) if sharded else setattr(space, "defer_depth", depth)
     space.queue_upload(kinds[:nq], grads[:nq], b0[:nq], b1[:nq])
@@ -826,8 +828,7 @@ def main() -> None:
     # beside this group's stage, which stretches both (they share the CUs and HBM); the isolated durations say what each
     # kernel does by itself.  `roofline.frac` stays the as-run figure (what rocprofv3 sees for this command).
     prof_iso = None
-    if P > 0 and variant == "ell" and not sharded and fused and space.get_option(pkg.capi.OPT_OVERLAP) != 0 \
-            and space.get_option(pkg.capi.OPT_LOOKAHEAD) > 3 and n % 64 == 0:
+    if P_iso > 0 and fused and space.get_option(pkg.capi.OPT_OVERLAP) != 0 and space.get_option(pkg.capi.OPT_LOOKAHEAD) > 3:
         space.set_option(pkg.capi.OPT_OVERLAP, 0)
         space.profile_enable(True)
         run(W + K + P, P)
@@ -835,10 +836,12 @@ def main() -> None:
         prof_iso = space.profile_read()
         space.profile_enable(False)
         space.set_option(pkg.capi.OPT_OVERLAP, 1)
+    elif P_iso > 0:
+        run(W + K + P, P_iso)   # (nothing overlaps in this configuration: the cuts set aside for the second region just run)
 
     # ---- the other schedules / depths on the same handle, for comparison (timed the same way + per-kernel events)
     others = []
-    pos = W + K + 2 * P
+    pos = W + K + P + P_iso
     for (alt_sched, alt_depth) in alts:
         alt_fused = alt_sched == "pipelined"
         space.set_defer_depth(alt_depth) if sharded else setattr(space, "defer_depth", alt_depth)

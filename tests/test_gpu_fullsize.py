@@ -79,9 +79,13 @@ def test_pipelined_equals_two_pass_at_full_size(gpu, cuts, lookahead):
     else:
         assert np.max(np.abs(ta - tb) / ta) <= 1e-12 and abs(a.kappa - b.kappa) <= 1e-12 * a.kappa
         assert np.max(np.abs(a.xc() - b.xc())) <= 1e-12 * np.max(np.abs(a.xc()))
-    qa = a.mq
-    assert np.array_equal(qa, b.mq)
-    assert np.array_equal(qa, qa.T)
+    qa, qb = a.mq, b.mq
+    if lookahead <= 3:
+        assert np.array_equal(qa, qb)
+    else:
+        for r in range(0, N, 2048):   # (in blocks of rows: the difference of two 2 GiB matrices is a third)
+            assert np.max(np.abs(qa[r:r + 2048] - qb[r:r + 2048])) <= 1e-12
+    assert np.array_equal(qa, qa.T) and np.array_equal(qb, qb.T)
 
 
 def test_deferred_symv_equals_immediate_path_at_full_size(gpu, cuts):
