@@ -477,17 +477,21 @@ def symv_kernel_name(pkg, space, symv_mode: bool, n: int, fused: bool = True) ->
     return "k_symv_multi" if look > 1 else "k_symv"
 
 
+def settle(space) -> None:
+    """After a handle with gigabytes of device memory has been destroyed and the next one created, ONE stream synchronisation
+    of the new handle within the next few hundred milliseconds takes 75-85 ms longer although the GPU timeline shows its
+    kernels back to back (the driver's housekeeping for the recycled memory; measured on this pool with
+    tools/probe_brief.py: 88 ms instead of 10.5 for the n = 32768 region right after an n = 16384 handle).  A pause after
+    the warm-up absorbs it outside the timed region."""
+    time.sleep(0.3)
+    space.synchronize()
+
+
 def brief_config(pkg, synth, torch, workload: str, K: int, W: int, P: int, device: int) -> dict:
     """One BASELINE configuration, timed like the headline run (device-resident queue, pipelined schedule, the depth a
     new handle of that size starts with; recorded updates flushed on both sides of the timed region), reduced to the
     figures `other_configs` carries."""
     n, variant, cutgen, desc = WORKLOADS[workload]
-    # The previous workload's handle has just been destroyed: the driver's housekeeping for gigabytes of freed device memory
-    # runs in the background for a while and stalls whatever synchronizes meanwhile (measured on this pool: 75-85 ms added
-    # to ONE later stream synchronization within ~100 ms of the hipFree calls, tools/probe_brief.py; the GPU timeline of the
-    # same run shows the kernels back to back).  Let it finish outside the timed regions.
-    torch.cuda.synchronize()
-    time.sleep(0.5)
     t_gen = time.perf_counter()
     kinds, grads, b0, b1 = (synth.parallel_cuts if cutgen == "parallel" else synth.deep_cuts)(n, W + K + P)
     if variant == "ell":
@@ -505,6 +509,7 @@ def brief_config(pkg, synth, torch, workload: str, K: int, W: int, P: int, devic
         space.flush()
     torch.cuda.synchronize()
     space.synchronize()
+    settle(space)
     t0 = time.perf_counter()
     space.queue_run(W, K, fused=fused)
     if variant == "ell":
@@ -803,6 +808,8 @@ def main() -> None:
     run(0, W)
     if variant == "ell":
         space.flush()
+    fence()
+    time.sleep(0.3)   # (see settle(): driver housekeeping after large allocations, kept out of the timed region)
     fence()
     t0 = time.perf_counter()
     run(W, K)

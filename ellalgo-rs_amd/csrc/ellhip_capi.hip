@@ -1609,6 +1609,7 @@ void ellhip_destroy(ellhip_space* s) {
     DeviceGuard guard(s->device);
     if (s->stream) (void)hipStreamSynchronize(s->stream);
     if (s->aux_stream) (void)hipStreamSynchronize(s->aux_stream);  // nothing may be in flight when the buffers go
+    if (s->symv_stream) (void)hipStreamSynchronize(s->symv_stream);
     for (auto& pe : s->prof_events) {
         (void)hipEventDestroy(pe.a);
         (void)hipEventDestroy(pe.b);

@@ -225,9 +225,10 @@ int ellhip_set_shard_symmetric(ellhip_space *s, int flag);
  *                                                    (n <= 4224 on a 256-CU device: 9 us instead of 39 us per update at
  *                                                    n = 4096); 0 = always the streamed schedules
  *   ELLHIP_OPT_OVERLAP           0 / 1      1        Ell, ellhip_queue_run_fused on the lower-triangle schedule: the NEXT queued
- *                                                    cut's GEMV (it reads Q_base, which the cut being taken does not change) is
- *                                                    issued on a second stream beside this cut's reduction + scalar stage;
- *                                                    bit-identical to 0 (same kernels, operands and summation order)
+ *                                                    cut's GEMV (LOOKAHEAD 1) or the next GROUP's products (LOOKAHEAD > 3) --
+ *                                                    they read Q_base, which the cuts being taken do not change -- are issued
+ *                                                    on a second stream beside the current reduction + scalar stage; same
+ *                                                    results as 0 to the bit (same kernels, operands and summation order)
  *   ELLHIP_OPT_LOOKAHEAD         1 .. 16    16       Ell, ellhip_queue_run_fused on the lower-triangle schedule: the GEMVs of up to
  *                                                    this many consecutive QUEUED cuts are formed in one pass over Q_base
  *                                                    (they all refer to the same matrix until the next apply pass):
@@ -285,7 +286,13 @@ int ellhip_queue_upload(ellhip_space *s, int64_t k, const int32_t *kinds, const 
                         const double *beta0, const int32_t *has_beta1, const double *beta1);
 /* Enqueue cuts [first, first+count) on the stream; asynchronous.  ellhip_queue_run uses the
  * two-pass schedule (GEMV pass + rank-1 pass per cut); ellhip_queue_run_fused the pipelined one
- * (one pass per cut: the shrink of cut i fused with the GEMV of cut i+1). Same results. */
+ * (one pass per cut: the shrink of cut i fused with the GEMV of cut i+1). Same results.
+ * On a handle that records its updates (lower-triangle schedule: unsharded, even n >= 8192 by default)
+ * ellhip_queue_run_fused also uses that the queue holds the NEXT gradients: the products Q_base g of up to
+ * ELLHIP_OPT_LOOKAHEAD consecutive queued cuts are formed in one pass over the matrix and their scalar stages run as
+ * one group ("options" above; results to ~1e-15 of the cut-by-cut schedules, to the bit for LOOKAHEAD <= 3).  It may
+ * use a second stream of its own beside the handle's; everything it issued there has been joined to the handle's
+ * stream when it returns. */
 int ellhip_queue_run(ellhip_space *s, int64_t first, int64_t count);
 int ellhip_queue_run_fused(ellhip_space *s, int64_t first, int64_t count);
 /* Phase-wise forms of one queued cut for the multi-GPU schedule; all asynchronous.  After every call
