@@ -418,7 +418,10 @@ def gemv_passes(steps: int, dep: int, lookahead: int) -> int:
     and at the end of the run)."""
     i = npend = passes = 0
     while i < steps:
-        g = min(lookahead, steps - i, dep - npend)
+        rem = min(steps - i, dep - npend)
+        g = min(lookahead, rem)
+        if lookahead > 3 and lookahead < rem < 2 * lookahead:
+            g = (rem + 1) // 2   # (two even groups rather than a full and a small one: queue_run_multi)
         passes += 1
         i += g
         npend = (npend + g) % dep

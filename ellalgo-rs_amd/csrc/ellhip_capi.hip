@@ -1393,8 +1393,12 @@ int queue_run_multi(ellhip_space* s, long long first, long long count) {
             rc = ensure_committed(s);
             if (rc) return rc;
             const long long room = (long long)qdepth - s->npend;  // cuts that can still be recorded before the apply pass
-            const long long cap = multi_mfma(s) ? MULTI_MAX : MULTI_VALU_MAX;
-            g = std::min<long long>(std::min<long long>(s->lookahead, cap), std::min(end - i, room));
+            const long long cap = std::min<long long>(s->lookahead, multi_mfma(s) ? MULTI_MAX : MULTI_VALU_MAX);
+            const long long rem = std::min(end - i, room);  // cuts up to the next apply pass or the end of the run
+            g = std::min(cap, rem);
+            // a matrix-core pass costs the same for 4 gradients as for 16: what is left goes into two even groups rather
+            // than a full one and a small one (the first group's stage then overlaps a pass that carries its share)
+            if (multi_mfma(s) && rem > cap && rem < 2 * cap) g = (rem + 1) / 2;
         }
         if (g <= 1) {  // a cut primed earlier, the last one before an apply pass, the last one of the run
             if (s->npend >= s->defer) {  // (the per-cut kernels hold `depth` recorded updates)
@@ -1420,8 +1424,12 @@ int queue_run_multi(ellhip_space* s, long long first, long long count) {
             // the NEXT group's products on the second stream beside this group's stage -- when there is one inside this run
             // and no apply pass comes first (it would read the matrix that pass writes)
             const long long i2 = i + g, room2 = (long long)qdepth - (s->npend + g);
-            const long long g2 = (i2 < end && room2 > 0)
-                                     ? std::min<long long>(std::min<long long>(s->lookahead, cap), std::min(end - i2, room2)) : 0;
+            long long g2 = 0;
+            if (i2 < end && room2 > 0) {
+                const long long cap2 = std::min<long long>(s->lookahead, cap), rem2 = std::min(end - i2, room2);
+                g2 = std::min(cap2, rem2);
+                if (rem2 > cap2 && rem2 < 2 * cap2) g2 = (rem2 + 1) / 2;  // (the rule the next trip of the loop applies)
+            }
             if (use_side && g2 >= 2) {
                 HIPCHK(hipStreamWaitEvent(s->symv_stream, s->ev_red[half ^ 1], 0));
                 rc = symm_go(s, qgrad(s, i2), (int)g2, s->symv_stream, half ^ 1);
