@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "../../ellalgo-rs_amd/csrc/ell_kernels.hpp"
+#include "symm_split_kernel.hpp"
 
 using namespace ellhip;
 
@@ -184,6 +185,36 @@ int main(int argc, char** argv) {
                 hipLaunchKernelGGL((k_symm_mfma<true, SEG>), dim3((unsigned)nstrips, (unsigned)nsegs), dim3(256), 0, 0,
                                    (const double*)Q, ld, n, (const double*)gT, lv, rpm, cpm, rs, cs, (const DevState*)st);
             });
+            snprintf(nm, sizeof nm, "k_symm_mfma_split alone, %d vectors", lv);
+            timeit(nm, lv, [&] {
+                hipLaunchKernelGGL((k_symm_mfma_split<true, SEG>), dim3((unsigned)nstrips, (unsigned)nsegs), dim3(256), 0, 0,
+                                   (const double*)Q, ld, n, (const double*)gT, lv, rpm, cpm, rs, cs, (const DevState*)st);
+            });
+            CK(hipDeviceSynchronize());
+            {
+                double worst = 0.0;
+                for (int l = 0; l < lv; l += (lv > 4 ? 5 : 1)) {
+                    CK(hipMemset(rp1, 0, (size_t)rs * 8));
+                    CK(hipMemset(cp1, 0, (size_t)cs * 8));
+                    hipLaunchKernelGGL((k_symv<2, true, 0, SEG>), dim3((unsigned)nstrips, (unsigned)nsegs), dim3(256), 0, 0,
+                                       (const double*)Q, ld, n, 0LL, n, (const double*)(g16 + l * n), rp1, cp1, (const DevState*)st);
+                    CK(hipDeviceSynchronize());
+                    for (int which = 0; which < 2; ++which) {
+                        const long long m = which ? cs : rs;
+                        CK(hipMemcpy(a.data(), (which ? cpm + l * cs : rpm + l * rs), (size_t)m * 8, hipMemcpyDeviceToHost));
+                        CK(hipMemcpy(b.data(), which ? cp1 : rp1, (size_t)m * 8, hipMemcpyDeviceToHost));
+                        double mx = 0.0, df = 0.0;
+                        for (long long i = 0; i < m; ++i) {
+                            mx = std::max(mx, std::fabs(b[i]));
+                            df = std::max(df, std::fabs(a[i] - b[i]));
+                        }
+                        worst = std::max(worst, df / mx);
+                    }
+                }
+                printf("   check (split): max |diff| / max |value| = %.3e %s\n", worst, worst < 1e-13 ? "ok" : "WRONG");
+            }
+            CK(hipMemset(rpm, 0, (size_t)NV * rs * 8));
+            CK(hipMemset(cpm, 0, (size_t)NV * cs * 8));
             snprintf(nm, sizeof nm, "k_symm_mfma alone, %d vectors", lv);
             timeit(nm, lv, [&] {
                 hipLaunchKernelGGL((k_symm_mfma<true, SEG>), dim3((unsigned)nstrips, (unsigned)nsegs), dim3(256), 0, 0,
