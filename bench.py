@@ -726,6 +726,10 @@ def main() -> None:
                 continue  # depth 16 exists on the lower-triangle schedule only
             if alt != (args.schedule, depth):
                 alts.append(alt)
+        # the timed configuration with ONE product per pass over Q (what a queue run did before it looked ahead, and the
+        # per-cut kernels a live loop's ellhip_update uses): the same handle, ELLHIP_OPT_LOOKAHEAD = 1
+        if not sharded and lower_ok and n >= symv_min_n and args.schedule == "pipelined" and depth >= 16:
+            alts.insert(0, ("pipelined, lookahead 1", depth))
     # (a second profiled region, kernels one at a time, where the default run overlaps them: see prof_iso below)
     P_iso = P if (variant == "ell" and not sharded and args.schedule == "pipelined" and n % 64 == 0 and n >= symv_min_n and lower_ok) else 0
     total = W + K + P + P_iso + 2 * C2 * len(alts) + H
@@ -853,8 +857,12 @@ def main() -> None:
     others = []
     pos = W + K + P + P_iso
     for (alt_sched, alt_depth) in alts:
-        alt_fused = alt_sched == "pipelined"
+        alt_fused = alt_sched.startswith("pipelined")
         space.set_defer_depth(alt_depth) if sharded else setattr(space, "defer_depth", alt_depth)
+        look1 = alt_sched.endswith("lookahead 1")
+        if look1:
+            look_was = space.get_option(pkg.capi.OPT_LOOKAHEAD)
+            space.set_option(pkg.capi.OPT_LOOKAHEAD, 1)
         fence()
         t2 = time.perf_counter()
         run(pos, C2, alt_fused)
@@ -871,6 +879,8 @@ def main() -> None:
         others.append({"schedule": alt_sched, "defer_depth": alt_depth, "steps": C2, "updates_per_s": C2 / el2,
                        "ms_per_step": el2 / C2 * 1e3, "prof": space.profile_read()})
         space.profile_enable(False)
+        if look1:
+            space.set_option(pkg.capi.OPT_LOOKAHEAD, look_was)
         pos += 2 * C2
 
     status, tsqs = space.queue_results()
@@ -1014,7 +1024,10 @@ def main() -> None:
     if "achieved" not in roofline:
         roofline.update({"kernel": "whole_update", "achieved": upd_gbps, "frac": upd_gbps / HBM_PEAK_GBS})
     for o in others:
-        ob, omodel = byte_model(o["schedule"], o["defer_depth"], o["steps"])
+        if o["schedule"].endswith("lookahead 1"):
+            ob, omodel = ell_bytes_per_update(n2w, "pipelined", o["defer_depth"], o["steps"], symv_mode, lower_apply, sharded, 1)
+        else:
+            ob, omodel = byte_model(o["schedule"], o["defer_depth"], o["steps"])
         og = ob / (o["ms_per_step"] * 1e-3) / 1e9
         o["byte_model"] = omodel
         o["whole_update"] = {"alg_bytes_per_gpu": ob, "GBps_per_gpu": og, "frac": og / HBM_PEAK_GBS}

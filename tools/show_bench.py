@@ -18,7 +18,7 @@ for path in sys.argv[1:]:
           f'ms={d["ms_per_step"]:.4f} dom={r.get("kernel")} frac={r.get("frac", 0):.3f} whole={(r.get("whole_update") or r.get("whole_iteration"))["frac"]:.3f} {pk}')
     for o in d.get("other_schedules", []):
         pk = {k: (round(v["avg_ms"], 4), round(v.get("GBps", 0))) for k, v in o["per_kernel"].items()}
-        print(f'{"":18s} {o["schedule"][:9]:9s} d{o["defer_depth"]}        upd/s={o["updates_per_s"]:9.1f} ms={o["ms_per_step"]:.4f} '
+        print(f'{"":18s} {o["schedule"][:22]:22s} d{o["defer_depth"]}        upd/s={o["updates_per_s"]:9.1f} ms={o["ms_per_step"]:.4f} '
               f'whole={o["whole_update"]["frac"]:.3f} {pk}')
     for o in d.get("other_configs", []):
         ro = o["roofline"]
