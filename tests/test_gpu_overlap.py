@@ -136,3 +136,69 @@ def test_overlapped_run_at_the_default_size_and_depth(gpu):
     # one pass over Q and one batched reduction per group of up to sixteen cuts (a run's end closes a group early):
     # (16, 15) + (16, 13); both runs end with more than 24 recorded and apply them before they return
     assert prof["symv_reduce"][1] == 4 and prof["symv"][1] == 4 and prof["apply"][1] == 2
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_option_mixes_against_the_oracle(gpu, orc, seed):
+    """Seeded walks over what the queue run can be asked to do: size (multiples of 64 and not, both segment widths), depth,
+    LOOKAHEAD / QUEUE_DEPTH / OVERLAP, the run cut into random pieces with direct updates, flushes, option switches and
+    observers in between, a failing cut at a random place; every cut's status and tsq and the final state against the
+    oracle's plain sequence of updates (north-star tolerance)."""
+    rng = np.random.default_rng(1000 + seed)
+    set_default("SYMV_MIN_N", 512)
+    set_default("RESIDENT", 0)
+    n = int(rng.choice([512, 576, 640, 1000, 1024, 1090, 2112, 4096 if seed % 6 == 0 else 1536]))
+    depth = int(rng.choice([8, 16, 24, 24]))
+    k = int(rng.integers(50, 110))
+    bad = int(rng.integers(10, k)) if rng.random() < 0.4 else None
+    kinds, grads, b0, b1 = _cuts(n, k, 17 * seed + n, fail_at=bad)
+    e = gpu.Ell.new_with_scalar(1.0, np.linspace(-1.0, 1.0, n))
+    e.defer_depth = depth
+
+    def reroll():
+        e.set_option(gpu.capi.OPT_LOOKAHEAD, int(rng.choice([1, 2, 3, 4, 7, 12, 16])))
+        e.set_option(gpu.capi.OPT_QUEUE_DEPTH, int(rng.choice([0, 48])))
+        e.set_option(gpu.capi.OPT_OVERLAP, int(rng.integers(0, 2)))
+
+    reroll()
+    e.queue_upload(kinds, grads, b0, b1)
+    o = orc.OracleEll.new_with_scalar(1.0, np.linspace(-1.0, 1.0, n))
+    want_st, want_ts, halted = [], [], False
+    for i in range(k):
+        if halted:
+            want_st.append(3)
+            want_ts.append(None)
+            continue
+        so = o.update(int(kinds[i]), grads[i], b0[i], None if np.isnan(b1[i]) else b1[i])
+        want_st.append(so)
+        want_ts.append(o.tsq)
+        halted = so != 0
+    stop = bad if bad is not None else k     # cuts [0, stop) succeed
+    pos = 0
+    while pos < k:
+        step = int(rng.integers(1, min(60, k - pos) + 1))
+        act = rng.random()
+        if act < 0.15 and pos < stop - 1 and (bad is None or pos < bad):
+            # a synchronous update of cut `pos` (only while the queue has not halted: a halted queue refuses nothing, but the
+            # oracle's sequence has no cut behind the failing one)
+            assert int(e._update(int(kinds[pos]), (grads[pos], _beta(b0, b1, pos)))) == 0
+            want_st[pos] = -1          # never ran in the queue
+            pos += 1
+            continue
+        e.queue_run(pos, step, fused=True)
+        pos += step
+        r = rng.random()
+        if r < 0.2:
+            e.flush()
+        elif r < 0.3:
+            reroll()
+        elif r < 0.4 and (bad is None or pos <= bad):
+            assert abs(e.kappa - 0.0) >= 0.0 and e.xc().shape == (n,)   # observers in the middle of the sequence
+    st, ts = e.queue_results()
+    for i in range(k):
+        if want_st[i] == -1:
+            continue
+        assert int(st[i]) == want_st[i], (i, int(st[i]), want_st[i], bad)
+        if want_ts[i] is not None:
+            assert abs(ts[i] - want_ts[i]) <= TOL * abs(want_ts[i]), (i, bad)
+    assert_state_close(e, o, what=f"seed {seed}: n={n} depth={depth} bad={bad}")
