@@ -439,7 +439,7 @@ def ell_bytes_per_update(n2w: float, sched: str, dep: int, steps: int, symv_mode
             return 16.0 * n2w, "16*n^2 B/update (rank-1 pass of cut k fused with the GEMV of cut k+1)"
         return 24.0 * n2w, "24*n^2 B/update (GEMV pass 8 + rank-1 pass 16; SURVEY 8d)"
     passes = -(-steps // dep)
-    if symv_mode and lower_apply and sched == "pipelined" and lookahead > 1 and not sharded:
+    if symv_mode and lower_apply and sched == "pipelined" and lookahead > 1:
         gp = gemv_passes(steps, dep, lookahead)
         per = (4.0 * gp + 8.0 * passes) / steps
         return per * n2w, (f"{per:.4g}*n^2 B/update = ({gp} passes over the lower triangle of 4*n^2, each forming the products of up to "
@@ -447,7 +447,9 @@ def ell_bytes_per_update(n2w: float, sched: str, dep: int, steps: int, symv_mode
                            f"(deferred shrink, depth {dep}, lookahead {lookahead}: only a queue knows the next gradients -- a live "
                            f"cutting-plane loop runs lookahead 1, see host_call_path; steady state "
                            f"{(4.0 * -(-dep // lookahead) + 8.0) / dep:.4g}*n^2; the partial sums the passes hand to the "
-                           "reductions, 2.2 n^2 / 64 per vector written and read, are not counted)")
+                           "reductions, 2.2 n^2 / 64 per vector written and read, are not counted" +
+                           ("; per GPU 1/P of that: symmetric row shards of equal trapezoid area, ONE all-reduce of the group's "
+                            "n-vectors per pass)" if sharded else ")"))
     if symv_mode and lower_apply:
         per = 4.0 + 8.0 * passes / steps
         return per * n2w, (f"{per:g}*n^2 B/update = ({steps} lower-triangle GEMV passes of 4*n^2 + {passes} lower-triangle apply "
@@ -703,9 +705,10 @@ def main() -> None:
         if not sharded:
             depth = 24 if (lower_ok and n >= symv_min_n) else 8
         else:
-            sym = (n % 64 == 0 and n // 64 >= world and (float(n) * n / 2 / world) / (64 * 2048) >= 200
-                   and os.environ.get("ELLHIP_SHARD_SYMMETRIC", "1") != "0")
-            depth = 16 if (lower_ok and sym) else 8
+            # symmetric shards take the pipelined queue run in groups (one pass over the local trapezoid and ONE all-reduce
+            # per 16 queued cuts): the per-cut latency that made small trapezoids a loss is gone
+            sym = (n % 64 == 0 and n // 64 >= world and os.environ.get("ELLHIP_SHARD_SYMMETRIC", "1") != "0")
+            depth = 24 if (lower_ok and sym) else 8
     C2 = args.compare_steps if variant == "ell" else 0
     # N > 1, depth 8: symmetric row shards (equal lower-trapezoid areas, partial symmetric GEMVs added by one
     # all-reduce, lower-trapezoid apply passes): 5*n^2/P bytes per GPU and update.  That schedule only, so the
@@ -713,8 +716,8 @@ def main() -> None:
     # (taken when a rank's trapezoid still fills the GPU with 64 x 2048 tiles: n = 16384 up to P = 4, n = 32768 up to
     # P = 8; below that the lower-triangle GEMV is latency bound and equal row blocks with full-row GEMVs are faster:
     # measured per rank with tools/shard_timing.py)
-    sym_default = "1" if (float(n) * n / 2 / world) / (64 * 2048) >= 200 else "0"
-    shard_sym = (sharded and variant == "ell" and depth in (8, 16) and n % 64 == 0 and n // 64 >= world
+    sym_default = "1"
+    shard_sym = (sharded and variant == "ell" and depth in (8, 16, 24) and n % 64 == 0 and n // 64 >= world
                  and os.environ.get("ELLHIP_SHARD_SYMMETRIC", sym_default) != "0")
     if shard_sym:
         C2 = 0
@@ -947,6 +950,10 @@ def main() -> None:
     if variant == "ell" and symv_mode and not sharded:
         lookahead = space.get_option(pkg.capi.OPT_LOOKAHEAD)
         queue_depth = space.get_option(pkg.capi.OPT_QUEUE_DEPTH)
+    elif shard_sym and str(sharded_via).startswith("c-abi"):
+        # symmetric shards behind the C ABI take the pipelined queue run in groups too (ellhip_sharded_queue_run_fused)
+        lookahead = opt(pkg.capi.OPT_LOOKAHEAD)
+        queue_depth = opt(pkg.capi.OPT_QUEUE_DEPTH)
 
     def eff_depth(sched, dep):
         """Recorded updates per apply pass: inside a pipelined queue run on the group stage (lookahead > 3, n % 64 == 0) a

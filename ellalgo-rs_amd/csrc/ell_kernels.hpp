@@ -1015,9 +1015,9 @@ __global__ __launch_bounds__(256) void k_apply_mfma(double* __restrict__ Q, long
 // the B operand of the row product (contraction over columns):
 //     Dr[j'][v][r] += sum_c gT[c][v] Q[r][c]        A = gT columns, 16 MFMAs
 // Dc leaves as colpart_v[I][c] per block, Dr is added over the four waves as ((w0 + w1) + w2) + w3 and leaves as
-// rowpart_v[J][r]: the partial sums k_symv_reduce expects.  Numerics: the MFMA sums four products per instruction in
+// rowpart_v[J][r]: the partial sums k_symv_reduce expects (for a row shard: of its trapezoid).  Numerics: the MFMA sums four products per instruction in
 // its own association and fuses the multiply-add; y differs from k_symv's by a few ulp (inside the 1e-10 contract, not
-// bit-identical to the vector-ALU kernels).  Requires n % 64 == 0, unsharded.
+// bit-identical to the vector-ALU kernels).  Requires n % 64 == 0 (and shard boundaries at multiples of 64).
 constexpr int SMM_NV = 16;
 constexpr int SMM_PITCH = 17;
 
@@ -1031,8 +1031,9 @@ __global__ __launch_bounds__(256) void k_pack_grads(const double* __restrict__ g
 }
 
 template <bool NT, int SEG>
-__global__ __launch_bounds__(256) void k_symm_mfma(const double* __restrict__ Q, long long ld, long long n,
-                                                   const double* __restrict__ gT, int lv, double* __restrict__ rowpart,
+__global__ __launch_bounds__(256) void k_symm_mfma(const double* __restrict__ Q, long long ld, long long n, long long row0,
+                                                   long long nrows, const double* __restrict__ gT, int lv,
+                                                   double* __restrict__ rowpart,
                                                    double* __restrict__ colpart, long long rowpart_stride,
                                                    long long colpart_stride, const DevState* __restrict__ st) {
     __shared__ double sh[4][SYMV_H * SMM_PITCH];
@@ -1040,9 +1041,12 @@ __global__ __launch_bounds__(256) void k_symm_mfma(const double* __restrict__ Q,
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int lr = lane >> 4, lc = lane & 15;
     const long long I = (long long)gridDim.x - 1 - blockIdx.x, J = (long long)blockIdx.y;
-    const long long r0 = I * SYMV_H;
+    // a symmetric row shard holds the rows [row0, row0 + nrows) (both multiples of 64): I counts its local strips, row and
+    // column indices are global, the result is this shard's PARTIAL sums (as k_symv's for a shard)
+    const long long r0 = row0 + I * SYMV_H;
     const long long c0 = J * SEG;
-    if (r0 >= n || c0 > r0 + SYMV_H - 1) return;
+    if (r0 >= row0 + nrows || c0 > r0 + SYMV_H - 1) return;
+    Q -= row0 * ld;
     const bool full = c0 + SEG - 1 < r0;
     // A operand of the column product: gT rows of the strip
     double gr[16];

@@ -134,6 +134,10 @@ struct ellhip_space {
     double* d_cpart = nullptr;       // [ceil(n/128)][GRP_MAX * GRP_MAX]
     double* d_gsums = nullptr;       // [GRP_MAX][MAXPEND + 1] + [GRP_MAX][GRP_MAX]: their sums over the blocks
     GroupOut* d_gout = nullptr;
+    // a symmetric row shard's group runs: the owner's all-reduce of the group's partial products (count doubles at buf, in
+    // place, on `stream`); set by sharded_capi.inc.hpp around its call of queue_run_multi
+    int (*grp_exchange)(void* ctx, double* buf, long long count, hipStream_t stream) = nullptr;
+    void* grp_exchange_ctx = nullptr;
     hipEvent_t ev_symv = nullptr;    // the GEMV issued ahead has finished
     hipEvent_t ev_red[2] = {nullptr, nullptr};  // set k is free again (its reduction, and every apply pass before, are done)
     int symv = 1;                    // allow the lower-triangle GEMV in deferred mode (ELLHIP_SYMV=0 disables)
@@ -1278,6 +1282,12 @@ bool multi_ok(const ellhip_space* s) {
     return s->lookahead > 1 && s->variant == ELLHIP_SPACE_ELL && !s->sharded && symv_ok(s);
 }
 bool multi_mfma(const ellhip_space* s) { return s->lookahead > MULTI_VALU_MAX && (s->n % 64) == 0; }
+// a symmetric row shard: the matrix-core groups only, and every cut through them (a single cut's GEMV would need the
+// owner's per-cut collective in between); its owner calls queue_run_multi with grp_exchange set
+bool multi_shard_ok(const ellhip_space* s) {
+    return s->variant == ELLHIP_SPACE_ELL && s->sharded && s->shard_symmetric && symv_ok(s) && multi_mfma(s) &&
+           (s->row0 % 64) == 0 && ((s->row0 + s->nrows) % 64 == 0 || s->row0 + s->nrows == s->n);
+}
 
 int multi_setup(ellhip_space* s) {
     if (s->d_rowpart_m) return 0;
@@ -1305,14 +1315,30 @@ int group_stage_go(ellhip_space* s, long long i, int g, int half, hipEvent_t set
     const double* grads = qgrad(s, i);
     {
         ProfScope ps(s, CLS_SYMV_REDUCE);
-        hipLaunchKernelGGL(k_group_reduce<NP>, dim3(nb, (unsigned)g), dim3(256), 0, s->stream, s->n, (long long)s->symv_seg,
-                           (const double*)(s->d_rowpart_m + (size_t)half * MULTI_MAX * rowpart_elems(s)),
-                           (const double*)(s->d_colpart_m + (size_t)half * MULTI_MAX * colpart_elems(s)),
-                           (long long)rowpart_elems(s), (long long)colpart_elems(s), s->d_grpY, grads, s->n,
-                           (const double*)s->d_pend, s->d_gpart, (const DevState*)s->d_st);
+        const double* rowp = s->d_rowpart_m + (size_t)half * MULTI_MAX * rowpart_elems(s);
+        const double* colp = s->d_colpart_m + (size_t)half * MULTI_MAX * colpart_elems(s);
+        if (s->sharded)
+            hipLaunchKernelGGL(k_group_reduce<0>, dim3(nb, (unsigned)g), dim3(256), 0, s->stream, s->n, s->row0, s->nrows,
+                               (long long)s->symv_seg, rowp, colp, (long long)rowpart_elems(s), (long long)colpart_elems(s),
+                               s->d_grpY, grads, s->n, (const double*)s->d_pend, s->d_gpart, (const DevState*)s->d_st);
+        else
+            hipLaunchKernelGGL(k_group_reduce<NP>, dim3(nb, (unsigned)g), dim3(256), 0, s->stream, s->n, s->row0, s->nrows,
+                               (long long)s->symv_seg, rowp, colp, (long long)rowpart_elems(s), (long long)colpart_elems(s),
+                               s->d_grpY, grads, s->n, (const double*)s->d_pend, s->d_gpart, (const DevState*)s->d_st);
         HIPCHK(hipGetLastError());
     }
     if (sets_free) HIPCHK(hipEventRecord(sets_free, s->stream));  // (the reduction is the only reader of the partial-sum sets)
+    if (s->sharded) {
+        // the shards' partial products become the products: ONE collective for the whole group, then the dot products from
+        // the complete vectors (every rank forms the same ones)
+        if (!s->grp_exchange) return fail(ELLHIP_E_STATE, "group run of a row shard without the owner's collective");
+        const int xrc = s->grp_exchange(s->grp_exchange_ctx, s->d_grpY, (long long)g * s->n, s->stream);
+        if (xrc) return xrc;
+        ProfScope ps(s, CLS_SYMV_REDUCE);
+        hipLaunchKernelGGL(k_group_dots<NP>, dim3(nb, (unsigned)g), dim3(256), 0, s->stream, s->n, (const double*)s->d_grpY, grads,
+                           s->n, (const double*)s->d_pend, s->d_gpart, (const DevState*)s->d_st);
+        HIPCHK(hipGetLastError());
+    }
     ProfScope ps(s, CLS_SCALAR);
     hipLaunchKernelGGL(k_group_gram, dim3(nb), dim3(256), 0, s->stream, s->n, g, (const double*)s->d_grpY, grads, s->n,
                        s->d_cpart, (const DevState*)s->d_st);
@@ -1337,11 +1363,11 @@ void symm_mfma_go(ellhip_space* s, const double* g_dev, int lv, hipStream_t st, 
     hipLaunchKernelGGL(k_pack_grads, dim3((unsigned)((s->n * SMM_NV + 255) / 256)), dim3(256), 0, st, g_dev, s->n, lv, s->n, gT);
     if (s->sh_gemv.nt != 0)
         hipLaunchKernelGGL((k_symm_mfma<true, SEG>), dim3(nstrips, nsegs), dim3(256), 0, st, (const double*)s->d_Q, s->ld, s->n,
-                           (const double*)gT, lv, rowp, colp, (long long)rowpart_elems(s), (long long)colpart_elems(s),
+                           s->row0, s->nrows, (const double*)gT, lv, rowp, colp, (long long)rowpart_elems(s), (long long)colpart_elems(s),
                            (const DevState*)s->d_st);
     else
         hipLaunchKernelGGL((k_symm_mfma<false, SEG>), dim3(nstrips, nsegs), dim3(256), 0, st, (const double*)s->d_Q, s->ld, s->n,
-                           (const double*)gT, lv, rowp, colp, (long long)rowpart_elems(s), (long long)colpart_elems(s),
+                           s->row0, s->nrows, (const double*)gT, lv, rowp, colp, (long long)rowpart_elems(s), (long long)colpart_elems(s),
                            (const DevState*)s->d_st);
 }
 int symm_go(ellhip_space* s, const double* g_dev, int lv, hipStream_t st, int half) {
@@ -1372,6 +1398,8 @@ int queue_run_multi(ellhip_space* s, long long first, long long count) {
     int rc = multi_setup(s);
     if (rc) return rc;
     const long long end = first + count;
+    if (s->sharded && (s->primed || !s->grp_exchange))
+        return fail(ELLHIP_E_STATE, "group run of a row shard: the owner takes a primed cut by itself and supplies the collective");
     // Inside this run the group stage may let more updates pile up than the handle's depth (its kernels are sized for
     // MAXPEND = 48; the per-cut kernels of every other path for the depth): half as many apply passes.  Whatever leaves
     // this function has fewer recorded than the depth again.
@@ -1379,7 +1407,7 @@ int queue_run_multi(ellhip_space* s, long long first, long long count) {
     const int qdepth = deep_ok ? s->queue_depth : s->defer;
     // (measured: +1.5 % / +8 % at n = 16384 for 200 / 20 cuts per run, -3 % at n = 32768, where stretching a 1.1 ms pass
     // costs more than hiding a 0.4 ms stage saves)
-    const bool use_side = multi_mfma(s) && s->overlap != 0 && s->n <= 24576;
+    const bool use_side = multi_mfma(s) && s->overlap != 0 && s->n <= 24576 && !s->sharded;
     if (use_side) {
         rc = side_setup(s);
         if (rc) return rc;
@@ -1402,7 +1430,7 @@ int queue_run_multi(ellhip_space* s, long long first, long long count) {
             // than a full one and a small one (the first group's stage then overlaps a pass that carries its share)
             if (multi_mfma(s) && rem > cap && rem < 2 * cap) g = (rem + 1) / 2;
         }
-        if (g <= 1) {  // a cut primed earlier, the last one before an apply pass, the last one of the run
+        if (g <= 1 && !s->sharded) {  // a cut primed earlier, the last one before an apply pass, the last one of the run
             if (s->npend >= s->defer) {  // (the per-cut kernels hold `depth` recorded updates)
                 rc = flush_pending(s, nullptr, nullptr);
                 if (rc) return rc;

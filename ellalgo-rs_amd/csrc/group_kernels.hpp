@@ -31,7 +31,8 @@ struct GroupOut {
 // y_l for every cut of the group (grid.y = l) + the dot products with what was recorded before the group: the body of
 // k_symv_reduce<NP>, G of them in one launch.  gpart[l][b][0] = slice of g_l.y_l, [1 + j] = slice of v_j.g_l.
 template <int NP>
-__global__ __launch_bounds__(256) void k_group_reduce(long long n, long long seg, const double* __restrict__ rowpart,
+__global__ __launch_bounds__(256) void k_group_reduce(long long n, long long row0, long long nrows, long long seg,
+                                                      const double* __restrict__ rowpart,
                                                       const double* __restrict__ colpart, long long rowpart_stride,
                                                       long long colpart_stride, double* __restrict__ Y,
                                                       const double* __restrict__ g, long long g_stride,
@@ -40,8 +41,41 @@ __global__ __launch_bounds__(256) void k_group_reduce(long long n, long long seg
     __shared__ double2_t part[4][64];
     if (st->halted) return;
     const long long l = blockIdx.y, nb = gridDim.x;
-    symv_reduce_block<NP, false>((long long)blockIdx.x, n, 0, n, seg, rowpart + l * rowpart_stride, colpart + l * colpart_stride,
-                                 Y + l * n, g + l * g_stride, pend, gpart + l * nb * (NP + 1), part);
+    // (NP = 0, a row shard: its partial y_l only -- the dot products wait for the all-reduce, k_group_dots)
+    symv_reduce_block<NP, false>((long long)blockIdx.x, n, row0, nrows, seg, rowpart + l * rowpart_stride,
+                                 colpart + l * colpart_stride, Y + l * n, g + l * g_stride, pend, gpart + l * nb * (NP + 1), part);
+}
+
+// The same for a symmetric row shard: k_group_reduce<0> yields the shard's PARTIAL y_l, the owner's ONE all-reduce of
+// the G vectors completes them, and the dot products follow from the complete vectors (every rank computes the same).
+// gpart as above; lane pairs and wave sums as in symv_reduce_block's dot section.
+template <int NP>
+__global__ __launch_bounds__(256) void k_group_dots(long long n, const double* __restrict__ Y, const double* __restrict__ g,
+                                                    long long g_stride, const double* __restrict__ pend,
+                                                    double* __restrict__ gpart, const DevState* __restrict__ st) {
+    if (st->halted) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long long l = blockIdx.y, nb = gridDim.x, blk = blockIdx.x;
+    const long long i = blk * 128 + 2 * lane;
+    double* out = gpart + (l * nb + blk) * (NP + 1);
+    double2_t gi = {0.0, 0.0};
+    if (i < n) gi = *reinterpret_cast<const double2_t*>(g + l * g_stride + i);
+    if (wave == 0) {
+        double2_t yv = {0.0, 0.0};
+        if (i < n) yv = *reinterpret_cast<const double2_t*>(Y + l * n + i);
+        double sgy = gi.x * yv.x;
+        sgy += gi.y * yv.y;
+        sgy = wave_allreduce_sum(sgy);
+        if (lane == 0) out[0] = sgy;
+    }
+    for (int j = wave; j < NP; j += 4) {
+        double2_t pv = {0.0, 0.0};
+        if (i < n) pv = *reinterpret_cast<const double2_t*>(pend + (long long)j * n + i);
+        double sv = pv.x * gi.x;
+        sv += pv.y * gi.y;
+        sv = wave_allreduce_sum(sv);
+        if (lane == 0) out[1 + j] = sv;
+    }
 }
 
 // cpart[b][m][l] = slice (128 columns) of y_m . g_l, m < l

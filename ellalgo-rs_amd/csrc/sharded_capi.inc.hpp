@@ -355,10 +355,48 @@ int ellhip_sharded_queue_run(ellhip_sharded* s, int64_t first, int64_t count) {
     return 0;
 }
 
+namespace {
+// the collective of a GROUP of queued cuts (symmetric shards, ELLHIP_OPT_LOOKAHEAD > 3): the shards' partial products of
+// all the group's cuts, `count` = cuts x n doubles, added in place -- one all-reduce where the cut-by-cut schedule has one
+// per cut
+int shard_group_exchange(void* ctx, double* buf, long long count, hipStream_t stream) {
+    ellhip_sharded* s = static_cast<ellhip_sharded*>(ctx);
+    if (s->user_allreduce) {
+        if (s->user_allreduce(s->user_ctx, buf, count, stream) != 0)
+            return fail(ELLHIP_E_NORCCL, "the host-supplied collective reported a failure");
+        return 0;
+    }
+    if (!s->comm) return 0;  // one rank: the local products are the products
+    const int rc = rccl()->AllReduce(buf, buf, (size_t)count, RCCL_DOUBLE, RCCL_SUM, s->comm, stream);
+    return rc != 0 ? rccl_fail("ncclAllReduce", rc) : 0;
+}
+}  // namespace
+
 int ellhip_sharded_queue_run_fused(ellhip_sharded* s, int64_t first, int64_t count) {
     if (!s || first < 0 || count < 0 || first + count > s->qk) return fail(ELLHIP_E_INVALID, "queue range");
     if (count == 0) return 0;
     int rc = 0;
+    if (s->partition == ELLHIP_SHARD_SYMMETRIC && multi_shard_ok(s->sh) && (s->user_allreduce || s->comm || s->nranks == 1) &&
+        !(s->user_allgather && !s->user_allreduce)) {
+        // Symmetric shards look ahead like the unsharded queue run: the products of up to 16 queued
+        // cuts in one pass over the local trapezoid, ONE all-reduce of the group's vectors, the group stage on every rank.
+        DeviceGuard guard(s->sh->device);
+        int64_t i = first;
+        if (shard_primed(s, first)) {  // primed and exchanged by an earlier call: that cut by itself
+            rc = ellhip_queue_cut(s->sh, first);
+            if (!rc) rc = ellhip_queue_commit(s->sh, first, -1);
+            if (rc) return rc;
+            i += 1;
+        }
+        if (i < first + count) {
+            s->sh->grp_exchange = &shard_group_exchange;
+            s->sh->grp_exchange_ctx = s;
+            rc = queue_run_multi(s->sh, i, first + count - i);
+            s->sh->grp_exchange = nullptr;
+            s->sh->grp_exchange_ctx = nullptr;
+        }
+        return rc;
+    }
     // pipelined: one pass over the local rows per cut; the collective follows whichever call ran a GEMV
     if (!shard_primed(s, first)) {
         rc = ellhip_queue_prime(s->sh, first);

@@ -183,12 +183,12 @@ int main(int argc, char** argv) {
             timeit(nm, lv, [&] {
                 hipLaunchKernelGGL(k_pack_grads, dim3((unsigned)((n * 16 + 255) / 256)), dim3(256), 0, 0, (const double*)g16, n, lv, n, gT);
                 hipLaunchKernelGGL((k_symm_mfma<true, SEG>), dim3((unsigned)nstrips, (unsigned)nsegs), dim3(256), 0, 0,
-                                   (const double*)Q, ld, n, (const double*)gT, lv, rpm, cpm, rs, cs, (const DevState*)st);
+                                   (const double*)Q, ld, n, 0LL, n, (const double*)gT, lv, rpm, cpm, rs, cs, (const DevState*)st);
             });
             snprintf(nm, sizeof nm, "k_symm_mfma_split alone, %d vectors", lv);
             timeit(nm, lv, [&] {
                 hipLaunchKernelGGL((k_symm_mfma_split<true, SEG>), dim3((unsigned)nstrips, (unsigned)nsegs), dim3(256), 0, 0,
-                                   (const double*)Q, ld, n, (const double*)gT, lv, rpm, cpm, rs, cs, (const DevState*)st);
+                                   (const double*)Q, ld, n, 0LL, n, (const double*)gT, lv, rpm, cpm, rs, cs, (const DevState*)st);
             });
             CK(hipDeviceSynchronize());
             {
@@ -218,7 +218,7 @@ int main(int argc, char** argv) {
             snprintf(nm, sizeof nm, "k_symm_mfma alone, %d vectors", lv);
             timeit(nm, lv, [&] {
                 hipLaunchKernelGGL((k_symm_mfma<true, SEG>), dim3((unsigned)nstrips, (unsigned)nsegs), dim3(256), 0, 0,
-                                   (const double*)Q, ld, n, (const double*)gT, lv, rpm, cpm, rs, cs, (const DevState*)st);
+                                   (const double*)Q, ld, n, 0LL, n, (const double*)gT, lv, rpm, cpm, rs, cs, (const DevState*)st);
             });
             CK(hipDeviceSynchronize());
             double worst = 0.0;
