@@ -162,8 +162,11 @@ __global__ __launch_bounds__(64) void k_group_scalar(int G, const double* __rest
     __shared__ double D[GRP_MAX][GRP_MAX];
     __shared__ double bc[4];  // roo, cnew, kappa | status in s_status
     __shared__ int s_status, s_halt;
+    __shared__ CutParams s_cp[GRP_MAX];  // (one round trip for all of them, not one per cut on the serial path)
     const int lane = threadIdx.x;
     const bool was_halted = st->halted != 0;
+    if (lane < G) s_cp[lane] = cp_dev[lane];
+    const double tol = st->tol;
     if (!was_halted) {
         for (int k = lane; k < G * (NP + 1); k += 64) {
             const int l = k / (NP + 1), c = k - l * (NP + 1);
@@ -197,7 +200,7 @@ __global__ __launch_bounds__(64) void k_group_scalar(int G, const double* __rest
         if (lane == 0) {
             const double tsq = kappa * omega;  // src/ell.rs:105
             Coef cf;
-            const CutParams cp = cp_dev[l];
+            const CutParams cp = s_cp[l];
             const int status = calc.dispatch(cp.kind, cp.b0, cp.has_b1, cp.b1, tsq, cf);  // :106
             st->tsq = tsq;
             st->omega = omega;
@@ -223,7 +226,7 @@ __global__ __launch_bounds__(64) void k_group_scalar(int G, const double* __rest
             q_status[l] = status;
             q_tsq[l] = tsq;
             s_status = status;
-            s_halt = st->halted;
+            s_halt = (status != 0 || tsq < tol) ? 1 : 0;  // what queue_bookkeeping has just stored in st->halted
         }
         __syncthreads();
         if (s_status == ST_SUCCESS) {
