@@ -161,6 +161,11 @@ __global__ __launch_bounds__(64) void k_group_scalar(int G, const double* __rest
     __shared__ double C[GRP_MAX][GRP_MAX];
     __shared__ double D[GRP_MAX][GRP_MAX];
     __shared__ double bc[4];  // roo, cnew, kappa | status in s_status
+    __shared__ double cdv[MAXPEND];
+    // results collected in LDS and stored after the loop: __syncthreads waits for outstanding global stores, and the loop has
+    // two barriers per cut
+    __shared__ double o_cd[GRP_MAX][MAXPEND], o_roo[GRP_MAX], o_cnew[GRP_MAX], o_tsq[GRP_MAX];
+    __shared__ int o_status[GRP_MAX];
     __shared__ int s_status, s_halt;
     __shared__ CutParams s_cp[GRP_MAX];  // (one round trip for all of them, not one per cut on the serial path)
     const int lane = threadIdx.x;
@@ -182,65 +187,126 @@ __global__ __launch_bounds__(64) void k_group_scalar(int G, const double* __rest
     }
     __syncthreads();
     double kappa = st->kappa;
+    const double tsq_in = st->tsq;
     int nok = 0;
+    // what the cuts leave in DevState: kept in lane 0's registers and stored once at the end (a store followed by a load of
+    // the same structure costs the serial path a memory round trip per cut)
+    double f_tsq = tsq_in, f_omega = 0.0, f_roo = 0.0, f_ratio = 0.0;
+    int f_status = ST_SUCCESS, f_apply = 0, f_any = 0, f_stop = STOP_NONE;
+    long long f_niter = 0;
     for (int l = 0; l < G; ++l) {
         const int slot = slot0 + l;  // every earlier cut of the group succeeded, or the queue has halted
         if (s_halt) {
             if (lane == 0) {
-                q_status[l] = ST_UNKNOWN;
-                q_tsq[l] = st->tsq;
+                o_status[l] = ST_UNKNOWN;
+                o_tsq[l] = f_tsq;
             }
             continue;  // (s_halt is not written again: uniform)
         }
         // d_jl of this lane's slot, its correction factor, and omega = g.y - sum_j c_j d_jl^2
         const double dj = lane < slot0 ? B[lane < NP ? lane : 0][l] : (lane < slot ? D[lane - slot0][l] : 0.0);
         const double cd = (lane < slot) ? cc * dj : 0.0;
-        if (lane < MAXPEND) out->cd[l][lane] = cd;
+        if (lane < MAXPEND) {
+            o_cd[l][lane] = cd;
+            cdv[lane] = cd;
+        }
         const double omega = A[l] - wave_allreduce_sum(cd * dj);
         if (lane == 0) {
             const double tsq = kappa * omega;  // src/ell.rs:105
             Coef cf;
             const CutParams cp = s_cp[l];
             const int status = calc.dispatch(cp.kind, cp.b0, cp.has_b1, cp.b1, tsq, cf);  // :106
-            st->tsq = tsq;
-            st->omega = omega;
-            st->status = status;
+            f_any = 1;
+            f_tsq = tsq;
+            f_omega = omega;
+            f_status = status;
             if (status == ST_SUCCESS) {
                 const double roo = cf.rho / omega;     // :112
                 const double cnew = cf.sigma / omega;  // :117
-                out->roo[l] = roo;
-                st->rho_over_omega = roo;
-                st->ratio = cnew;
-                const double knew = kappa * cf.delta;  // :130
-                st->kappa = knew;
-                st->scale = 1.0;
-                st->apply = 1;
-                cpend[slot] = cnew;
-                st->npend = slot + 1;
+                o_roo[l] = roo;
+                o_cnew[l] = cnew;
+                f_roo = roo;
+                f_ratio = cnew;
+                f_apply = 1;
                 bc[1] = cnew;
-                bc[2] = knew;
+                bc[2] = kappa * cf.delta;  // :130
             } else {
-                st->apply = 0;  // :107-109
+                f_apply = 0;  // :107-109
             }
-            queue_bookkeeping(st, status, tsq, 1);
-            q_status[l] = status;
-            q_tsq[l] = tsq;
+            // queue_bookkeeping (src/cutting_plane.rs:222,308)
+            int halt = 0;
+            if (status != 0) {
+                halt = 1;
+                f_stop = STOP_STATUS;
+            } else if (tsq < tol) {
+                halt = 1;  // (this cut's shrink is still recorded)
+                f_stop = STOP_TOL;
+            } else {
+                f_niter += 1;
+            }
+            o_status[l] = status;
+            o_tsq[l] = tsq;
             s_status = status;
-            s_halt = (status != 0 || tsq < tol) ? 1 : 0;  // what queue_bookkeeping has just stored in st->halted
+            s_halt = halt;
         }
         __syncthreads();
         if (s_status == ST_SUCCESS) {
             nok = l + 1;
             kappa = bc[2];
             if (lane == slot) cc = bc[1];
-            // v_l . g_t = y_l . g_t - sum_j cd_j (v_j . g_t) for the cuts t still to come: one wave sum per t
-            for (int t = l + 1; t < G; ++t) {
-                const double djt = lane < slot0 ? B[lane < NP ? lane : 0][t] : (lane < slot ? D[lane - slot0][t] : 0.0);
-                const double sum = wave_allreduce_sum(cd * djt);
-                if (lane == 0) D[l][t] = C[l][t] - sum;
+            // v_l . g_t = y_l . g_t - sum_j cd_j (v_j . g_t) for the cuts t still to come: lane t its own, slots in order
+            if (lane > l && lane < G) {
+                // (the products first, eight LDS reads in flight; then the subtractions in slot order)
+                double d = C[l][lane];
+                int jq = 0;
+                for (; jq + 8 <= slot0; jq += 8) {
+                    double pr[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) pr[u] = cdv[jq + u] * B[jq + u][lane];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) d = d - pr[u];
+                }
+                for (; jq < slot0; ++jq) d = d - cdv[jq] * B[jq][lane];
+                for (; jq + 4 <= slot; jq += 4) {
+                    double pr[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) pr[u] = cdv[jq + u] * D[jq + u - slot0][lane];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) d = d - pr[u];
+                }
+                for (; jq < slot; ++jq) d = d - cdv[jq] * D[jq - slot0][lane];
+                D[l][lane] = d;
             }
         }
         __syncthreads();
+    }
+    __syncthreads();
+    for (int k = lane; k < G * MAXPEND; k += 64) out->cd[k / MAXPEND][k % MAXPEND] = (k / MAXPEND < nok) ? o_cd[k / MAXPEND][k % MAXPEND] : 0.0;
+    if (lane < G) {
+        q_status[lane] = o_status[lane];
+        q_tsq[lane] = o_tsq[lane];
+        if (lane < nok) {
+            out->roo[lane] = o_roo[lane];
+            cpend[slot0 + lane] = o_cnew[lane];
+        }
+    }
+    if (lane == 0 && f_any) {
+        st->tsq = f_tsq;
+        st->omega = f_omega;
+        st->status = f_status;
+        st->apply = f_apply;
+        if (nok > 0) {
+            st->rho_over_omega = f_roo;   // of the last successful cut, as the cut-by-cut stage leaves them
+            st->ratio = f_ratio;
+            st->kappa = kappa;
+            st->scale = 1.0;
+            st->npend = slot0 + nok;
+        }
+        if (f_stop != STOP_NONE) {
+            st->halted = 1;
+            st->stop = f_stop;
+        }
+        st->niter += f_niter;
     }
     if (lane == 0) out->nok = nok;
 }
