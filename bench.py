@@ -609,7 +609,7 @@ def main() -> None:
                     help="pipelined: one pass over Q per update (shrink of cut k fused with the GEMV of cut k+1, "
                          "16*n^2 B); two-pass: GEMV pass + rank-1 pass per update (24*n^2 B). Same results.")
     ap.add_argument("--defer", type=int, choices=[0, 1, 8, 16, 24], default=0,
-                    help="0 (default): 16 where the lower-triangle schedule exists (unsharded n even >= 8192, symmetric "
+                    help="0 (default): 16 where the lower-triangle schedule exists (unsharded n even >= 5120, symmetric "
                          "shards), else 8.  "
                          "8: record cuts and apply them to Q in batches of 8 (GEMV passes are read-only, "
                          "8*n^2*(1+1/8) B per update); 1: rewrite Q at every cut like the reference. Same results "

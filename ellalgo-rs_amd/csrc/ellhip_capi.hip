@@ -62,7 +62,7 @@ struct ProfEvent {
 struct Defaults {
     int auto_defer = 1;        // ELLHIP_OPT_AUTO_DEFER
     int symv = 1;              // ELLHIP_OPT_SYMV
-    long long symv_min_n = 8192;  // ELLHIP_OPT_SYMV_MIN_N
+    long long symv_min_n = 5120;  // ELLHIP_OPT_SYMV_MIN_N
     int apply_lower = 1;       // ELLHIP_OPT_APPLY_LOWER
     int apply_kernel = -1;     // ELLHIP_OPT_APPLY_KERNEL (-1: by depth)
     int fuse_dots = 1;         // ELLHIP_OPT_FUSE_DOTS
@@ -142,7 +142,7 @@ struct ellhip_space {
     hipEvent_t ev_red[2] = {nullptr, nullptr};  // set k is free again (its reduction, and every apply pass before, are done)
     int symv = 1;                    // allow the lower-triangle GEMV in deferred mode (ELLHIP_SYMV=0 disables)
     int symv_rw = 2;
-    long long symv_min_n = 8192;     // below this the full-row pass is faster (few, small triangle tiles)
+    long long symv_min_n = 5120;     // below this the full-row pass wins for synchronous updates (tools/midsize_sweep.py)
     bool shard_symmetric = false;    // row shard whose GEMVs are partial symmetric sums (ellhip_set_shard_symmetric)
     int symv_seg = SYMV_SEG;         // segment width of the lower-triangle GEMV's tiles (see symv_alloc)
     int apply_lower = 1;             // with symv: apply passes touch the lower triangle only (ELLHIP_APPLY_LOWER)
@@ -1103,7 +1103,7 @@ int create_impl(ellhip_space** out, int variant, long long n, long long row0, lo
     rc = write_state(s);
     if (rc) return bail(rc);
     // Default schedule of a new unsharded Ell handle: depth 24 wherever the lower-triangle schedule exists (even
-    // n >= 8192: 4.33 n^2 instead of 24 n^2 bytes per update, the recorded updates applied as one rank-24 update on the
+    // n >= 5120 (ELLHIP_OPT_SYMV_MIN_N): 4.33 n^2 instead of 24 n^2 bytes per update, the recorded updates applied as one rank-24 update on the
     // matrix cores; results within the parity tolerance of depth 1, Q made current for every observer), otherwise the
     // reference's data flow (depth 1).  ELLHIP_OPT_AUTO_DEFER = 0 keeps depth 1 everywhere; ellhip_set_defer_depth overrides either way.  Row shards stay at 1 until their owner chooses.
     // Between 3072 and that size (and for odd n) depth 8 with full-row GEMVs is the faster one, for synchronous calls
@@ -1974,7 +1974,7 @@ int ellhip_set_defer_depth(ellhip_space* s, int depth) {
                                     (s->sharded ? s->shard_symmetric : s->n >= s->symv_min_n);
         if (!lower_schedule)
             return fail(ELLHIP_E_INVALID, "defer depth 16 / 24 needs the lower-triangle schedule: an unsharded handle with n "
-                                          "even and >= 8192, or a symmetric row shard");
+                                          "even and >= ELLHIP_OPT_SYMV_MIN_N (5120 by default), or a symmetric row shard");
     }
     s->defer = depth;
     return 0;

@@ -244,7 +244,7 @@ class Ell(_SpaceBase):
     @property
     def defer_depth(self) -> int:
         """1 = shrink Q at every cut (reference data flow); 8 / 16 = record cuts and apply them in batches.
-        A new handle with even n >= 8192 starts at 16, another one with n >= 3072 at 8 (include/ellhip.h, "deferred
+        A new handle with even n >= 5120 starts at 24, another one with n >= 3072 at 8 (include/ellhip.h, "deferred
         shrink"), anything smaller at 1."""
         return self._lib.ellhip_defer_depth(self._h)
 

@@ -155,7 +155,7 @@ int ellhip_commit(ellhip_space *s, const double *next_grad);
 
 /* ---- deferred shrink: 8 n^2 (1 + 1/8) bytes per update (Ell) -----------------------------------
  * depth = 1: Q is rewritten at every successful cut, exactly as src/ell.rs:117-128 does.  This is what a new handle
- * starts with, EXCEPT an unsharded Ell handle with n >= 3072: it starts at depth 24 when n is even and >= 8192 and
+ * starts with, EXCEPT an unsharded Ell handle with n >= 3072: it starts at depth 24 when n is even and >= 5120 (ELLHIP_OPT_SYMV_MIN_N) and
  * at depth 8 otherwise (the fastest schedules at those sizes; same results to the parity tolerance).
  * ellhip_set_default_option(ELLHIP_OPT_AUTO_DEFER, 0) makes every later handle start at depth 1;
  * ellhip_set_defer_depth(h, 1) does it for one handle.
@@ -168,7 +168,7 @@ int ellhip_commit(ellhip_space *s, const double *next_grad);
  * 1e-10 parity tolerance of depth 1 (gt is the same vector computed in a different order); they are
  * bit-identical across schedules, row partitions and GPU counts for a given depth.  Not used while
  * no_defer_trick is set or before a non-symmetric input matrix has been mirrored.  Ell only.
- * On an unsharded handle (even n >= 8192) depth 8 also computes Q_base*g through the lower triangle only
+ * On an unsharded handle (even n >= 5120) depth 8 also computes Q_base*g through the lower triangle only
  * (every stored element is used for a row sum and a column sum: 4 n^2 bytes per GEMV pass) and applies the
  * recorded updates to the lower triangle only (8 n^2 bytes per 8 updates; the upper half is mirrored back
  * before anything observes Q).  An equal-block row shard keeps the full-row passes, so its bits differ from an
@@ -213,7 +213,8 @@ int ellhip_set_shard_symmetric(ellhip_space *s, int flag);
  *   ELLHIP_OPT_AUTO_DEFER        0 / 1      1        default only: 0 = every new handle starts at depth 1 (the
  *                                                    reference's data flow) instead of 16 / 8 by size
  *   ELLHIP_OPT_SYMV              0 / 1      1        Ell: lower-triangle GEMV on the recorded schedule (4 n^2 bytes)
- *   ELLHIP_OPT_SYMV_MIN_N        >= 512     8192     Ell: smallest n of an unsharded handle that takes it
+ *   ELLHIP_OPT_SYMV_MIN_N        >= 512     5120     Ell: smallest n of an unsharded handle that takes it (synchronous
+ *                                                    updates break even there, queue runs gain 5-8x: tools/midsize_sweep.py)
  *   ELLHIP_OPT_APPLY_LOWER       0 / 1      1        Ell: apply passes touch the lower triangle only (8 n^2 bytes)
  *   ELLHIP_OPT_APPLY_KERNEL      -1 .. 2    -1       Ell, lower-triangle apply pass (-1 = 2 at depth 24, else 1): 2 = k_apply_mfma (the recorded updates as ONE rank-NP
  *                                                    update on the FP64 matrix cores: one rounding per update and element where the
@@ -287,7 +288,7 @@ int ellhip_queue_upload(ellhip_space *s, int64_t k, const int32_t *kinds, const 
 /* Enqueue cuts [first, first+count) on the stream; asynchronous.  ellhip_queue_run uses the
  * two-pass schedule (GEMV pass + rank-1 pass per cut); ellhip_queue_run_fused the pipelined one
  * (one pass per cut: the shrink of cut i fused with the GEMV of cut i+1). Same results.
- * On a handle that records its updates (lower-triangle schedule: unsharded, even n >= 8192 by default)
+ * On a handle that records its updates (lower-triangle schedule: unsharded, even n >= 5120 by default)
  * ellhip_queue_run_fused also uses that the queue holds the NEXT gradients: the products Q_base g of up to
  * ELLHIP_OPT_LOOKAHEAD consecutive queued cuts are formed in one pass over the matrix and their scalar stages run as
  * one group ("options" above; results to ~1e-15 of the cut-by-cut schedules, to the bit for LOOKAHEAD <= 3).  It may

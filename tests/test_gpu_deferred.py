@@ -25,7 +25,7 @@ def test_deferred_mixed_sequence_matches_oracle(gpu, orc, n):
 
 @pytest.mark.parametrize("n", [512, 1000, 2112, 4096])
 def test_deferred_symv_mixed_sequence_matches_oracle(gpu, orc, n, monkeypatch):
-    """Depth 8 with the lower-triangle GEMV forced on at small sizes (default threshold n >= 8192)."""
+    """Depth 8 with the lower-triangle GEMV forced on at small sizes (default threshold n >= 5120)."""
     set_default("SYMV_MIN_N", 512)
     xc0 = np.linspace(-1.0, 1.0, n)
     g = gpu.Ell.new_with_scalar(2.0, xc0)
@@ -260,11 +260,13 @@ def test_apply_kernels_agree_bit_for_bit(gpu, monkeypatch):
 
 
 def test_default_depth_of_new_handles(gpu, monkeypatch):
-    """ellhip_create: depth 16 wherever the lower-triangle schedule exists (unsharded Ell, even n >= 8192), depth 8
+    """ellhip_create: depth 24 wherever the lower-triangle schedule exists (unsharded Ell, even n >= 5120), depth 8
     for other n >= 3072, else the reference's data flow; ELLHIP_OPT_AUTO_DEFER = 0 keeps depth 1 everywhere; clones
     inherit; the setter overrides."""
     assert gpu.Ell.new_with_scalar(1.0, np.zeros(2048)).defer_depth == 1
-    assert gpu.Ell.new_with_scalar(1.0, np.zeros(4096)).defer_depth == 8      # 3072 <= n < 8192: full-row GEMVs, depth 8
+    assert gpu.Ell.new_with_scalar(1.0, np.zeros(4096)).defer_depth == 8      # 3072 <= n < 5120: full-row GEMVs, depth 8
+    assert gpu.Ell.new_with_scalar(1.0, np.zeros(5118)).defer_depth == 8
+    assert gpu.Ell.new_with_scalar(1.0, np.zeros(5120)).defer_depth == 24     # the threshold (tools/midsize_sweep.py)
     assert gpu.Ell.new_with_scalar(1.0, np.zeros(8191)).defer_depth == 8      # odd n: no 16-byte pairs, no lower schedule
     e = gpu.Ell.new_with_scalar(1.0, np.zeros(8192))
     assert e.defer_depth == 24 and e.clone().defer_depth == 24
