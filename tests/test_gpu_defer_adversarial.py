@@ -22,6 +22,7 @@ pytestmark = pytest.mark.gpu
 
 FACTOR = 2.0     # default-depth error may exceed the depth-1 error by at most this factor ...
 FLOOR = 1e-10    # ... unless it is within the north-star tolerance anyway
+FACTOR_QUEUE = 4.0   # the same bound for the queue replay with lookahead 16 (groups of cuts, Gram-matrix recurrence)
 
 
 def _errs(e, o):
@@ -42,6 +43,7 @@ def _drive(gpu, orc, n, cuts, make_cut, seed):
     assert depth in (8, 24), depth          # what a new handle of this size starts with
     worst = {"tsq1": 0.0, "tsqd": 0.0}
     state = {}
+    rec = {"kinds": [], "grads": [], "b0": [], "b1": [], "status": [], "tsq": []}
     for k in range(cuts):
         g = make_cut.grad(k, rng, state)
         tau = float(np.sqrt(max(o.kappa * float(g @ (o.mq @ g)), 0.0)))
@@ -51,6 +53,8 @@ def _drive(gpu, orc, n, cuts, make_cut, seed):
         s1 = int(e1._update(kind, (g, beta)))
         sd = int(ed._update(kind, (g, beta)))
         assert so == s1 == sd, f"cut {k}: status oracle={so} depth1={s1} depth{depth}={sd}"
+        rec["kinds"].append(kind), rec["grads"].append(g), rec["b0"].append(float(b0))
+        rec["b1"].append(np.nan if b1 is None else float(b1)), rec["status"].append(so), rec["tsq"].append(o.tsq)
         if abs(o.tsq) > 0:
             worst["tsq1"] = max(worst["tsq1"], abs(e1.tsq() - o.tsq) / abs(o.tsq))
             worst["tsqd"] = max(worst["tsqd"], abs(ed.tsq() - o.tsq) / abs(o.tsq))
@@ -59,6 +63,21 @@ def _drive(gpu, orc, n, cuts, make_cut, seed):
     print(f"\n  n={n} depth {depth}: depth-1 errors {a1}\n  {'':>{len(str(n)) + 9}}depth-{depth} errors {ad}")
     for key in a1:
         assert ad[key] <= max(FACTOR * a1[key], FLOOR), (key, ad[key], a1[key])
+    if depth == 24 and n % 64 == 0:
+        # The recorded sequence once more as a QUEUE run: the products of up to 16 of these nearly parallel gradients in one
+        # pass on the matrix cores, and their dot products with the vectors the group itself records through the Gram-matrix
+        # recurrence (csrc/group_kernels.hpp) -- the cancellation-prone place, were there one.
+        eq = gpu.Ell.new_with_scalar(1.0, np.zeros(n))
+        assert eq.defer_depth == 24 and eq.get_option(gpu.capi.OPT_LOOKAHEAD) == 16
+        eq.queue_upload(np.array(rec["kinds"], dtype=np.int32), np.array(rec["grads"]), np.array(rec["b0"]), np.array(rec["b1"]))
+        eq.queue_run(0, cuts, fused=True)
+        st, ts = eq.queue_results()
+        assert list(st) == rec["status"]
+        aq = _errs(eq, o)
+        aq["tsq"] = float(np.max(np.abs(ts - np.array(rec["tsq"])) / np.abs(np.array(rec["tsq"]))))
+        print(f"  {'':>{len(str(n)) + 9}}queue run, lookahead 16: errors {aq}")
+        for key in a1:
+            assert aq[key] <= max(FACTOR_QUEUE * a1[key], FLOOR), ("queue", key, aq[key], a1[key])
     return a1, ad
 
 
