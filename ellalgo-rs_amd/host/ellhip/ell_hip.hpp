@@ -105,6 +105,40 @@ class SpaceHip {
     void set_defer_depth(int depth) { check(ellhip_set_defer_depth(h_, depth), "ellhip_set_defer_depth"); }
     int defer_depth() const { return ellhip_defer_depth(h_); }
     void flush() { check(ellhip_flush(h_), "ellhip_flush"); }
+    // options (include/ellhip.h, "options": ELLHIP_OPT_LOOKAHEAD, ELLHIP_OPT_RESIDENT, ...)
+    void set_option(int key, long long value) { check(ellhip_set_option(h_, key, (int64_t)value), "ellhip_set_option"); }
+    long long option(int key) const {
+        int64_t v = 0;
+        check(ellhip_get_option(h_, key, &v), "ellhip_get_option");
+        return (long long)v;
+    }
+    // a recorded cut sequence replayed from device memory (ellhip_queue_*): `grads` holds k gradients of ndim() each,
+    // beta1[i] = NaN for a single cut.  run() takes the pipelined schedule, which looks ahead in the queue where the
+    // handle records its updates; results() returns every cut's CutStatus (3 = not run: the
+    // queue halted before it, src/cutting_plane.rs:222,308) and tsq.
+    void queue_upload(const std::vector<int32_t>& kinds, const Arr& grads, const Arr& beta0, const Arr& beta1) {
+        const std::size_t k = kinds.size();
+        if (grads.size() != k * n_ || beta0.size() != k || beta1.size() != k)
+            throw Error(ELLHIP_E_INVALID, "queue_upload: array sizes do not match");
+        std::vector<int32_t> has(k);
+        Arr b1(k);
+        for (std::size_t i = 0; i < k; ++i) {
+            has[i] = beta1[i] == beta1[i] ? 1 : 0;
+            b1[i] = has[i] ? beta1[i] : 0.0;
+        }
+        check(ellhip_queue_upload(h_, (int64_t)k, kinds.data(), grads.data(), beta0.data(), has.data(), b1.data()),
+              "ellhip_queue_upload");
+        qk_ = k;
+    }
+    void queue_run(std::size_t first, std::size_t count) {
+        check(ellhip_queue_run_fused(h_, (int64_t)first, (int64_t)count), "ellhip_queue_run_fused");
+    }
+    std::pair<std::vector<int32_t>, Arr> queue_results() {
+        std::vector<int32_t> st(qk_);
+        Arr ts(qk_);
+        check(ellhip_queue_results(h_, st.data(), ts.data()), "ellhip_queue_results");
+        return {st, ts};
+    }
     long long queue_primed() const { return ellhip_queue_primed(h_); }
     std::size_t ndim() const { return n_; }
     ellhip_space* handle() { return h_; }
@@ -123,6 +157,7 @@ class SpaceHip {
 
     ellhip_space* h_ = nullptr;
     std::size_t n_ = 0;
+    std::size_t qk_ = 0;
 };
 
 using EllHip = SpaceHip<ELLHIP_SPACE_ELL>;

@@ -70,8 +70,56 @@ static std::pair<std::optional<Arr>, std::size_t> run_feas(Oracle& omega, Space&
     return cutting_plane_feas(omega, space, opt);
 }
 
+#ifdef BACKEND_HIP
+// --queue-replay: a recorded cut sequence through EllHip::queue_upload / queue_run / queue_results (the pipelined queue
+// run with its lookahead) against the same cuts taken one ellhip_update at a time on a second handle
+static int queue_replay() {
+    const size_t n = 1024, k = 40;
+    ellhip_set_default_option(ELLHIP_OPT_SYMV_MIN_N, 512);  // (so that this small handle records its updates and looks ahead)
+    ellhip_set_default_option(ELLHIP_OPT_RESIDENT, 0);
+    Arr xc0(n, 0.0);
+    ellhip::EllHip a = ellhip::EllHip::new_with_scalar(1.0, xc0), b = ellhip::EllHip::new_with_scalar(1.0, xc0);
+    std::vector<int32_t> kinds(k, 0);
+    Arr grads(k * n), b0(k), b1(k);
+    unsigned long long h = 88172645463325252ULL;
+    for (size_t i = 0; i < k; ++i) {
+        double nrm = 0.0;
+        for (size_t j = 0; j < n; ++j) {
+            h ^= h << 13, h ^= h >> 7, h ^= h << 17;
+            grads[i * n + j] = (double)(h >> 11) / 9007199254740992.0 - 0.5;
+            nrm += grads[i * n + j] * grads[i * n + j];
+        }
+        for (size_t j = 0; j < n; ++j) grads[i * n + j] /= std::sqrt(nrm);
+        b0[i] = 0.01;
+        b1[i] = (i % 2) ? 0.2 : std::numeric_limits<double>::quiet_NaN();  // parallel cuts alternate with deep cuts
+    }
+    a.queue_upload(kinds, grads, b0, b1);
+    a.queue_run(0, 17);
+    a.queue_run(17, k - 17);
+    auto [st, ts] = a.queue_results();
+    double worst = 0.0;
+    bool ok = a.option(ELLHIP_OPT_LOOKAHEAD) == 16 && a.defer_depth() == 24;
+    for (size_t i = 0; i < k; ++i) {
+        Arr g(grads.begin() + i * n, grads.begin() + (i + 1) * n);
+        CutStatus s = (i % 2) ? b.update_bias_cut(std::make_pair(g, ParallelCut{b0[i], std::optional<double>(b1[i])}))
+                              : b.update_bias_cut(std::make_pair(g, SingleCut{b0[i]}));
+        ok = ok && s == CutStatus::Success && st[i] == 0;
+        worst = std::max(worst, std::fabs(ts[i] - b.tsq()) / b.tsq());
+    }
+    Arr xa = a.xc(), xb = b.xc();
+    for (size_t j = 0; j < n; ++j) worst = std::max(worst, std::fabs(xa[j] - xb[j]));
+    worst = std::max(worst, std::fabs(a.kappa() - b.kappa()) / b.kappa());
+    printf("{\"case\": \"queue_replay\", \"ok\": %s, \"worst\": %.3e}\n", ok ? "true" : "false", worst);
+    return 0;
+}
+#endif
+
 int main(int argc, char** argv) {
     bool with_stable = true;
+#ifdef BACKEND_HIP
+    for (int i = 1; i < argc; ++i)
+        if (std::string(argv[i]) == "--queue-replay") return queue_replay();
+#endif
     for (int i = 1; i < argc; ++i) {
         if (std::string(argv[i]) == "--no-stable") with_stable = false;
         if (std::string(argv[i]) == "--pipelined") g_pipelined = true;

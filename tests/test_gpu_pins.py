@@ -73,3 +73,10 @@ def test_solutions_match_oracle_backend(results, results_oracle):
             np.testing.assert_allclose(got["x"], want["x"], rtol=1e-9, atol=1e-12, err_msg=case)
         if want["gamma"]:
             assert abs(got["gamma"] - want["gamma"]) <= 1e-9 * abs(want["gamma"]), case
+
+
+def test_cpp_host_queue_replay(gpu):
+    """EllHip::queue_upload / queue_run / queue_results (host/ellhip/ell_hip.hpp): a recorded cut sequence through the
+    pipelined queue run (lookahead 16, groups on the matrix cores) against the same cuts taken one update at a time."""
+    out = run_json_lines(build_runner("pins_runner.cpp", "hip"), "--queue-replay")["queue_replay"]
+    assert out["ok"] is True and out["worst"] <= 1e-12, out
