@@ -472,7 +472,7 @@ def ell_bytes_per_update(n2w: float, sched: str, dep: int, steps: int, symv_mode
 
 # the BASELINE.json configurations besides the headline one, with the brief (steps, warmup, profile steps) they are run
 # at inside the default invocation so that the driver's one line carries all of them
-BRIEF_CONFIGS = [("n4096-deep", 200, 20, 40), ("n32768-deep", 64, 16, 16), ("n16384-ellstable", 48, 8, 16)]
+BRIEF_CONFIGS = [("n4096-deep", 200, 20, 40), ("n32768-deep", 96, 16, 16), ("n16384-ellstable", 48, 8, 16)]
 
 
 def symv_kernel_name(pkg, space, symv_mode: bool, n: int, fused: bool = True) -> str:
