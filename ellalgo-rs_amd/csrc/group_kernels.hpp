@@ -1,6 +1,7 @@
 // group_kernels.hpp -- the scalar stage of a GROUP of queued cuts whose products y_l = Q_base g_l came out of one pass
-// (k_symm_mfma, ELLHIP_OPT_LOOKAHEAD > 3): three n-parallel launches and one small serial one per group instead of a
-// reduction and a scalar stage per cut.
+// (k_symm_mfma, ELLHIP_OPT_LOOKAHEAD > 3): four parallel launches and one one-wave recurrence per group (k_group_reduce,
+// k_group_gram, k_group_sums, k_group_scalar, k_group_apply; for a row shard k_group_dots after the owner's all-reduce)
+// instead of a reduction and a scalar stage per cut.
 //
 // What Ell::update_core needs per cut (src/ell.rs:97-137 on the recorded schedule, ell_kernels.hpp "Deferred rank-1
 // updates"):   gt_l = y_l - sum_j (c_j d_jl) v_j,   omega_l = g_l.y_l - sum_j c_j d_jl^2,   d_jl = v_j . g_l
@@ -10,7 +11,7 @@
 //     v_m . g_l = y_m . g_l - sum_{j before m} (c_j d_jm) (v_j . g_l)
 // so with   A_l  = g_l . y_l,   B_jl = v_j . g_l (j recorded before the group),   C_ml = y_m . g_l (m < l)
 // (all n-length dot products of vectors that exist when the group starts: k_group_reduce, k_group_gram) the whole chain
-// of omegas, EllCalc coefficients and correction factors is O(G^2 NP) scalar work (k_group_scalar, one workgroup), and
+// of omegas, EllCalc coefficients and correction factors is O(G^2 NP) scalar work (k_group_scalar, one wave), and
 // the vectors follow in one elementwise pass (k_group_apply).  The matrix-core products differ from the vector-ALU
 // schedules by a few ulp already; this stage adds the rounding of the recurrence above (same size: every term is a dot
 // product of the same vectors), far inside the 1e-10 contract and not bit-identical to the per-cut stage.
