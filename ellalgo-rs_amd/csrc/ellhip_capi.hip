@@ -1289,21 +1289,48 @@ bool multi_shard_ok(const ellhip_space* s) {
            (s->row0 % 64) == 0 && ((s->row0 + s->nrows) % 64 == 0 || s->row0 + s->nrows == s->n);
 }
 
+constexpr int MULTI_NO_MEMORY = 1;  // multi_setup: the buffers do not fit; the handle has been switched to lookahead 1
+
+void multi_free(ellhip_space* s) {
+    double** bufs[] = {&s->d_rowpart_m, &s->d_colpart_m, &s->d_gT, &s->d_grpY, &s->d_gpart, &s->d_cpart, &s->d_gsums};
+    for (double** b : bufs) {
+        if (*b) (void)hipFree(*b);
+        *b = nullptr;
+    }
+    if (s->d_gout) (void)hipFree(s->d_gout);
+    s->d_gout = nullptr;
+}
+
+// The group runs' buffers: 2 x 16 sets of partial sums are 2.2 n^2 / 64 x 32 = 1.1 n^2 doubles-worth of memory beside
+// the matrix' n^2 (4.4 GB at n = 32768).  When they do not fit, the handle continues with one product per pass
+// (returns MULTI_NO_MEMORY once; ELLHIP_OPT_LOOKAHEAD reads 1 afterwards): slower, not an error.
 int multi_setup(ellhip_space* s) {
     if (s->d_rowpart_m) return 0;
+    const size_t nb = (size_t)((s->n + 127) / 128);
     // two halves of MULTI_MAX sets each (and of the packed gradients): the next group's products are formed on the second
     // stream while this group's stage reads the other half
-    HIPCHK(hipMalloc(&s->d_rowpart_m, (size_t)2 * MULTI_MAX * rowpart_elems(s) * sizeof(double)));
-    HIPCHK(hipMalloc(&s->d_colpart_m, (size_t)2 * MULTI_MAX * colpart_elems(s) * sizeof(double)));
-    HIPCHK(hipMemsetAsync(s->d_rowpart_m, 0, (size_t)2 * MULTI_MAX * rowpart_elems(s) * sizeof(double), s->stream));
-    HIPCHK(hipMemsetAsync(s->d_colpart_m, 0, (size_t)2 * MULTI_MAX * colpart_elems(s) * sizeof(double), s->stream));
-    HIPCHK(hipMalloc(&s->d_gT, (size_t)2 * s->n * SMM_NV * sizeof(double)));
-    const size_t nb = (size_t)((s->n + 127) / 128);
-    HIPCHK(hipMalloc(&s->d_grpY, (size_t)GRP_MAX * (size_t)s->n * sizeof(double)));
-    HIPCHK(hipMalloc(&s->d_gpart, (size_t)GRP_MAX * nb * (MAXPEND + 1) * sizeof(double)));
-    HIPCHK(hipMalloc(&s->d_cpart, nb * GRP_MAX * GRP_MAX * sizeof(double)));
-    HIPCHK(hipMalloc(&s->d_gout, sizeof(GroupOut)));
-    HIPCHK(hipMalloc(&s->d_gsums, (size_t)(GRP_MAX * (MAXPEND + 1) + GRP_MAX * GRP_MAX) * sizeof(double)));
+    const size_t rbytes = (size_t)2 * MULTI_MAX * rowpart_elems(s) * sizeof(double);
+    const size_t cbytes = (size_t)2 * MULTI_MAX * colpart_elems(s) * sizeof(double);
+    hipError_t e = hipMalloc(&s->d_rowpart_m, rbytes);
+    if (e == hipSuccess) e = hipMalloc(&s->d_colpart_m, cbytes);
+    if (e == hipSuccess) e = hipMalloc(&s->d_gT, (size_t)2 * s->n * SMM_NV * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc(&s->d_grpY, (size_t)GRP_MAX * (size_t)s->n * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc(&s->d_gpart, (size_t)GRP_MAX * nb * (MAXPEND + 1) * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc(&s->d_cpart, nb * GRP_MAX * GRP_MAX * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc(&s->d_gout, sizeof(GroupOut));
+    if (e == hipSuccess) e = hipMalloc(&s->d_gsums, (size_t)(GRP_MAX * (MAXPEND + 1) + GRP_MAX * GRP_MAX) * sizeof(double));
+    if (e == hipErrorOutOfMemory) {
+        (void)hipGetLastError();
+        multi_free(s);
+        s->lookahead = 1;
+        return MULTI_NO_MEMORY;
+    }
+    if (e != hipSuccess) {
+        multi_free(s);
+        return fail(ELLHIP_E_HIP, "hipMalloc (group-run buffers)", e);
+    }
+    HIPCHK(hipMemsetAsync(s->d_rowpart_m, 0, rbytes, s->stream));
+    HIPCHK(hipMemsetAsync(s->d_colpart_m, 0, cbytes, s->stream));
     HIPCHK(hipMemsetAsync(s->d_gout, 0, sizeof(GroupOut), s->stream));
     return 0;
 }
@@ -1396,7 +1423,7 @@ void symv_multi_go(ellhip_space* s, const double* g_dev) {
 
 int queue_run_multi(ellhip_space* s, long long first, long long count) {
     int rc = multi_setup(s);
-    if (rc) return rc;
+    if (rc) return rc;  // (MULTI_NO_MEMORY: the caller goes on with the schedules that need no extra buffers)
     const long long end = first + count;
     if (s->sharded && (s->primed || !s->grp_exchange))
         return fail(ELLHIP_E_STATE, "group run of a row shard: the owner takes a primed cut by itself and supplies the collective");
@@ -2275,7 +2302,10 @@ int ellhip_queue_run_fused(ellhip_space* s, int64_t first, int64_t count) {
     if (!s || first < 0 || count < 0 || first + count > s->qk) return fail(ELLHIP_E_INVALID, "queue range");
     DeviceGuard guard(s->device);
     if (resident_ok(s, count)) return resident_run(s, first, count);
-    if (multi_ok(s)) return queue_run_multi(s, first, count);
+    if (multi_ok(s)) {
+        const int mrc = queue_run_multi(s, first, count);
+        if (mrc != MULTI_NO_MEMORY) return mrc;
+    }
     if (overlap_ok(s)) return queue_run_overlapped(s, first, count);
     for (int64_t i = first; i < first + count; ++i) {
         int rc = queue_prime_impl(s, i);  // (pipelined form: only the first cut of a run pays a separate GEMV pass)

@@ -394,9 +394,17 @@ int ellhip_sharded_queue_run_fused(ellhip_sharded* s, int64_t first, int64_t cou
             rc = queue_run_multi(s->sh, i, first + count - i);
             s->sh->grp_exchange = nullptr;
             s->sh->grp_exchange_ctx = nullptr;
+            if (rc == MULTI_NO_MEMORY) {  // (every rank allocates the same sizes: the same decision everywhere)
+                const int64_t end = first + count;
+                first = i;
+                count = end - i;
+                rc = 0;
+                goto cut_by_cut;
+            }
         }
         return rc;
     }
+cut_by_cut:
     // pipelined: one pass over the local rows per cut; the collective follows whichever call ran a GEMV
     if (!shard_primed(s, first)) {
         rc = ellhip_queue_prime(s->sh, first);

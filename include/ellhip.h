@@ -238,7 +238,9 @@ int ellhip_set_shard_symmetric(ellhip_space *s, int flag);
  *                                                    cores, y differs by a few ulp from the other schedules (own
  *                                                    association; inside the 1e-10 contract).  Only a queue knows the
  *                                                    next gradients: ellhip_update and the prime / cut / commit calls are
- *                                                    unaffected
+ *                                                    unaffected.  The group runs need 1.1 n^2 doubles of extra device
+ *                                                    memory (2 x 16 sets of partial sums); a handle for which that does not
+ *                                                    fit continues with 1 (and reports 1 here)
  *   ELLHIP_OPT_QUEUE_DEPTH       0 / 48     48       Ell, depth 24, LOOKAHEAD > 3: inside one ellhip_queue_run_fused call the
  *                                                    recorded updates may pile up to 48 before an apply pass (the group
  *                                                    stage is sized for it): half as many apply passes; on return fewer
