@@ -1019,6 +1019,15 @@ def main() -> None:
         pass
     upd_gbps = bytes_update / (ms_per_step * 1e-3) / 1e9
     roofline["per_kernel"] = per_kernel
+    if roofline.get("kernel") == "k_symm_mfma":
+        # the pass is not a pure stream: 32 v_mfma_f64_16x16x4_f64 per 16 x 64 block of Q (two products of the block with
+        # 16 gradients, padded), 64 cycles each on one SIMD = the FP64 vector-FMA rate: 78.6 TFLOP/s on 1024 SIMDs at 2.4 GHz
+        mf = 32.0 * n2w
+        roofline["matrix_pipe"] = {"flop_per_launch": mf, "peak_TFLOPs": 78.6,
+                                   "achieved_TFLOPs": mf / (roofline["avg_launch_ms"] * 1e-3) / 1e12,
+                                   "frac": mf / (roofline["avg_launch_ms"] * 1e-3) / 1e12 / 78.6,
+                                   "note": "HBM time and matrix-pipe time of this kernel add up rather than overlap "
+                                           "(DESIGN.md 3.6): read frac and matrix_pipe.frac together"}
     if prof_iso:
         iso = kernel_table(prof_iso)
         roofline["per_kernel_isolated"] = iso
