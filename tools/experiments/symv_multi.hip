@@ -13,6 +13,7 @@
 
 #include "../../ellalgo-rs_amd/csrc/ell_kernels.hpp"
 #include "symm_split_kernel.hpp"
+#include "symm32_kernel.hpp"
 
 using namespace ellhip;
 
@@ -188,7 +189,7 @@ int main(int argc, char** argv) {
             snprintf(nm, sizeof nm, "k_symm_mfma_split alone, %d vectors", lv);
             timeit(nm, lv, [&] {
                 hipLaunchKernelGGL((k_symm_mfma_split<true, SEG>), dim3((unsigned)nstrips, (unsigned)nsegs), dim3(256), 0, 0,
-                                   (const double*)Q, ld, n, 0LL, n, (const double*)gT, lv, rpm, cpm, rs, cs, (const DevState*)st);
+                                   (const double*)Q, ld, n, (const double*)gT, lv, rpm, cpm, rs, cs, (const DevState*)st);
             });
             CK(hipDeviceSynchronize());
             {
@@ -242,6 +243,53 @@ int main(int argc, char** argv) {
             }
             printf("   check: partial sums of %d vectors vs k_symv, max |diff| / max |value| = %.3e %s\n", lv, worst,
                    worst < 1e-13 ? "ok" : "WRONG");
+        }
+    }
+    // ---- 32 gradients per pass (two N-tiles)
+    {
+        constexpr int SEG = 2048;
+        const long long nsegs = (n + SEG - 1) / SEG;
+        const long long rs = nsegs * n;
+        const int NV = 32;
+        double *g32, *gT, *rpm, *cpm;
+        CK(hipMalloc(&g32, (size_t)NV * n * 8));
+        CK(hipMalloc(&gT, (size_t)NV * n * 8));
+        CK(hipMalloc(&rpm, (size_t)NV * rs * 8));
+        CK(hipMalloc(&cpm, (size_t)NV * cs * 8));
+        hipLaunchKernelGGL(k_fill_vec, dim3(256), dim3(256), 0, 0, g32, (long long)NV * n);
+        hipLaunchKernelGGL(k_scale_vec, dim3(256), dim3(256), 0, 0, g32, (long long)NV * n);
+        CK(hipMemset(rpm, 0, (size_t)NV * rs * 8));
+        CK(hipMemset(cpm, 0, (size_t)NV * cs * 8));
+        std::vector<double> a((size_t)std::max(rs, cs)), b((size_t)std::max(rs, cs));
+        for (int lv : {32, 20}) {
+            char nm[64];
+            hipLaunchKernelGGL(k_pack_grads32, dim3((unsigned)((n * 32 + 255) / 256)), dim3(256), 0, 0, (const double*)g32, n, lv, n, gT);
+            snprintf(nm, sizeof nm, "k_symm_mfma32 alone, %d vectors", lv);
+            timeit(nm, lv, [&] {
+                hipLaunchKernelGGL((k_symm_mfma32<true, SEG>), dim3((unsigned)nstrips, (unsigned)nsegs), dim3(256), 0, 0,
+                                   (const double*)Q, ld, n, (const double*)gT, lv, rpm, cpm, rs, cs, (const DevState*)st);
+            });
+            CK(hipDeviceSynchronize());
+            double worst = 0.0;
+            for (int l : {0, 7, 16, lv - 1}) {
+                CK(hipMemset(rp1, 0, (size_t)rs * 8));
+                CK(hipMemset(cp1, 0, (size_t)cs * 8));
+                hipLaunchKernelGGL((k_symv<2, true, 0, SEG>), dim3((unsigned)nstrips, (unsigned)nsegs), dim3(256), 0, 0,
+                                   (const double*)Q, ld, n, 0LL, n, (const double*)(g32 + l * n), rp1, cp1, (const DevState*)st);
+                CK(hipDeviceSynchronize());
+                for (int which = 0; which < 2; ++which) {
+                    const long long m = which ? cs : rs;
+                    CK(hipMemcpy(a.data(), (which ? cpm + l * cs : rpm + l * rs), (size_t)m * 8, hipMemcpyDeviceToHost));
+                    CK(hipMemcpy(b.data(), which ? cp1 : rp1, (size_t)m * 8, hipMemcpyDeviceToHost));
+                    double mx = 0.0, df = 0.0;
+                    for (long long i = 0; i < m; ++i) {
+                        mx = std::max(mx, std::fabs(b[i]));
+                        df = std::max(df, std::fabs(a[i] - b[i]));
+                    }
+                    worst = std::max(worst, df / mx);
+                }
+            }
+            printf("   check (32): max |diff| / max |value| = %.3e %s\n", worst, worst < 1e-13 ? "ok" : "WRONG");
         }
     }
     return 0;
