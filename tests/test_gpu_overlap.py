@@ -11,6 +11,8 @@ schedule: src/ell.rs:117-128 is deferred), so
 The vector-ALU forms are bit-identical to the serial order (LOOKAHEAD 1, OVERLAP 0), the matrix-core form agrees with it to
 1e-12, through apply passes, runs in pieces, flushes, direct updates in between, a failing cut, observers; all within the
 north-star tolerance of the oracle."""
+import os
+
 import numpy as np
 import pytest
 
@@ -138,7 +140,7 @@ def test_overlapped_run_at_the_default_size_and_depth(gpu):
     assert prof["symv_reduce"][1] == 4 and prof["symv"][1] == 4 and prof["apply"][1] == 2
 
 
-@pytest.mark.parametrize("seed", range(24))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("ELLHIP_FUZZ_OPTION_SEEDS", "24"))))   # (soak: ELLHIP_FUZZ_OPTION_SEEDS=400)
 def test_random_option_mixes_against_the_oracle(gpu, orc, seed):
     """Seeded walks over what the queue run can be asked to do: size (multiples of 64 and not, both segment widths), depth,
     LOOKAHEAD / QUEUE_DEPTH / OVERLAP, the run cut into random pieces with direct updates, flushes, option switches and
