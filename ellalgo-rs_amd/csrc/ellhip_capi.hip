@@ -1488,6 +1488,12 @@ int queue_run_multi(ellhip_space* s, long long first, long long count) {
                 if (rem2 > cap2 && rem2 < 2 * cap2) g2 = (rem2 + 1) / 2;  // (the rule the next trip of the loop applies)
             }
             if (use_side && g2 >= 2) {
+                // The products issued ahead follow EVERYTHING enqueued on the handle's stream so far: the last reduction that
+                // read the other half of the sets, and whatever wrote Q -- an apply pass of this loop, of the single-cut
+                // path (a cut taken by itself when one slot was left), or of ensure_committed.  (A soak run of
+                // tests/test_gpu_overlap.py found the single-cut path's apply pass missing from an event recorded earlier:
+                // 8 of 400 seeded walks off by 1e-3.)
+                HIPCHK(hipEventRecord(s->ev_red[half ^ 1], s->stream));
                 HIPCHK(hipStreamWaitEvent(s->symv_stream, s->ev_red[half ^ 1], 0));
                 rc = symm_go(s, qgrad(s, i2), (int)g2, s->symv_stream, half ^ 1);
                 if (rc) return rc;
