@@ -11,9 +11,10 @@ LIB_PATH = os.path.join(PKG_DIR, "libellhip.so")
 REPO_ROOT = os.path.dirname(PKG_DIR)
 
 SOURCES = ["ellhip_capi.hip"]
-HEADERS = ["ell_kernels.hpp", "ellstable_kernels.hpp", "ellcalc_device.hpp", "lowpass_kernels.hpp",
-           "lowpass_capi.inc.hpp", "batch_kernels.hpp", "batch_capi.inc.hpp", "lmi_kernels.hpp",
-           "lmi_capi.inc.hpp", "sharded_capi.inc.hpp"]
+# every header under csrc/ is a dependency of the one translation unit (tests/test_build_recipe.py checks that each
+# `#include "..."` reachable from SOURCES is in this list, so an edited header can never ship a stale libellhip.so)
+HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith(".hpp"))
+PUBLIC_HEADERS = sorted(f for f in os.listdir(os.path.join(REPO_ROOT, "include")) if f.endswith(".h"))
 
 # -ffp-contract=off: the reference never fuses a*b+c (two roundings per multiply-add); keeping
 # that makes the rank-1 pass bit-identical to the CPU arithmetic for the same gt.
@@ -32,7 +33,7 @@ def needs_build() -> bool:
     if not os.path.exists(LIB_PATH):
         return True
     t = os.path.getmtime(LIB_PATH)
-    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS] + [os.path.join(REPO_ROOT, "include", f) for f in ("ellhip.h", "ellhip_lowpass.h", "ellhip_batch.h", "ellhip_lmi.h", "ellhip_sharded.h")]
+    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS] + [os.path.join(REPO_ROOT, "include", f) for f in PUBLIC_HEADERS]
     return any(os.path.getmtime(d) > t for d in deps)
 
 

@@ -1432,6 +1432,8 @@ int queue_run_multi(ellhip_space* s, long long first, long long count) {
     // this function has fewer recorded than the depth again.
     const bool deep_ok = multi_mfma(s) && s->defer == 24 && s->apply_lower && s->queue_depth > s->defer;
     const int qdepth = deep_ok ? s->queue_depth : s->defer;
+    if (qdepth != 8 && qdepth != 16 && qdepth != 24 && qdepth != MAXPEND)  // (the group kernels' slot counts; pend / cpend hold MAXPEND)
+        return fail(ELLHIP_E_STATE, "queue run: recorded-update depth must be 8, 16, 24 or 48");
     // (measured: +1.5 % / +8 % at n = 16384 for 200 / 20 cuts per run, -3 % at n = 32768, where stretching a 1.1 ms pass
     // costs more than hiding a 0.4 ms stage saves)
     const bool use_side = multi_mfma(s) && s->overlap != 0 && s->n <= 24576 && !s->sharded;
@@ -1506,9 +1508,9 @@ int queue_run_multi(ellhip_space* s, long long first, long long count) {
             drop_prime(s);
             s->dots_np = 0;
             hipEvent_t ev = use_side ? s->ev_red[half] : nullptr;
-            rc = qdepth == 48 ? group_stage_go<48>(s, i, (int)g, half, ev)
-               : s->defer == 24 ? group_stage_go<24>(s, i, (int)g, half, ev)
-               : s->defer == 16 ? group_stage_go<16>(s, i, (int)g, half, ev) : group_stage_go<8>(s, i, (int)g, half, ev);
+            rc = qdepth == MAXPEND ? group_stage_go<MAXPEND>(s, i, (int)g, half, ev)
+               : qdepth == 24 ? group_stage_go<24>(s, i, (int)g, half, ev)
+               : qdepth == 16 ? group_stage_go<16>(s, i, (int)g, half, ev) : group_stage_go<8>(s, i, (int)g, half, ev);
             if (rc) return rc;
             s->npend += (int)g;       // (optimistic, as after every queue cut: ellhip_queue_results settles it after a halt)
             s->scalars_stale = true;
@@ -2127,19 +2129,28 @@ int ellhip_set_option(ellhip_space* s, int key, int64_t value) {
     DeviceGuard guard(s->device);
     const bool ell = s->variant == ELLHIP_SPACE_ELL;
     switch (key) {
-        case ELLHIP_OPT_SYMV: case ELLHIP_OPT_SYMV_MIN_N: case ELLHIP_OPT_APPLY_LOWER: case ELLHIP_OPT_APPLY_KERNEL:
-        case ELLHIP_OPT_RESIDENT: case ELLHIP_OPT_OVERLAP: case ELLHIP_OPT_LOOKAHEAD: case ELLHIP_OPT_QUEUE_DEPTH:
+        // chosen per queue run: nothing recorded depends on them
+        case ELLHIP_OPT_RESIDENT:
             if (!ell) return fail(ELLHIP_E_INVALID, "this option exists on Ell only");
-            // (chosen per queue run: nothing recorded depends on them)
-            if (key == ELLHIP_OPT_RESIDENT) s->resident = (int)value;
-            else if (key == ELLHIP_OPT_OVERLAP) s->overlap = (int)value;
-            else if (key == ELLHIP_OPT_LOOKAHEAD) s->lookahead = (int)value;
-            else s->queue_depth = (int)value;
+            s->resident = (int)value;
             return 0;
+        case ELLHIP_OPT_OVERLAP:
+            if (!ell) return fail(ELLHIP_E_INVALID, "this option exists on Ell only");
+            s->overlap = (int)value;
+            return 0;
+        case ELLHIP_OPT_LOOKAHEAD:
+            if (!ell) return fail(ELLHIP_E_INVALID, "this option exists on Ell only");
+            s->lookahead = (int)value;
+            return 0;
+        case ELLHIP_OPT_QUEUE_DEPTH:
+            if (!ell) return fail(ELLHIP_E_INVALID, "this option exists on Ell only");
+            s->queue_depth = (int)value;
+            return 0;
+        // what has been recorded (and a stale upper triangle) belongs to the schedule in force: Q is made current first
+        case ELLHIP_OPT_SYMV: case ELLHIP_OPT_SYMV_MIN_N: case ELLHIP_OPT_APPLY_LOWER: case ELLHIP_OPT_APPLY_KERNEL:
         case ELLHIP_OPT_FUSE_DOTS: {
             if (!ell) return fail(ELLHIP_E_INVALID, "this option exists on Ell only");
             if (s->in_two_phase) return fail(ELLHIP_E_STATE, "update_begin without update_end");
-            // what has been recorded (and a stale upper triangle) belongs to the schedule in force: make Q current first
             rc = make_q_current(s);
             if (rc) return rc;
             if (key == ELLHIP_OPT_SYMV) s->symv = (int)value;

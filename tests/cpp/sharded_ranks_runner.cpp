@@ -230,10 +230,16 @@ int main(int argc, char** argv) {
         }
         // an equal-block shard runs full-row GEMVs: so must the reference, for the comparison to be one of bits -- and
         // neither may its queue runs take the resident kernel (its own summation shape)
-        (void)ellhip_set_option(h.s, ELLHIP_OPT_RESIDENT, 0);
-        if (partition == ELLHIP_SHARD_EQUAL_BLOCKS) (void)ellhip_set_option(h.s, ELLHIP_OPT_SYMV, 0);
-        else (void)ellhip_set_option(h.s, ELLHIP_OPT_SYMV_MIN_N, 512);
-        (void)ellhip_set_defer_depth(h.s, depth);
+        int orc = ellhip_set_option(h.s, ELLHIP_OPT_RESIDENT, 0);
+        if (!orc) orc = (partition == ELLHIP_SHARD_EQUAL_BLOCKS) ? ellhip_set_option(h.s, ELLHIP_OPT_SYMV, 0)
+                                                                : ellhip_set_option(h.s, ELLHIP_OPT_SYMV_MIN_N, 512);
+        if (!orc) orc = ellhip_set_defer_depth(h.s, depth);
+        int64_t got = -1;
+        if (!orc) orc = ellhip_get_option(h.s, partition == ELLHIP_SHARD_EQUAL_BLOCKS ? ELLHIP_OPT_SYMV : ELLHIP_OPT_SYMV_MIN_N, &got);
+        if (orc || got != (partition == ELLHIP_SHARD_EQUAL_BLOCKS ? 0 : 512) || ellhip_defer_depth(h.s) != depth) {
+            std::printf("{\"case\": \"ranks\", \"ok\": false, \"error\": \"reference handle options: %s\"}\n", ellhip_last_error());
+            return 0;
+        }
         [&]() { sequence(h, cuts, n, out); }();
         ellhip_destroy(h.s);
         if (ref.rc) {

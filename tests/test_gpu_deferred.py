@@ -522,11 +522,49 @@ def test_matrix_core_apply_pass_matches_the_oracle(gpu, orc, n, depth):
         g = gpu.Ell.new_with_scalar(2.0, xc0)
         g.defer_depth = depth
         g.set_option(gpu.capi.OPT_APPLY_KERNEL, kern)
+        assert g.get_option(gpu.capi.OPT_APPLY_KERNEL) == kern and g.defer_depth == depth
+        assert g.get_option(gpu.capi.OPT_QUEUE_DEPTH) == 48   # (round 3: the four schedule keys fell through to this one)
+        g.profile_enable(True)
         o = orc.OracleEll.new_with_scalar(2.0, xc0)
         nsucc = run_mixed(g, o, 3 * depth + 5, seed=4100 + n + depth, check_every=depth + 3)
         assert nsucc >= depth + 4
+        assert g.profile_read()["apply"][1] >= 1   # at least one apply pass of the pinned kernel ran before the observer's
         assert_state_close(g, o, what=f"apply kernel {kern} depth {depth} n={n}")
         outs.append((g.mq, g.xc(), g.kappa))
     assert np.max(np.abs(outs[0][0] - outs[1][0])) <= 1e-12 * np.max(np.abs(outs[1][0]))
     assert np.array_equal(outs[0][0], outs[0][0].T)
     assert np.max(np.abs(outs[0][1] - outs[1][1])) <= 1e-12 * np.max(np.abs(outs[1][1]))
+
+
+def test_every_per_handle_option_round_trips(gpu):
+    """ellhip_set_option -> ellhip_get_option for every per-handle key, and nothing else moves (round 3: SYMV, SYMV_MIN_N,
+    APPLY_LOWER and APPLY_KERNEL were silently stored into QUEUE_DEPTH, unvalidated)."""
+    capi = gpu.capi
+    ell_keys = {"SYMV": [0, 1], "SYMV_MIN_N": [512, 4096, 5120], "APPLY_LOWER": [0, 1], "APPLY_KERNEL": [0, 1, 2, -1],
+                "FUSE_DOTS": [0, 1], "RESIDENT": [0, 1], "OVERLAP": [0, 1], "LOOKAHEAD": [1, 3, 16], "QUEUE_DEPTH": [0, 48]}
+    e = gpu.Ell.new_with_scalar(1.0, np.zeros(640))
+    snapshot = lambda s, keys: {k: s.get_option(getattr(capi, "OPT_" + k)) for k in keys}
+    for name, values in ell_keys.items():
+        for v in values:
+            before = snapshot(e, ell_keys)
+            e.set_option(getattr(capi, "OPT_" + name), v)
+            after = snapshot(e, ell_keys)
+            before[name] = v
+            assert after == before, (name, v)
+    for name, bad in (("QUEUE_DEPTH", 4096), ("LOOKAHEAD", 17), ("APPLY_KERNEL", 3), ("SYMV_MIN_N", 8), ("SYMV", 2)):
+        with pytest.raises(Exception):
+            e.set_option(getattr(capi, "OPT_" + name), bad)
+    # the handle still works, on the schedule the options describe
+    e.set_option(capi.OPT_SYMV_MIN_N, 512)
+    e.defer_depth = 24
+    assert e.defer_depth == 24
+    e.set_option(capi.OPT_SYMV, 0)      # the lower-triangle schedule is gone: depth 24 falls back to 8
+    assert e.defer_depth == 8
+    st_keys = {"STABLE_SOLVE": [0, 1, 2], "STABLE_FACTOR": [0, 1, 2]}
+    s = gpu.EllStable.new_with_scalar(1.0, np.zeros(64))
+    for name, values in st_keys.items():
+        for v in values:
+            before = snapshot(s, st_keys)
+            s.set_option(getattr(capi, "OPT_" + name), v)
+            before[name] = v
+            assert snapshot(s, st_keys) == before
