@@ -138,8 +138,9 @@ struct ellhip_space {
     // place, on `stream`); set by sharded_capi.inc.hpp around its call of queue_run_multi
     int (*grp_exchange)(void* ctx, double* buf, long long count, hipStream_t stream) = nullptr;
     void* grp_exchange_ctx = nullptr;
-    hipEvent_t ev_symv = nullptr;    // the GEMV issued ahead has finished
-    hipEvent_t ev_red[2] = {nullptr, nullptr};  // set k is free again (its reduction, and every apply pass before, are done)
+    hipEvent_t ev_symv = nullptr;    // side_mark: what was issued on the second stream has finished
+    hipEvent_t ev_side_go = nullptr; // side_fork: everything enqueued on the handle's stream up to the fork
+    bool side_busy = false;          // work issued on the second stream has not been joined yet (side_fork .. side_join)
     int symv = 1;                    // allow the lower-triangle GEMV in deferred mode (ELLHIP_SYMV=0 disables)
     int symv_rw = 2;
     long long symv_min_n = 5120;     // below this the full-row pass wins for synchronous updates (tools/midsize_sweep.py)
@@ -153,6 +154,10 @@ struct ellhip_space {
     double* d_rs_part = nullptr;     // [2][grid][2 R 64]
     double* d_rs_omega = nullptr;    // [2][grid]
     unsigned* d_rs_bar = nullptr;    // RS_BAR_WORDS
+    double* d_rs_xc0 = nullptr;      // xc at the start of the batch in flight (restored when the batch is abandoned)
+    DevState* d_rs_st0 = nullptr;    // ... and the scalar state
+    long long rs_fault_at = -1;      // ELLHIP_OPT_RESIDENT_FAULT (test hook)
+    long long rs_abandoned = 0;      // batches abandoned and rerun on the streamed schedule (ELLHIP_OPT_RESIDENT_ABANDONED)
     int dots_np = 0;                 // > 0: d_partial holds dot products of the primed gradient for this depth: [ceil(n/128)][dots_np + 1]
                                      // from k_symv_reduce, or [scalar_groups(n)][...] WITHOUT the g.y column from k_sweep_gemv_dots
     bool dots_need_gy = false;       // the latter: k_scalar_apply_def forms g.y itself
@@ -406,8 +411,11 @@ bool symv_ok(const ellhip_space* s);
 // Apply every pending update to Q (one pass), optionally fused with the GEMV of `gvec`; then clear the slots.
 // While the GEMVs of this handle read the lower triangle only (symv_ok), so does the apply pass: half the
 // traffic; the strict upper triangle goes stale until make_q_current() mirrors it back.
+int side_join(ellhip_space* s);
 int flush_pending(ellhip_space* s, const double* gvec, double* gv_out) {
     {
+        int jrc = side_join(s);  // a writer of Q: nothing issued ahead on the second stream may still be reading it
+        if (jrc) return jrc;
         ProfScope ps(s, gvec ? CLS_APPLY_GEMV : CLS_APPLY);
         const bool even = (s->n % 2) == 0;
         const bool nt = even && s->sh_apply.nt;
@@ -820,9 +828,14 @@ int read_back(ellhip_space* s) {
         // A bounded wait of a persistent solve gave up: this update's result is invalid and the call fails.  The
         // error word is cleared once it has been reported and the handle falls back to one launch per block (no
         // inter-workgroup waits), so the handle stays usable -- its state, though, is what the failed update left.
+        // (Ell: resident batches settle their own time-outs inside resident_run and leave no error word behind.)
         s->h_result->solve_err = 0;
         (void)hipMemsetAsync(reinterpret_cast<char*>(s->d_st) + offsetof(DevState, solve_err), 0, sizeof(int), s->stream);
         (void)hipStreamSynchronize(s->stream);
+        if (s->variant == ELLHIP_SPACE_ELL) {
+            s->resident = 0;
+            return fail(ELLHIP_E_HIP, "a bounded in-launch wait timed out on an Ell handle; resident batches are now off on it");
+        }
         s->stable_solve = 0;
         return fail(ELLHIP_E_HIP, "a bounded in-launch wait of an EllStable persistent solve timed out; this handle now uses one "
                                   "launch per block (no inter-workgroup waits)");
@@ -1195,17 +1208,54 @@ bool overlap_ok(const ellhip_space* s) {
     return s->overlap && s->variant == ELLHIP_SPACE_ELL && !s->sharded && symv_ok(s);
 }
 
-// the second stream and its events (overlapped queue runs: queue_run_overlapped, the group runs of queue_run_multi)
+// ---- the second stream: three functions carry every cross-stream ordering of the queue runs -------------------------
+// queue_run_overlapped (the next cut's GEMV) and queue_run_multi (the next group's products) issue kernels that READ Q
+// and WRITE one half of the partial-sum sets on a second stream beside the handle's own.  The rules:
+//   side_fork   what is issued on the second stream from here on follows EVERYTHING enqueued on the handle's stream so
+//               far -- whatever wrote Q (apply passes of this loop, of a cut taken by itself, of ensure_committed) and
+//               whatever read the half about to be overwritten.  Not "the events that matter": both ordering bugs of
+//               round 3 were a writer of Q that one of several hand-placed events did not cover.
+//   side_mark   the side kernels have been issued (records their completion event).
+//   side_join   the handle's stream waits for them.  Called before their results are read, by every writer of Q on the
+//               handle's stream (flush_pending) and when a queue run returns (SideGuard): nothing outside a queue run
+//               ever sees side work in flight.
+// ELLHIP_OPT_OVERLAP = 2 issues the "side" kernels on the handle's own stream (same kernels, same order of issue, one
+// stream): the serial form the option-mix walks compare the overlapped one against, seed by seed.
 int side_setup(ellhip_space* s) {
     if (s->symv_stream) return 0;
     int least = 0, greatest = 0;
     HIPCHK(hipDeviceGetStreamPriorityRange(&least, &greatest));
     HIPCHK(hipEventCreateWithFlags(&s->ev_symv, hipEventDisableTiming));
-    for (int k = 0; k < 2; ++k) HIPCHK(hipEventCreateWithFlags(&s->ev_red[k], hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&s->ev_side_go, hipEventDisableTiming));
     // lowest priority: the short reduction / scalar kernels of the main stream get the CU slots the GEMV's workgroups free
     HIPCHK(hipStreamCreateWithPriority(&s->symv_stream, hipStreamNonBlocking, least));
     return 0;
 }
+hipStream_t side_stream(const ellhip_space* s) { return s->overlap == 2 ? s->stream : s->symv_stream; }
+int side_join(ellhip_space* s) {
+    if (!s->side_busy) return 0;
+    s->side_busy = false;
+    if (side_stream(s) != s->stream) HIPCHK(hipStreamWaitEvent(s->stream, s->ev_symv, 0));
+    return 0;
+}
+int side_fork(ellhip_space* s) {
+    int rc = side_join(s);  // (one batch of side work at a time)
+    if (rc) return rc;
+    if (side_stream(s) != s->stream) {
+        HIPCHK(hipEventRecord(s->ev_side_go, s->stream));
+        HIPCHK(hipStreamWaitEvent(s->symv_stream, s->ev_side_go, 0));
+    }
+    return 0;
+}
+int side_mark(ellhip_space* s) {
+    if (side_stream(s) != s->stream) HIPCHK(hipEventRecord(s->ev_symv, side_stream(s)));
+    s->side_busy = true;
+    return 0;
+}
+struct SideGuard {  // a queue run never returns (error paths included) with side work in flight
+    ellhip_space* s;
+    ~SideGuard() { (void)side_join(s); }
+};
 
 int overlap_setup(ellhip_space* s) {
     if (s->d_rowpart2) return 0;
@@ -1222,43 +1272,37 @@ int overlap_setup(ellhip_space* s) {
 int queue_run_overlapped(ellhip_space* s, long long first, long long count) {
     int rc = overlap_setup(s);
     if (rc) return rc;
-    // everything enqueued so far (apply passes of direct updates, an earlier run's reductions) precedes the first GEMV
-    // issued ahead
-    for (int k = 0; k < 2; ++k) HIPCHK(hipEventRecord(s->ev_red[k], s->stream));
+    SideGuard guard{s};
     for (long long i = first; i < first + count; ++i) {
-        const bool was_primed = s->primed && s->primed_qindex == i;
         rc = queue_prime_impl(s, i);  // (only the first cut of a run pays its GEMV on the main stream)
         if (rc) return rc;
-        if (!was_primed)  // that reduction reads the current set: the GEMV after next may only overwrite it afterwards
-            for (int k = 0; k < 2; ++k) HIPCHK(hipEventRecord(s->ev_red[k], s->stream));
         const long long next = (i + 1 < s->qk) ? i + 1 : -1;
         // this cut becomes recorded update number npend; when that fills the slots an apply pass follows it, and the
         // next GEMV has to read what that pass writes
         const bool ahead = next >= 0 && symv_ok(s) && s->npend + 1 < s->defer;
         const int set = s->part_set ^ 1;
         if (ahead) {
-            HIPCHK(hipStreamWaitEvent(s->symv_stream, s->ev_red[set], 0));
-            rc = launch_symv_tiles(s, qgrad(s, next), s->symv_stream, set);
+            rc = side_fork(s);
+            if (!rc) rc = launch_symv_tiles(s, qgrad(s, next), side_stream(s), set);
+            if (!rc) rc = side_mark(s);
             if (rc) return rc;
-            HIPCHK(hipEventRecord(s->ev_symv, s->symv_stream));
         }
         rc = queue_cut_impl(s, i);
         if (rc) return rc;
         if (!ahead) {
             rc = queue_commit_impl(s, i, next);  // apply pass if due, then GEMV + reduction on the main stream
             if (rc) return rc;
-            for (int k = 0; k < 2; ++k) HIPCHK(hipEventRecord(s->ev_red[k], s->stream));
             continue;
         }
         // what queue_commit_impl does on this schedule when no apply pass is due, with the GEMV already in flight
         s->shrink_pending = false;
         s->dots_np = 0;
         s->dots_need_gy = false;
-        HIPCHK(hipStreamWaitEvent(s->stream, s->ev_symv, 0));
+        rc = side_join(s);
+        if (rc) return rc;
         s->part_set = set;
         rc = launch_symv_reduce(s, qgrad(s, next), s->d_gt[s->cur ^ 1]);
         if (rc) return rc;
-        HIPCHK(hipEventRecord(s->ev_red[set], s->stream));
         s->cur ^= 1;
         s->primed = true;
         s->g_cur = qgrad(s, next);
@@ -1337,7 +1381,7 @@ int multi_setup(ellhip_space* s) {
 
 // the scalar stage of a group whose products sit in the partial-sum sets 2 .. 2 + g - 1 (group_kernels.hpp)
 template <int NP>
-int group_stage_go(ellhip_space* s, long long i, int g, int half, hipEvent_t sets_free) {
+int group_stage_go(ellhip_space* s, long long i, int g, int half) {
     const unsigned nb = (unsigned)((s->n + 127) / 128);
     const double* grads = qgrad(s, i);
     {
@@ -1354,7 +1398,6 @@ int group_stage_go(ellhip_space* s, long long i, int g, int half, hipEvent_t set
                                s->d_grpY, grads, s->n, (const double*)s->d_pend, s->d_gpart, (const DevState*)s->d_st);
         HIPCHK(hipGetLastError());
     }
-    if (sets_free) HIPCHK(hipEventRecord(sets_free, s->stream));  // (the reduction is the only reader of the partial-sum sets)
     if (s->sharded) {
         // the shards' partial products become the products: ONE collective for the whole group, then the dot products from
         // the complete vectors (every rank forms the same ones)
@@ -1440,9 +1483,8 @@ int queue_run_multi(ellhip_space* s, long long first, long long count) {
     if (use_side) {
         rc = side_setup(s);
         if (rc) return rc;
-        // everything enqueued so far (apply passes, an earlier run's reductions) precedes the first products issued ahead
-        for (int k = 0; k < 2; ++k) HIPCHK(hipEventRecord(s->ev_red[k], s->stream));
     }
+    SideGuard guard{s};
     int half = 0;                       // the half of the partial-sum sets the current group's products are in
     long long ahead_i = -1, ahead_g = 0;  // the group whose products are in flight on the second stream
     long long i = first;
@@ -1473,11 +1515,11 @@ int queue_run_multi(ellhip_space* s, long long first, long long count) {
         }
         if (multi_mfma(s)) {
             const long long cap = MULTI_MAX;
-            if (!(ahead_i == i && ahead_g == g)) {  // this group's products are not in flight yet
+            rc = side_join(s);  // (this group's products, when they were issued ahead)
+            if (rc) return rc;
+            if (!(ahead_i == i && ahead_g == g)) {  // this group's products are not in the sets yet
                 rc = symm_go(s, qgrad(s, i), (int)g, s->stream, half);
                 if (rc) return rc;
-            } else {
-                HIPCHK(hipStreamWaitEvent(s->stream, s->ev_symv, 0));
             }
             ahead_i = -1;
             // the NEXT group's products on the second stream beside this group's stage -- when there is one inside this run
@@ -1490,16 +1532,10 @@ int queue_run_multi(ellhip_space* s, long long first, long long count) {
                 if (rem2 > cap2 && rem2 < 2 * cap2) g2 = (rem2 + 1) / 2;  // (the rule the next trip of the loop applies)
             }
             if (use_side && g2 >= 2) {
-                // The products issued ahead follow EVERYTHING enqueued on the handle's stream so far: the last reduction that
-                // read the other half of the sets, and whatever wrote Q -- an apply pass of this loop, of the single-cut
-                // path (a cut taken by itself when one slot was left), or of ensure_committed.  (A soak run of
-                // tests/test_gpu_overlap.py found the single-cut path's apply pass missing from an event recorded earlier:
-                // 8 of 400 seeded walks off by 1e-3.)
-                HIPCHK(hipEventRecord(s->ev_red[half ^ 1], s->stream));
-                HIPCHK(hipStreamWaitEvent(s->symv_stream, s->ev_red[half ^ 1], 0));
-                rc = symm_go(s, qgrad(s, i2), (int)g2, s->symv_stream, half ^ 1);
+                rc = side_fork(s);  // after this group's products, the last reader of the other half, every writer of Q so far
+                if (!rc) rc = symm_go(s, qgrad(s, i2), (int)g2, side_stream(s), half ^ 1);
+                if (!rc) rc = side_mark(s);
                 if (rc) return rc;
-                HIPCHK(hipEventRecord(s->ev_symv, s->symv_stream));
                 ahead_i = i2;
                 ahead_g = g2;
             }
@@ -1507,10 +1543,9 @@ int queue_run_multi(ellhip_space* s, long long first, long long count) {
             // starts, then the vectors in one elementwise pass
             drop_prime(s);
             s->dots_np = 0;
-            hipEvent_t ev = use_side ? s->ev_red[half] : nullptr;
-            rc = qdepth == MAXPEND ? group_stage_go<MAXPEND>(s, i, (int)g, half, ev)
-               : qdepth == 24 ? group_stage_go<24>(s, i, (int)g, half, ev)
-               : qdepth == 16 ? group_stage_go<16>(s, i, (int)g, half, ev) : group_stage_go<8>(s, i, (int)g, half, ev);
+            rc = qdepth == MAXPEND ? group_stage_go<MAXPEND>(s, i, (int)g, half)
+               : qdepth == 24 ? group_stage_go<24>(s, i, (int)g, half)
+               : qdepth == 16 ? group_stage_go<16>(s, i, (int)g, half) : group_stage_go<8>(s, i, (int)g, half);
             if (rc) return rc;
             s->npend += (int)g;       // (optimistic, as after every queue cut: ellhip_queue_results settles it after a halt)
             s->scalars_stale = true;
@@ -1518,8 +1553,6 @@ int queue_run_multi(ellhip_space* s, long long first, long long count) {
             if (s->npend >= qdepth) {
                 rc = flush_pending(s, nullptr, nullptr);
                 if (rc) return rc;
-                if (use_side)
-                    for (int k = 0; k < 2; ++k) HIPCHK(hipEventRecord(s->ev_red[k], s->stream));
             }
             if (ahead_i >= 0) half ^= 1;
             i += g;
@@ -1581,6 +1614,8 @@ int resident_setup(ellhip_space* s) {  // once per handle: can this n run reside
         HIPCHK(hipMalloc(&s->d_rs_part, 2 * G * NV * sizeof(double)));
         HIPCHK(hipMalloc(&s->d_rs_omega, 2 * G * sizeof(double)));
         HIPCHK(hipMalloc(&s->d_rs_bar, RS_BAR_WORDS * sizeof(unsigned)));
+        HIPCHK(hipMalloc(&s->d_rs_xc0, (size_t)s->n * sizeof(double)));
+        HIPCHK(hipMalloc(&s->d_rs_st0, sizeof(DevState)));
         s->rs_R = r;
         s->rs_S = S;
         break;
@@ -1596,6 +1631,16 @@ bool resident_ok(ellhip_space* s, long long count) {
     return s->rs_R > 0;
 }
 
+constexpr int RS_FALLBACK = 1;  // resident_run: the batch did not run (or was abandoned and undone): take the streamed schedule
+
+// One batch = one cooperative launch.  The call returns when the batch has finished (one stream synchronisation per
+// batch: the verdict "committed or abandoned" is needed before anything else may be enqueued behind it).
+//   0            the batch ran: Q (lower triangle), xc, DevState and the queue results are those of `count` more cuts;
+//   RS_FALLBACK  nothing happened as far as the caller can tell -- the launch was refused (the grid cannot be co-resident
+//                on this device as it is partitioned now) or a bounded wait inside the kernel gave up, in which case no
+//                tile was written back (rs_commit) and xc / DevState / the batch's queue results have been restored from
+//                the snapshots taken below.  The caller continues with the streamed schedule; so does the handle from
+//                now on (s->resident = 0).
 int resident_run(ellhip_space* s, long long first, long long count) {
     // the lower triangle must be current: commit a pending shrink, apply what the recorded schedule holds; a primed
     // gradient is simply dropped (the kernel forms every Q g itself)
@@ -1626,14 +1671,39 @@ int resident_run(ellhip_space* s, long long first, long long count) {
     A.ctr = s->d_rs_bar;
     A.stamps = nullptr;
     A.calc = EllCalcDev::make(s->n, s->use_parallel_cut);
+    A.fault_at = s->rs_fault_at;
     const unsigned G = (unsigned)(s->rs_S * (s->rs_S + 1) / 2);
+    HIPCHK(hipMemcpyAsync(s->d_rs_xc0, s->d_xc, (size_t)s->n * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
+    HIPCHK(hipMemcpyAsync(s->d_rs_st0, s->d_st, sizeof(DevState), hipMemcpyDeviceToDevice, s->stream));
     HIPCHK(hipMemsetAsync(s->d_rs_bar, 0, RS_BAR_WORDS * sizeof(unsigned), s->stream));
     {
         ProfScope ps(s, CLS_RESIDENT);
-        if (s->rs_R == 1) hipLaunchKernelGGL(k_ell_resident<1>, dim3(G), dim3(RS_THREADS), 0, s->stream, A);
-        else if (s->rs_R == 2) hipLaunchKernelGGL(k_ell_resident<2>, dim3(G), dim3(RS_THREADS), 0, s->stream, A);
-        else hipLaunchKernelGGL(k_ell_resident<3>, dim3(G), dim3(RS_THREADS), 0, s->stream, A);
-        HIPCHK(hipGetLastError());
+        const void* k = s->rs_R == 1 ? (const void*)k_ell_resident<1> : (s->rs_R == 2 ? (const void*)k_ell_resident<2> : (const void*)k_ell_resident<3>);
+        void* args[] = {&A};
+        const hipError_t e = hipLaunchCooperativeKernel(k, dim3(G), dim3(RS_THREADS), args, 0, s->stream);
+        if (e != hipSuccess) {
+            // not co-resident on this device (partitioned, CU mask, ...): no resident batches on this handle any more
+            (void)hipGetLastError();
+            s->resident = 0;
+            return RS_FALLBACK;
+        }
+    }
+    HIPCHK(hipMemcpyAsync(s->h_result, s->d_st, sizeof(DevState), hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    if (s->h_result->solve_err) {
+        // abandoned: Q was not written.  Put back what the kernel's cuts wrote on the way -- xc (the diagonal workgroups),
+        // the scalar state, the batch's queue results ("not run yet") -- and let the streamed schedule take the batch.
+        HIPCHK(hipMemcpyAsync(s->d_xc, s->d_rs_xc0, (size_t)s->n * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
+        HIPCHK(hipMemcpyAsync(s->d_st, s->d_rs_st0, sizeof(DevState), hipMemcpyDeviceToDevice, s->stream));
+        HIPCHK(hipMemsetAsync(s->d_qstatus + first, 0xff, (size_t)count * sizeof(int), s->stream));
+        HIPCHK(hipMemsetAsync(s->d_qtsq + first, 0, (size_t)count * sizeof(double), s->stream));
+        HIPCHK(hipMemcpyAsync(s->h_result, s->d_st, sizeof(DevState), hipMemcpyDeviceToHost, s->stream));
+        HIPCHK(hipStreamSynchronize(s->stream));
+        s->resident = 0;
+        s->rs_abandoned += 1;
+        (void)fail(0, "a resident batch was abandoned (bounded in-launch wait) and rerun on the streamed schedule; "
+                      "ELLHIP_OPT_RESIDENT is now 0 on this handle");
+        return RS_FALLBACK;
     }
     // The kernel wrote the lower triangle (diagonal tiles whole).  Where the streamed schedule of this handle reads
     // full rows, the mirrored half is rebuilt at once; a handle on the lower-triangle schedule leaves it stale as its
@@ -1647,7 +1717,9 @@ int resident_run(ellhip_space* s, long long first, long long count) {
         s->upper_stale = false;
     }
     s->shrink_pending = false;
-    s->scalars_stale = true;
+    s->kappa = s->h_result->kappa;
+    s->tsq = s->h_result->tsq;
+    s->scalars_stale = false;
     return 0;
 }
 
@@ -1706,6 +1778,8 @@ void ellhip_destroy(ellhip_space* s) {
     if (s->d_rs_part) (void)hipFree(s->d_rs_part);
     if (s->d_rs_omega) (void)hipFree(s->d_rs_omega);
     if (s->d_rs_bar) (void)hipFree(s->d_rs_bar);
+    if (s->d_rs_xc0) (void)hipFree(s->d_rs_xc0);
+    if (s->d_rs_st0) (void)hipFree(s->d_rs_st0);
     if (s->d_rowpart) (void)hipFree(s->d_rowpart);
     if (s->d_colpart) (void)hipFree(s->d_colpart);
     if (s->d_rowpart2) (void)hipFree(s->d_rowpart2);
@@ -1719,8 +1793,7 @@ void ellhip_destroy(ellhip_space* s) {
     if (s->d_gout) (void)hipFree(s->d_gout);
     if (s->d_gsums) (void)hipFree(s->d_gsums);
     if (s->ev_symv) (void)hipEventDestroy(s->ev_symv);
-    for (int k = 0; k < 2; ++k)
-        if (s->ev_red[k]) (void)hipEventDestroy(s->ev_red[k]);
+    if (s->ev_side_go) (void)hipEventDestroy(s->ev_side_go);
     if (s->symv_stream) (void)hipStreamDestroy(s->symv_stream);
     if (s->d_flags) (void)hipFree(s->d_flags);
     if (s->d_st) (void)hipFree(s->d_st);
@@ -2057,10 +2130,12 @@ int option_ok(int key, long long v) {
         case ELLHIP_OPT_APPLY_KERNEL:
             return (v >= -1 && v <= 2) ? 0 : fail(ELLHIP_E_INVALID, "option value must be -1, 0, 1 or 2");
         case ELLHIP_OPT_AUTO_DEFER: case ELLHIP_OPT_SYMV: case ELLHIP_OPT_APPLY_LOWER:
-        case ELLHIP_OPT_FUSE_DOTS: case ELLHIP_OPT_RESIDENT: case ELLHIP_OPT_OVERLAP:
+        case ELLHIP_OPT_FUSE_DOTS: case ELLHIP_OPT_RESIDENT:
             return (v == 0 || v == 1) ? 0 : fail(ELLHIP_E_INVALID, "option value must be 0 or 1");
+        case ELLHIP_OPT_OVERLAP: return (v >= 0 && v <= 2) ? 0 : fail(ELLHIP_E_INVALID, "ELLHIP_OPT_OVERLAP: 0, 1 or 2");
         case ELLHIP_OPT_LOOKAHEAD: return (v >= 1 && v <= 16) ? 0 : fail(ELLHIP_E_INVALID, "ELLHIP_OPT_LOOKAHEAD: 1 .. 16");
         case ELLHIP_OPT_QUEUE_DEPTH: return (v == 0 || v == 48) ? 0 : fail(ELLHIP_E_INVALID, "ELLHIP_OPT_QUEUE_DEPTH: 0 or 48");
+        case ELLHIP_OPT_RESIDENT_FAULT: return v >= -1 ? 0 : fail(ELLHIP_E_INVALID, "ELLHIP_OPT_RESIDENT_FAULT: -1 or a cut index");
         case ELLHIP_OPT_SYMV_MIN_N: return v >= 512 ? 0 : fail(ELLHIP_E_INVALID, "ELLHIP_OPT_SYMV_MIN_N must be >= 512");
         case ELLHIP_OPT_STABLE_SOLVE: case ELLHIP_OPT_STABLE_FACTOR:
             return (v >= 0 && v <= 2) ? 0 : fail(ELLHIP_E_INVALID, "option value must be 0, 1 or 2");
@@ -2146,6 +2221,10 @@ int ellhip_set_option(ellhip_space* s, int key, int64_t value) {
             if (!ell) return fail(ELLHIP_E_INVALID, "this option exists on Ell only");
             s->queue_depth = (int)value;
             return 0;
+        case ELLHIP_OPT_RESIDENT_FAULT:
+            if (!ell) return fail(ELLHIP_E_INVALID, "this option exists on Ell only");
+            s->rs_fault_at = value;
+            return 0;
         // what has been recorded (and a stale upper triangle) belongs to the schedule in force: Q is made current first
         case ELLHIP_OPT_SYMV: case ELLHIP_OPT_SYMV_MIN_N: case ELLHIP_OPT_APPLY_LOWER: case ELLHIP_OPT_APPLY_KERNEL:
         case ELLHIP_OPT_FUSE_DOTS: {
@@ -2191,6 +2270,8 @@ int ellhip_get_option(const ellhip_space* s, int key, int64_t* value) {
         case ELLHIP_OPT_OVERLAP: *value = s->overlap; break;
         case ELLHIP_OPT_LOOKAHEAD: *value = s->lookahead; break;
         case ELLHIP_OPT_QUEUE_DEPTH: *value = s->queue_depth; break;
+        case ELLHIP_OPT_RESIDENT_FAULT: *value = s->rs_fault_at; break;
+        case ELLHIP_OPT_RESIDENT_ABANDONED: *value = s->rs_abandoned; break;
         case ELLHIP_OPT_STABLE_SOLVE: *value = s->stable_solve; break;
         case ELLHIP_OPT_STABLE_FACTOR: *value = s->stable_factor; break;
         case ELLHIP_OPT_PAD: *value = s->ld - s->n; break;
@@ -2305,7 +2386,10 @@ int ellhip_queue_end(ellhip_space* s, int64_t index) {
 int ellhip_queue_run(ellhip_space* s, int64_t first, int64_t count) {
     if (!s || first < 0 || count < 0 || first + count > s->qk) return fail(ELLHIP_E_INVALID, "queue range");
     DeviceGuard guard(s->device);
-    if (resident_ok(s, count)) return resident_run(s, first, count);
+    if (resident_ok(s, count)) {
+        const int rrc = resident_run(s, first, count);
+        if (rrc != RS_FALLBACK) return rrc;
+    }
     for (int64_t i = first; i < first + count; ++i) {
         int rc = queue_prime_impl(s, i);
         if (!rc) rc = queue_cut_impl(s, i);
@@ -2318,7 +2402,10 @@ int ellhip_queue_run(ellhip_space* s, int64_t first, int64_t count) {
 int ellhip_queue_run_fused(ellhip_space* s, int64_t first, int64_t count) {
     if (!s || first < 0 || count < 0 || first + count > s->qk) return fail(ELLHIP_E_INVALID, "queue range");
     DeviceGuard guard(s->device);
-    if (resident_ok(s, count)) return resident_run(s, first, count);
+    if (resident_ok(s, count)) {
+        const int rrc = resident_run(s, first, count);
+        if (rrc != RS_FALLBACK) return rrc;
+    }
     if (multi_ok(s)) {
         const int mrc = queue_run_multi(s, first, count);
         if (mrc != MULTI_NO_MEMORY) return mrc;

@@ -34,8 +34,13 @@
 // atomics in the data path, static assignment).
 //
 // The grid is one workgroup per CU and must be resident as a whole (a workgroup that waits holds its CU): the host
-// checks the occupancy (1 x CU count >= super-tiles) before it chooses this path, every wait is bounded, and a time-out
-// sets DevState.solve_err (the call fails, the GPU is not hung).
+// launches it COOPERATIVELY (hipLaunchCooperativeKernel refuses a grid the device cannot hold at once, and the runtime
+// does not run two cooperative grids side by side -- two handles on one card, BSearchAdaptor's clone per probe
+// src/cutting_plane.rs:409-418, cannot starve each other of CUs); every wait is bounded all the same.
+// Failure contract (a bounded wait gave up): the batch is ABANDONED AS A WHOLE.  The tiles are written back only behind a
+// commit word on which every workgroup either arrives or aborts, never both (rs_commit): if any workgroup aborted, none
+// writes, Q in HBM is still the pre-batch matrix, DevState.solve_err = RS_WAIT_ERR, and the host restores xc / DevState /
+// the batch's queue results from its snapshots and reruns the batch on the streamed schedule (resident_run).
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -73,6 +78,8 @@ struct ResidentArgs {
     unsigned* ctr;             // barrier words (RS_BAR_WORDS unsigned), zero at launch
     unsigned long long* stamps;  // RS_TIMELINE builds only
     EllCalcDev calc;
+    long long fault_at;        // test hook (ELLHIP_OPT_RESIDENT_FAULT): workgroup 1 % grid abandons the batch at this cut of
+                               // it as if its wait had timed out; < 0: never
 };
 
 __device__ __forceinline__ int rs_super_index(int SI, int SJ) { return SI * (SI + 1) / 2 + SJ; }
@@ -120,7 +127,30 @@ __device__ __forceinline__ double rs_reduce2_halves(const double (&v)[2], int la
 // `bar`: RS_BAR_WORDS unsigned words, zero at launch: root at [0], group counter g at [32 (1 + g)], release word g at
 // [32 (17 + g)].  Waits are bounded.
 constexpr int RS_BAR_GROUPS = 16;
-constexpr int RS_BAR_WORDS = 32 * (1 + 2 * RS_BAR_GROUPS);
+constexpr int RS_BAR_COMMIT = 32 * (1 + 2 * RS_BAR_GROUPS);  // the commit word (its own 128-byte line)
+constexpr int RS_BAR_WORDS = RS_BAR_COMMIT + 32;
+constexpr unsigned RS_ABORT = 0x80000000u;
+constexpr int RS_SPINS = 1 << 22;
+
+// The commit word: arrivals in the low bits, RS_ABORT on top.  Both transitions are compare-and-swap loops with the
+// invariants  "RS_ABORT is only ever set while fewer than G workgroups have arrived"  and  "nobody arrives once RS_ABORT
+// is set", so the word ends in exactly one of the states {G arrivals, no abort} | {abort}, and every workgroup reads the
+// same verdict off it.
+__device__ __forceinline__ bool rs_aborted(const unsigned* bar) {
+    return (__hip_atomic_load(bar + RS_BAR_COMMIT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & RS_ABORT) != 0;
+}
+// returns true when the batch is (now) aborted, false when all G workgroups had already arrived (the batch commits)
+__device__ __forceinline__ bool rs_abort(unsigned* bar, unsigned G) {
+    unsigned* cw = bar + RS_BAR_COMMIT;
+    unsigned old = __hip_atomic_load(cw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (;;) {
+        if (old & RS_ABORT) return true;
+        if (old == G) return false;
+        if (__hip_atomic_compare_exchange_strong(cw, &old, old | RS_ABORT, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+            return true;
+    }
+}
+
 __device__ __forceinline__ bool rs_grid_barrier(unsigned* bar, unsigned k, int* sh_ok) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the storing waves drain their write-through stores
     __syncthreads();
@@ -139,11 +169,43 @@ __device__ __forceinline__ bool rs_grid_barrier(unsigned* bar, unsigned k, int* 
             }
         }
         const unsigned* rel = bar + 32 * (1 + RS_BAR_GROUPS + g);
-        for (int spin = 0; spin < (1 << 22) && !good; ++spin) {
+        for (int spin = 0; spin < RS_SPINS && !good; ++spin) {
             if ((int)(__hip_atomic_load(rel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - k) >= 0) good = 1;
+            else if ((spin & 63) == 63 && rs_aborted(bar)) break;  // somebody has abandoned the batch: so does this workgroup
             else __builtin_amdgcn_s_sleep(1);
         }
         *sh_ok = good;
+    }
+    __syncthreads();
+    return *sh_ok != 0;
+}
+
+// End of the batch: true = every workgroup got here (write the tiles back), false = the batch was abandoned (write
+// nothing).  `failed`: this workgroup gave up inside the loop.
+__device__ __forceinline__ bool rs_commit(unsigned* bar, bool failed, int* sh_ok) {
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned G = gridDim.x;
+        unsigned* cw = bar + RS_BAR_COMMIT;
+        int ok = -1;
+        if (failed) {
+            ok = rs_abort(bar, G) ? 0 : 1;  // (it has not arrived, so G arrivals are impossible: always an abort)
+        } else {
+            unsigned old = __hip_atomic_load(cw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (;;) {  // arrive, unless the batch is already abandoned
+                if (old & RS_ABORT) { ok = 0; break; }
+                if (__hip_atomic_compare_exchange_strong(cw, &old, old + 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+                    break;
+            }
+            for (int spin = 0; spin < RS_SPINS && ok < 0; ++spin) {
+                const unsigned v = __hip_atomic_load(cw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (v & RS_ABORT) ok = 0;
+                else if (v == G) ok = 1;
+                else __builtin_amdgcn_s_sleep(1);
+            }
+            if (ok < 0) ok = rs_abort(bar, G) ? 0 : 1;
+        }
+        *sh_ok = ok;
     }
     __syncthreads();
     return *sh_ok != 0;
@@ -303,6 +365,10 @@ __global__ __launch_bounds__(RS_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
         const bool more = cut + 1 < A.first + A.count;
         const double gn = (more && tid < NV) ? g_at(A.qgrads + (cut + 1) * n, tid) : 0.0;
         RS_STAMP(2);
+        if (cut - A.first == A.fault_at && wg == 1 % G) {  // test hook: as if this workgroup's wait had timed out
+            err = 1;
+            break;
+        }
         if (!rs_grid_barrier(A.ctr, ++bar, &sh_ok)) {
             err = 1;
             break;
@@ -427,6 +493,11 @@ __global__ __launch_bounds__(RS_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
         __syncthreads();  // sh_row / sh_col / sh_w are rewritten by the next cut
         RS_STAMP(6);
     }
+    // ---- commit or abandon (rs_commit): the tiles go back only when EVERY workgroup has finished the batch
+    if (!rs_commit(A.ctr, err != 0, &sh_ok)) {
+        if (tid == 0) atomicExch(&A.st->solve_err, RS_WAIT_ERR);  // Q untouched; the host restores the rest and reruns
+        return;
+    }
     // ---- write the tiles back: the lower triangle (diagonal tiles whole); the copies above the diagonal are dropped
     // (the pitch goes through an opaque copy so that the 72 element addresses are formed HERE: otherwise the compiler
     // keeps the ones it formed for parking alive across the whole loop -- 144 registers)
@@ -448,7 +519,6 @@ __global__ __launch_bounds__(RS_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
             }
     if (wg == 0 && tid == 0) {
         A.st->kappa = kappa;
-        if (err) atomicExch(&A.st->solve_err, RS_WAIT_ERR);
         // cuts behind a halt never ran: the status the streamed scalar stage reports for them (ELLHIP_UNKNOWN)
         const double t_last = A.st->tsq;
         for (long long c = cut; c < A.first + A.count; ++c) {

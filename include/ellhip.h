@@ -224,7 +224,15 @@ int ellhip_set_shard_symmetric(ellhip_space *s, int flag);
  *   ELLHIP_OPT_RESIDENT          0 / 1      1        Ell: ellhip_queue_run / _run_fused of >= 4 cuts park the lower triangle in the
  *                                                    chip's register files and run the whole batch in ONE persistent launch
  *                                                    (n <= 4224 on a 256-CU device: 9 us instead of 39 us per update at
- *                                                    n = 4096); 0 = always the streamed schedules
+ *                                                    n = 4096); 0 = always the streamed schedules.  The launch is
+ *                                                    cooperative (the grid is co-resident or the launch is refused) and
+ *                                                    one batch is synchronous: a refused launch or an in-launch wait that
+ *                                                    gave up leaves Q, xc and the scalars at their pre-batch values, the
+ *                                                    batch is rerun on the streamed schedule inside the same call and the
+ *                                                    handle reads 0 here from then on
+ *   ELLHIP_OPT_RESIDENT_FAULT    -1, >= 0   -1       Ell, per handle, TEST HOOK: one workgroup abandons every resident batch
+ *                                                    at this cut of it as if its wait had timed out (exercises the above)
+ *   ELLHIP_OPT_RESIDENT_ABANDONED  read only          Ell, per handle: resident batches abandoned and rerun so far
  *   ELLHIP_OPT_OVERLAP           0 / 1      1        Ell, ellhip_queue_run_fused on the lower-triangle schedule: the NEXT queued
  *                                                    cut's GEMV (LOOKAHEAD 1) or the next GROUP's products (LOOKAHEAD > 3) --
  *                                                    they read Q_base, which the cuts being taken do not change -- are issued
@@ -276,6 +284,8 @@ int ellhip_set_shard_symmetric(ellhip_space *s, int flag);
 #define ELLHIP_OPT_OVERLAP 14
 #define ELLHIP_OPT_LOOKAHEAD 15
 #define ELLHIP_OPT_QUEUE_DEPTH 16
+#define ELLHIP_OPT_RESIDENT_FAULT 17
+#define ELLHIP_OPT_RESIDENT_ABANDONED 18
 int ellhip_set_option(ellhip_space *s, int key, int64_t value);
 int ellhip_get_option(const ellhip_space *s, int key, int64_t *value);
 int ellhip_set_default_option(int key, int64_t value);
@@ -287,7 +297,8 @@ int ellhip_default_option(int key, int64_t *value);
  * drivers do (src/cutting_plane.rs:222,308).  grads: k*n doubles. */
 int ellhip_queue_upload(ellhip_space *s, int64_t k, const int32_t *kinds, const double *grads,
                         const double *beta0, const int32_t *has_beta1, const double *beta1);
-/* Enqueue cuts [first, first+count) on the stream; asynchronous.  ellhip_queue_run uses the
+/* Enqueue cuts [first, first+count) on the stream; asynchronous (except resident batches, ELLHIP_OPT_RESIDENT,
+ * which have finished when the call returns).  ellhip_queue_run uses the
  * two-pass schedule (GEMV pass + rank-1 pass per cut); ellhip_queue_run_fused the pipelined one
  * (one pass per cut: the shrink of cut i fused with the GEMV of cut i+1). Same results.
  * On a handle that records its updates (lower-triangle schedule: unsharded, even n >= 5120 by default)

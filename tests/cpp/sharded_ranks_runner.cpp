@@ -11,7 +11,9 @@
 //   [34, 40) with cut 36 failing (every rank halts at the same index) -> queue_results.
 // Checked per rank against (a) an UNSHARDED handle running the same sequence (equal blocks: with the lower-triangle GEMV
 // off, bit for bit incl. this rank's rows of Q; symmetric shards: 1e-12) and (b) the CPU oracle (1e-10).
-// Usage: sharded_ranks_runner <rccl|custom> <n> <P> <partition 0|1> <depth>      -> one JSON line
+// Usage: sharded_ranks_runner <rccl|custom> <n> <P> <partition 0|1> <depth> [<rccl|custom> <n> <P> <partition> <depth> ...]
+//        -> one JSON line per case, "case": "ranks:<mode>:<n>:<P>:<partition>:<depth>" (all cases of a test session run in
+//        ONE process: a process per case spent most of its time starting the HIP runtime)
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -173,14 +175,10 @@ double rel_inf(const double* a, const double* b, size_t m) {
 
 }  // namespace
 
-int main(int argc, char** argv) {
-    if (argc < 6) {
-        std::fprintf(stderr, "usage: %s <rccl|custom> <n> <P> <partition> <depth>\n", argv[0]);
-        return 2;
-    }
-    const std::string mode = argv[1];
-    const int64_t n = atoll(argv[2]);
-    const int P = atoi(argv[3]), partition = atoi(argv[4]), depth = atoi(argv[5]);
+int run_case(const std::string& mode, const int64_t n, const int P, const int partition, const int depth) {
+    char tagbuf[96];
+    std::snprintf(tagbuf, sizeof tagbuf, "ranks:%s:%lld:%d:%d:%d", mode.c_str(), (long long)n, P, partition, depth);
+    const std::string tag = tagbuf;
     const Cuts cuts = make_cuts(n);
     std::vector<double> xc0((size_t)n);
     for (int64_t i = 0; i < n; ++i) xc0[(size_t)i] = 0.001 * (double)(i % 13);
@@ -188,7 +186,7 @@ int main(int argc, char** argv) {
     // ---- the P ranks
     char id[ELLHIP_NCCL_ID_BYTES] = {0};
     if (mode == "rccl" && ellhip_sharded_unique_id(id) != 0) {
-        std::printf("{\"case\": \"ranks\", \"ok\": false, \"error\": \"unique_id: %s\"}\n", ellhip_last_error());
+        std::printf("{\"case\": \"%s\", \"ok\": false, \"error\": \"unique_id: %s\"}\n", tag.c_str(), ellhip_last_error());
         return 0;
     }
     inproc::Group group(P);
@@ -213,7 +211,7 @@ int main(int argc, char** argv) {
     for (auto& t : th) t.join();
     for (int r = 0; r < P; ++r)
         if (res[(size_t)r].rc) {
-            std::printf("{\"case\": \"ranks\", \"ok\": false, \"rank\": %d, \"error\": \"%s\"}\n", r, res[(size_t)r].err.c_str());
+            std::printf("{\"case\": \"%s\", \"ok\": false, \"rank\": %d, \"error\": \"%s\"}\n", tag.c_str(), r, res[(size_t)r].err.c_str());
             return 0;
         }
 
@@ -225,7 +223,7 @@ int main(int argc, char** argv) {
         PlainH h;
         const int rc = ellhip_create(&h.s, ELLHIP_SPACE_ELL, n, 1.0, nullptr, nullptr, xc0.data(), 0);
         if (rc) {
-            std::printf("{\"case\": \"ranks\", \"ok\": false, \"error\": \"ellhip_create: %s\"}\n", ellhip_last_error());
+            std::printf("{\"case\": \"%s\", \"ok\": false, \"error\": \"ellhip_create: %s\"}\n", tag.c_str(), ellhip_last_error());
             return 0;
         }
         // an equal-block shard runs full-row GEMVs: so must the reference, for the comparison to be one of bits -- and
@@ -237,13 +235,13 @@ int main(int argc, char** argv) {
         int64_t got = -1;
         if (!orc) orc = ellhip_get_option(h.s, partition == ELLHIP_SHARD_EQUAL_BLOCKS ? ELLHIP_OPT_SYMV : ELLHIP_OPT_SYMV_MIN_N, &got);
         if (orc || got != (partition == ELLHIP_SHARD_EQUAL_BLOCKS ? 0 : 512) || ellhip_defer_depth(h.s) != depth) {
-            std::printf("{\"case\": \"ranks\", \"ok\": false, \"error\": \"reference handle options: %s\"}\n", ellhip_last_error());
+            std::printf("{\"case\": \"%s\", \"ok\": false, \"error\": \"reference handle options: %s\"}\n", tag.c_str(), ellhip_last_error());
             return 0;
         }
         [&]() { sequence(h, cuts, n, out); }();
         ellhip_destroy(h.s);
         if (ref.rc) {
-            std::printf("{\"case\": \"ranks\", \"ok\": false, \"error\": \"reference: %s\"}\n", ref.err.c_str());
+            std::printf("{\"case\": \"%s\", \"ok\": false, \"error\": \"reference: %s\"}\n", tag.c_str(), ref.err.c_str());
             return 0;
         }
     }
@@ -309,9 +307,21 @@ int main(int argc, char** argv) {
     if (equal) note(bits, "equal blocks are not bit-identical to the unsharded engine", -1);
     else note(worst_ref <= 1e-12, "symmetric shards vs unsharded", -1);
     orc_ell_free(o);
-    std::printf("{\"case\": \"ranks\", \"ok\": %s, \"mode\": \"%s\", \"n\": %lld, \"P\": %d, \"partition\": %d, \"depth\": %d, \"bit_identical\": %s, "
+    std::printf("{\"case\": \"%s\", \"ok\": %s, \"mode\": \"%s\", \"n\": %lld, \"P\": %d, \"partition\": %d, \"depth\": %d, \"bit_identical\": %s, "
                 "\"vs_unsharded\": %.3e, \"vs_oracle\": %.3e, \"collectives\": %ld, \"why\": \"%s\"}\n",
-                ok ? "true" : "false", mode.c_str(), (long long)n, P, partition, depth, bits ? "true" : "false", worst_ref, worst_orc,
+                tag.c_str(), ok ? "true" : "false", mode.c_str(), (long long)n, P, partition, depth, bits ? "true" : "false", worst_ref, worst_orc,
                 mode == "custom" ? group.ncalls : -1L, why.c_str());
+    return 0;
+}
+
+int main(int argc, char** argv) {
+    if (argc < 6 || (argc - 1) % 5 != 0) {
+        std::fprintf(stderr, "usage: %s <rccl|custom> <n> <P> <partition> <depth> [... more cases]\n", argv[0]);
+        return 2;
+    }
+    for (int a = 1; a + 4 < argc; a += 5) {
+        run_case(argv[a], atoll(argv[a + 1]), atoi(argv[a + 2]), atoi(argv[a + 3]), atoi(argv[a + 4]));
+        std::fflush(stdout);
+    }
     return 0;
 }

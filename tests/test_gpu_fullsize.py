@@ -231,6 +231,43 @@ def test_ell_n32768_matches_oracle(gpu, orc):
         assert np.max(np.abs(qg[r:r + 512] - qo[r:r + 512])) <= TOL * scale
 
 
+def test_ell_n32768_default_queue_run_matches_oracle(gpu, orc):
+    """The configuration bench.py times as `n32768-deep` (BASELINE config 4's size on ONE GPU, Q = 8 GiB): 56 deep cuts
+    through `queue_run(fused=True)` at the defaults of a new handle of this size -- depth 24, lookahead 16, 48 recorded
+    updates per apply pass: groups of 16, 16, 16 on the matrix cores (k_symm_mfma on its 512 x 16 grid), the group stage
+    sized for 48 slots, the in-run rank-48 apply pass (k_apply_mfma<48> on 512 x 32), a group of 8 left recorded when the
+    state is read -- against the oracle's row-parallel loop (tests/test_oracle_pins.py ties it bit for bit to the reference
+    loop order): every cut's tsq, xc, kappa, and three 512-row bands of Q (8 GiB each side: bands bound the temporaries)."""
+    from ellalgo_rs_amd import synth
+    from util import TOL
+    n, k = 32768, 56
+    kinds, grads, b0, _ = synth.deep_cuts(n, k)
+    e = gpu.Ell.new_with_scalar(1.0, np.zeros(n))
+    assert e.defer_depth == 24 and e.get_option(gpu.capi.OPT_LOOKAHEAD) == 16 and e.get_option(gpu.capi.OPT_QUEUE_DEPTH) == 48
+    e.profile_enable(True)
+    e.queue_upload(kinds, grads, b0)
+    e.queue_run(0, k, fused=True)
+    st, ts = e.queue_results()
+    prof = e.profile_read()
+    assert prof["symv"][1] == 4 and prof["apply"][1] == 1, prof     # groups of 16, 16, 16 | 8; ONE apply pass, at cut 48
+    assert np.all(st == 0)
+    o = orc.OracleEll.new_with_scalar(1.0, np.zeros(n))
+    for i in range(k):
+        assert o.update_rowwise_mt(0, grads[i], b0[i], None) == 0
+        assert abs(ts[i] - o.tsq) <= TOL * abs(o.tsq), i
+    assert abs(e.kappa - o.kappa) <= TOL * abs(o.kappa)
+    xo = np.array(o.xc)
+    assert np.max(np.abs(e.xc() - xo)) <= TOL * np.max(np.abs(xo))
+    qg = e.mq                      # applies the eight recorded updates and mirrors the lower triangle
+    qo = o.mq
+    scale = float(np.max(np.abs(np.diagonal(qo))))
+    for r in (0, n // 2 - 256, n - 512):
+        assert np.max(np.abs(qg[r:r + 512] - qo[r:r + 512])) <= TOL * scale, r
+        assert np.array_equal(qg[r:r + 512, r:r + 512], qg[r:r + 512, r:r + 512].T)
+    # ... and not a comparison of an untouched identity: 56 rank-1 corrections left their mark off the diagonal
+    assert np.count_nonzero(qg[n - 512:, :512]) == 512 * 512
+
+
 def test_ellstable_n32768_persistent_equals_per_block_launches(gpu):
     """n = 32768 is the largest size the persistent solves cover (256 column strips = one workgroup per CU) and the one
     size where k_st_fwd_persist / k_st_bwd_persist are the DEFAULT (the helped forms need two workgroups per strip).

@@ -17,7 +17,7 @@ import numpy as np
 import pytest
 
 from test_gpu_resident import _cuts
-from util import TOL, assert_state_close, set_default
+from util import TOL, assert_state_close, dense_spd, set_default
 
 pytestmark = pytest.mark.gpu
 
@@ -39,8 +39,9 @@ def _same(a, b, exact):
     return np.max(np.abs(a - b)) <= RTOL * max(np.max(np.abs(a)), 1e-300)
 
 
-def _drive(gpu, n, depth, mode, kinds, grads, b0, b1, pieces, direct=(), flush_after=()):
-    e = gpu.Ell.new_with_scalar(1.0, np.linspace(-1.0, 1.0, n))
+def _drive(gpu, n, depth, mode, kinds, grads, b0, b1, pieces, direct=(), flush_after=(), q0=None):
+    e = gpu.Ell.new_with_scalar(1.0, np.linspace(-1.0, 1.0, n)) if q0 is None else \
+        gpu.Ell.new_with_matrix(1.0, q0, np.linspace(-1.0, 1.0, n))
     e.defer_depth = depth
     e.set_option(gpu.capi.OPT_OVERLAP, mode[0])
     e.set_option(gpu.capi.OPT_LOOKAHEAD, mode[1])
@@ -57,17 +58,21 @@ def _drive(gpu, n, depth, mode, kinds, grads, b0, b1, pieces, direct=(), flush_a
     return e, st, ts
 
 
-@pytest.mark.parametrize("n,depth", [(512, 8), (1024, 16), (1024, 24), (2050, 24), (4096, 24)])
-def test_overlapped_runs_equal_the_serial_issue_order_to_the_bit(gpu, orc, n, depth):
+@pytest.mark.parametrize("n,depth,dense", [(512, 8, False), (1024, 16, False), (1024, 24, False), (2050, 24, False),
+                                           (4096, 24, False), (1024, 24, True), (2112, 24, True)])
+def test_overlapped_runs_equal_the_serial_issue_order_to_the_bit(gpu, orc, n, depth, dense):
+    """dense: from a dense SPD start matrix (new_with_matrix) -- the first group's products already multiply a full matrix
+    (every tile of k_symm_mfma / k_symv carries data from the first pass on), not the identity."""
     set_default("SYMV_MIN_N", 512)
     set_default("RESIDENT", 0)
     k = 70
     kinds, grads, b0, b1 = _cuts(n, k, 31 * n + depth)
+    q0 = dense_spd(n, 5 * n + depth) if dense else None
     pieces = [(0, 9), (9, 1), (10, 33), (43, 27)]
     st_ok = np.arange(k) != 43
     outs = []
     for mode in MODES:
-        e, st, ts = _drive(gpu, n, depth, mode, kinds, grads, b0, b1, pieces, direct=(43,), flush_after=(10,))
+        e, st, ts = _drive(gpu, n, depth, mode, kinds, grads, b0, b1, pieces, direct=(43,), flush_after=(10,), q0=q0)
         assert np.all(st[:43] == 0) and np.all(st[44:] == 0)
         outs.append((st, ts, e.xc(), e.kappa, e.mq, e))
     a = outs[0]
@@ -76,12 +81,15 @@ def test_overlapped_runs_equal_the_serial_issue_order_to_the_bit(gpu, orc, n, de
         assert np.array_equal(a[0], b[0]) and _same(a[1][st_ok], b[1][st_ok], exact) and _same(a[2], b[2], exact), mode
         assert _same([a[3]], [b[3]], exact) and _same(a[4], b[4], exact), mode
     b = outs[-2]
-    o = orc.OracleEll.new_with_scalar(1.0, np.linspace(-1.0, 1.0, n))
+    o = orc.OracleEll.new_with_scalar(1.0, np.linspace(-1.0, 1.0, n)) if q0 is None else \
+        orc.OracleEll.new_with_matrix(1.0, q0, np.linspace(-1.0, 1.0, n))
     for i in range(k):
         assert o.update(int(kinds[i]), grads[i], b0[i], None if np.isnan(b1[i]) else b1[i]) == 0
         if i != 43:
             assert abs(b[1][i] - o.tsq) <= TOL * abs(o.tsq), i
-    assert_state_close(b[5], o, what=f"overlapped n={n} depth={depth}")
+    assert_state_close(b[5], o, what=f"overlapped n={n} depth={depth} dense={dense}")
+    if dense:   # ... and the default mode (the last one: lookahead 16, 48 per apply pass) as well
+        assert_state_close(outs[-1][5], o, what=f"lookahead 16 n={n} depth={depth} dense start")
 
 
 @pytest.mark.parametrize("depth", [8, 24])
@@ -140,15 +148,18 @@ def test_overlapped_run_at_the_default_size_and_depth(gpu):
     assert prof["symv_reduce"][1] == 4 and prof["symv"][1] == 4 and prof["apply"][1] == 2
 
 
-@pytest.mark.parametrize("seed", range(int(os.environ.get("ELLHIP_FUZZ_OPTION_SEEDS", "24"))))   # (soak: ELLHIP_FUZZ_OPTION_SEEDS=400)
-def test_random_option_mixes_against_the_oracle(gpu, orc, seed):
-    """Seeded walks over what the queue run can be asked to do: size (multiples of 64 and not, both segment widths), depth,
-    LOOKAHEAD / QUEUE_DEPTH / OVERLAP, the run cut into random pieces with direct updates, flushes, option switches and
-    observers in between, a failing cut at a random place; every cut's status and tsq and the final state against the
-    oracle's plain sequence of updates (north-star tolerance)."""
+# Seeds the 400-seed soak of round 3 failed on with the library as it was before 957140e (products issued ahead on the second
+# stream were not ordered after an apply pass of the single-cut path): found again in round 4 by running that soak against
+# the old library (tools/experiments/README_soak_r03.md), pinned here so the default suite always walks them.
+PINNED_SEEDS = [39, 99, 150, 191, 203, 332, 336, 369]
+_NSEEDS = int(os.environ.get("ELLHIP_FUZZ_OPTION_SEEDS", "24"))   # (soak: ELLHIP_FUZZ_OPTION_SEEDS=400)
+_SEEDS = list(range(_NSEEDS)) + [x for x in PINNED_SEEDS if x >= _NSEEDS]
+
+
+def _option_walk(gpu, seed, serial):
+    """One seeded walk (see test_random_option_mixes_against_the_oracle).  serial: every ELLHIP_OPT_OVERLAP = 1 of the walk
+    becomes 2 -- the same kernels in the same order of issue, all on the handle's own stream."""
     rng = np.random.default_rng(1000 + seed)
-    set_default("SYMV_MIN_N", 512)
-    set_default("RESIDENT", 0)
     n = int(rng.choice([512, 576, 640, 1000, 1024, 1090, 2112, 4096 if seed % 6 == 0 else 1536]))
     depth = int(rng.choice([8, 16, 24, 24]))
     k = int(rng.integers(50, 110))
@@ -160,22 +171,13 @@ def test_random_option_mixes_against_the_oracle(gpu, orc, seed):
     def reroll():
         e.set_option(gpu.capi.OPT_LOOKAHEAD, int(rng.choice([1, 2, 3, 4, 7, 12, 16])))
         e.set_option(gpu.capi.OPT_QUEUE_DEPTH, int(rng.choice([0, 48])))
-        e.set_option(gpu.capi.OPT_OVERLAP, int(rng.integers(0, 2)))
+        ov = int(rng.integers(0, 2))
+        e.set_option(gpu.capi.OPT_OVERLAP, 2 if (serial and ov) else ov)
 
     reroll()
     e.queue_upload(kinds, grads, b0, b1)
-    o = orc.OracleEll.new_with_scalar(1.0, np.linspace(-1.0, 1.0, n))
-    want_st, want_ts, halted = [], [], False
-    for i in range(k):
-        if halted:
-            want_st.append(3)
-            want_ts.append(None)
-            continue
-        so = o.update(int(kinds[i]), grads[i], b0[i], None if np.isnan(b1[i]) else b1[i])
-        want_st.append(so)
-        want_ts.append(o.tsq)
-        halted = so != 0
     stop = bad if bad is not None else k     # cuts [0, stop) succeed
+    direct = set()
     pos = 0
     while pos < k:
         step = int(rng.integers(1, min(60, k - pos) + 1))
@@ -184,7 +186,7 @@ def test_random_option_mixes_against_the_oracle(gpu, orc, seed):
             # a synchronous update of cut `pos` (only while the queue has not halted: a halted queue refuses nothing, but the
             # oracle's sequence has no cut behind the failing one)
             assert int(e._update(int(kinds[pos]), (grads[pos], _beta(b0, b1, pos)))) == 0
-            want_st[pos] = -1          # never ran in the queue
+            direct.add(pos)            # never ran in the queue
             pos += 1
             continue
         e.queue_run(pos, step, fused=True)
@@ -197,10 +199,37 @@ def test_random_option_mixes_against_the_oracle(gpu, orc, seed):
         elif r < 0.4 and (bad is None or pos <= bad):
             assert abs(e.kappa - 0.0) >= 0.0 and e.xc().shape == (n,)   # observers in the middle of the sequence
     st, ts = e.queue_results()
+    return dict(n=n, depth=depth, k=k, bad=bad, cuts=(kinds, grads, b0, b1), direct=direct, e=e, st=st, ts=ts)
+
+
+@pytest.mark.parametrize("seed", _SEEDS)
+def test_random_option_mixes_against_the_oracle(gpu, orc, seed):
+    """Seeded walks over what the queue run can be asked to do: size (multiples of 64 and not, both segment widths), depth,
+    LOOKAHEAD / QUEUE_DEPTH / OVERLAP, the run cut into random pieces with direct updates, flushes, option switches and
+    observers in between, a failing cut at a random place; every cut's status and tsq and the final state against the
+    oracle's plain sequence of updates (north-star tolerance).  Every walk runs twice: with the second stream, and with the
+    same kernels issued in the same order on ONE stream (ELLHIP_OPT_OVERLAP = 2); the two must agree to the bit -- nothing in
+    the data path depends on timing, so any difference is a missing cross-stream ordering."""
+    set_default("SYMV_MIN_N", 512)
+    set_default("RESIDENT", 0)
+    w = _option_walk(gpu, seed, serial=False)
+    ws = _option_walk(gpu, seed, serial=True)
+    n, k, bad, e = w["n"], w["k"], w["bad"], w["e"]
+    assert np.array_equal(w["st"], ws["st"]) and np.array_equal(w["ts"], ws["ts"], equal_nan=True), f"seed {seed}: queue results"
+    assert np.array_equal(e.xc(), ws["e"].xc()) and e.kappa == ws["e"].kappa, f"seed {seed}: xc / kappa overlapped vs serial"
+    assert np.array_equal(e.mq, ws["e"].mq), f"seed {seed}: Q overlapped vs one stream"
+    kinds, grads, b0, b1 = w["cuts"]
+    o = orc.OracleEll.new_with_scalar(1.0, np.linspace(-1.0, 1.0, n))
+    st, ts = w["st"], w["ts"]
+    halted = False
     for i in range(k):
-        if want_st[i] == -1:
+        if halted:
+            assert int(st[i]) == 3, (i, int(st[i]), bad)
             continue
-        assert int(st[i]) == want_st[i], (i, int(st[i]), want_st[i], bad)
-        if want_ts[i] is not None:
-            assert abs(ts[i] - want_ts[i]) <= TOL * abs(want_ts[i]), (i, bad)
-    assert_state_close(e, o, what=f"seed {seed}: n={n} depth={depth} bad={bad}")
+        so = o.update(int(kinds[i]), grads[i], b0[i], None if np.isnan(b1[i]) else b1[i])
+        halted = so != 0
+        if i in w["direct"]:
+            continue
+        assert int(st[i]) == so, (i, int(st[i]), so, bad)
+        assert abs(ts[i] - o.tsq) <= TOL * abs(o.tsq), (i, bad)
+    assert_state_close(e, o, what=f"seed {seed}: n={n} depth={w['depth']} bad={bad}")

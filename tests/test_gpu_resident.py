@@ -7,7 +7,7 @@ tolerance, against the streamed schedules to rounding, bit-reproducible run to r
 import numpy as np
 import pytest
 
-from util import TOL, assert_state_close, set_default
+from util import TOL, assert_state_close, dense_spd, set_default
 
 pytestmark = pytest.mark.gpu
 
@@ -43,13 +43,23 @@ def _resident_launches(e):
     return e.profile_read()["resident"][1]
 
 
-@pytest.mark.parametrize("n", [2, 63, 64, 65, 130, 1000, 1001, 1408, 1409, 2048, 2817, 2818, 4096, 4224])
-def test_resident_queue_run_matches_the_oracle(gpu, orc, n):
-    """One batch of 24 cuts from a non-trivial start (xc != 0, kappa != 1, random SPD matrix for the small sizes)."""
+@pytest.mark.parametrize("n,dense", [(2, 1), (63, 1), (64, 1), (65, 1), (130, 1), (1000, 0), (1001, 0), (1408, 0), (1409, 0), (2048, 0),
+                                     (2817, 0), (2818, 0), (4096, 0), (4224, 0), (1408, 2), (2048, 2), (2817, 2), (4096, 2)])
+def test_resident_queue_run_matches_the_oracle(gpu, orc, n, dense):
+    """One batch of 24 cuts from a non-trivial start (xc != 0, kappa != 1; dense = 1: a random SPD matrix for the small
+    sizes, dense = 2: a dense SPD matrix at R = 1, 2 and 3 -- n = 4096: the LDS-resident third tile column holds data
+    at entry, not zeros)."""
     k = 24
     kinds, grads, b0, b1 = _cuts(n, k, 100 + n)
     xc0 = np.linspace(-1.0, 1.0, n)
-    if n <= 130:
+    if dense == 2:
+        q0 = dense_spd(n, 7 * n)
+        e = gpu.Ell.new_with_matrix(1.5, q0, xc0)
+        o = orc.OracleEll.new_with_matrix(1.5, q0, xc0)
+        scale = float(np.sqrt(1.5))
+        b0, b1 = b0 * scale, b1 * scale
+        del q0
+    elif n <= 130:
         rng = np.random.default_rng(n)
         a = rng.standard_normal((n, n)) * 0.1
         q0 = np.eye(n) + a @ a.T
@@ -201,3 +211,113 @@ def test_what_does_not_take_the_resident_kernel(gpu):
     s = gpu.EllStable.new_with_scalar(1.0, np.zeros(512))
     with pytest.raises(gpu.capi.EllHipError):
         s.set_option(gpu.capi.OPT_RESIDENT, 1)
+
+
+@pytest.mark.parametrize("n,fault_at", [(200, 0), (2048, 5), (4096, 11), (4096, 23)])
+def test_abandoned_resident_batch_is_undone_and_rerun_on_the_streamed_schedule(gpu, orc, n, fault_at):
+    """A bounded in-launch wait that gives up (here: one workgroup abandons the batch at cut `fault_at`, ELLHIP_OPT_RESIDENT_FAULT)
+    must never leave a half-updated matrix: no workgroup writes its tiles back (rs_commit), xc / the scalar state / the
+    batch's queue results are restored, and the same call reruns the batch on the streamed schedule.  Checked against a
+    twin handle that took the streamed schedule for that batch from the start -- to the bit, which it can only be when the
+    pre-batch state was restored exactly -- and against the oracle."""
+    k = 36
+    kinds, grads, b0, b1 = _cuts(n, k, 31 * n + fault_at)
+    twins = []
+    for faulty in (True, False):
+        e = gpu.Ell.new_with_scalar(1.0, np.linspace(-1.0, 1.0, n))
+        e.profile_enable(True)
+        e.queue_upload(kinds, grads, b0, b1)
+        e.queue_run(0, 12, fused=True)                       # a resident batch that commits
+        assert e.get_option(gpu.capi.OPT_RESIDENT_ABANDONED) == 0
+        if faulty:
+            e.set_option(gpu.capi.OPT_RESIDENT_FAULT, fault_at)
+        else:
+            e.set_option(gpu.capi.OPT_RESIDENT, 0)
+        e.queue_run(12, 24, fused=True)                      # abandoned at cut 12 + fault_at, undone, rerun | streamed
+        if faulty:
+            assert e.get_option(gpu.capi.OPT_RESIDENT_ABANDONED) == 1 and e.get_option(gpu.capi.OPT_RESIDENT) == 0
+            assert _resident_launches(e) == 2
+        st, ts = e.queue_results()
+        assert np.all(st == 0)
+        twins.append((ts, e.xc(), e.kappa, e.mq, e))
+    a, b = twins
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[2] == b[2] and np.array_equal(a[3], b[3])
+    o = orc.OracleEll.new_with_scalar(1.0, np.linspace(-1.0, 1.0, n))
+    for i in range(k):
+        assert o.update_rowwise_mt(int(kinds[i]), grads[i], b0[i], None if np.isnan(b1[i]) else b1[i]) == 0
+        assert abs(a[0][i] - o.tsq) <= TOL * abs(o.tsq), i
+    assert_state_close(a[4], o, what=f"after an abandoned batch n={n}")
+    # the handle keeps working (streamed from now on), and switching the option back on brings the resident kernel back
+    e = a[4]
+    e.set_option(gpu.capi.OPT_RESIDENT_FAULT, -1)
+    e.set_option(gpu.capi.OPT_RESIDENT, 1)
+    e.queue_upload(kinds, grads, b0, b1)
+    e.queue_run(0, 4, fused=True)
+    e.queue_results()
+    assert _resident_launches(e) == 1 and e.get_option(gpu.capi.OPT_RESIDENT_ABANDONED) == 1
+
+
+def test_abandoned_batch_with_a_failing_cut_inside(gpu, orc):
+    """The batch is abandoned AFTER one of its cuts failed?  No: the kernel leaves the loop at the failing cut, so a fault
+    placed behind it never fires and the batch commits; a fault in front of it abandons the batch and the rerun halts at
+    the same cut.  Both end in the oracle's state with the same queue results."""
+    n, k, bad = 2048, 20, 9
+    kinds, grads, b0, b1 = _cuts(n, k, 4242, fail_at=bad)
+    outs = []
+    for fault_at, abandoned in ((15, 0), (3, 1)):
+        e = gpu.Ell.new_with_scalar(1.0, np.zeros(n))
+        e.set_option(gpu.capi.OPT_RESIDENT_FAULT, fault_at)
+        e.queue_upload(kinds, grads, b0, b1)
+        e.queue_run(0, k, fused=False)
+        st, ts = e.queue_results()
+        assert e.get_option(gpu.capi.OPT_RESIDENT_ABANDONED) == abandoned
+        assert list(st[:bad]) == [0] * bad and int(st[bad]) == 1 and all(int(x) == 3 for x in st[bad + 1:])
+        outs.append(e)
+    o = orc.OracleEll.new_with_scalar(1.0, np.zeros(n))
+    for i in range(bad):
+        assert o.update(int(kinds[i]), grads[i], b0[i], None if np.isnan(b1[i]) else b1[i]) == 0
+    assert o.update(int(kinds[bad]), grads[bad], b0[bad], None) == 1
+    for e in outs:
+        assert_state_close(e, o, what="failing cut inside a batch")
+
+
+def test_two_handles_run_resident_batches_from_two_host_threads(gpu, orc):
+    """BSearchAdaptor clones the space per probe (src/cutting_plane.rs:409-418): two handles on one card, each driven from its
+    own host thread through resident batches of n = 4096 (253 workgroups each: two such grids cannot be co-resident).  The
+    launches are cooperative, so the runtime runs one grid at a time; whatever the interleaving, every handle must end in
+    the oracle's state -- right results, or a batch abandoned and rerun (counted), never a matrix that mixes update counts."""
+    import threading
+    n, k, piece = 4096, 96, 12
+    kinds, grads, b0, b1 = _cuts(n, k, 909)
+    hs = []
+    for _ in range(2):
+        e = gpu.Ell.new_with_scalar(1.0, np.linspace(-1.0, 1.0, n))
+        e.queue_upload(kinds, grads, b0, b1)
+        hs.append(e)
+    start = threading.Barrier(2)
+    errs = []
+
+    def worker(e):
+        try:
+            start.wait()
+            for a in range(0, k, piece):
+                e.queue_run(a, piece, fused=True)
+        except Exception as ex:   # noqa: BLE001 -- reported below
+            errs.append(repr(ex))
+
+    ts = [threading.Thread(target=worker, args=(e,)) for e in hs]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errs, errs
+    o = orc.OracleEll.new_with_scalar(1.0, np.linspace(-1.0, 1.0, n))
+    want = np.empty(k)
+    for i in range(k):
+        assert o.update_rowwise_mt(int(kinds[i]), grads[i], b0[i], None if np.isnan(b1[i]) else b1[i]) == 0
+        want[i] = o.tsq
+    for e in hs:
+        st, tsq = e.queue_results()
+        assert np.all(st == 0)
+        assert np.max(np.abs(tsq - want) / want) <= TOL
+        assert_state_close(e, o, what=f"concurrent resident batches (abandoned: {e.get_option(gpu.capi.OPT_RESIDENT_ABANDONED)})")

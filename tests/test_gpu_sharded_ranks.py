@@ -18,16 +18,31 @@ CASES = [
     (192, 2, EQUAL, 1), (192, 3, EQUAL, 8), (2048, 2, EQUAL, 1), (2048, 2, EQUAL, 8), (3072, 3, EQUAL, 8), (4096, 2, EQUAL, 8),
     (512, 2, SYMMETRIC, 8), (2048, 2, SYMMETRIC, 8), (2048, 3, SYMMETRIC, 16), (4096, 2, SYMMETRIC, 16), (4096, 3, SYMMETRIC, 8),
     (2048, 2, SYMMETRIC, 24), (4096, 3, SYMMETRIC, 24),
+    # P = 8, the only rank count the driver's node runs: both partitions; symmetric shards at depth 8 (groups end at every 8th
+    # cut) and 24 (the pipelined runs in groups of up to 16, one all-reduce per group)
+    (4096, 8, EQUAL, 1), (4096, 8, EQUAL, 8), (4096, 8, SYMMETRIC, 8), (4096, 8, SYMMETRIC, 24),
 ]
+MODES = ["rccl", "custom"]
 
 
-@pytest.mark.parametrize("mode", ["rccl", "custom"])
-@pytest.mark.parametrize("n,P,partition,depth", CASES)
-def test_ranks_on_one_gpu(gpu, mode, n, P, partition, depth):
+@pytest.fixture(scope="module")
+def ranks_results(gpu):
+    """Every case in ONE runner process (round 3 started one per case: 26 HIP start-ups, the file took 80 s of the suite)."""
     from cpp_build import build_fake_rccl, build_runner, run_json_lines
     exe = build_runner("sharded_ranks_runner.cpp", "hip+oracle")
-    env = {"ELLHIP_RCCL_PATH": build_fake_rccl()} if mode == "rccl" else None
-    out = run_json_lines(exe, mode, str(n), str(P), str(partition), str(depth), env=env)["ranks"]
+    args = []
+    for mode in MODES:
+        for n, P, partition, depth in CASES:
+            args += [mode, str(n), str(P), str(partition), str(depth)]
+    return run_json_lines(exe, *args, env={"ELLHIP_RCCL_PATH": build_fake_rccl()}, timeout=900)
+
+
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("n,P,partition,depth", CASES)
+def test_ranks_on_one_gpu(ranks_results, mode, n, P, partition, depth):
+    key = f"ranks:{mode}:{n}:{P}:{partition}:{depth}"
+    assert key in ranks_results, f"the runner printed no line for {key} (did an earlier case take the process down?)"
+    out = ranks_results[key]
     assert out["ok"] is True, out
     assert out["vs_oracle"] <= 1e-10
     if partition == EQUAL:

@@ -75,6 +75,18 @@ def beta_of(b0, b1):
     return float(b0) if b1 is None else (float(b0), float(b1))
 
 
+def dense_spd(n, seed, rank=32, amp=0.3):
+    """A dense symmetric positive definite start matrix, symmetric to the bit: I + A A' with A = amp * randn(n, rank).
+    Every entry is non-zero, g'Qg stays O(1) for unit g (1 + |A'g|^2 ~ 1 + amp^2 rank), so cut sequences scaled for
+    Q0 = I (tau ~ 1) stay well-posed.  (Round 3's fast paths were only ever tested from Q0 = I, where the first group of
+    a queue run multiplies the identity and the off-diagonal tiles see data only after the first apply pass.)"""
+    rng = np.random.default_rng(seed)
+    a = rng.standard_normal((n, rank)) * amp
+    q = a @ a.T
+    q[np.arange(n), np.arange(n)] += 1.0
+    return np.ascontiguousarray(0.5 * (q + q.T))
+
+
 def random_factor(n, seed, junk=True):
     """Packed EllStable state with a NON-trivial factor (src/ell_stable.rs:18-27 accepts any matrix): positive random
     diagonal, unit-upper-triangular factor with entries ~ 0.1/sqrt(n), and junk in the scratch triangle (the forward
