@@ -50,5 +50,26 @@ def build(force: bool = False, verbose: bool = False) -> str:
     return LIB_PATH
 
 
+HOST_DIR = os.path.join(PKG_DIR, "host")
+LIVE_LOOP_SRC = os.path.join(HOST_DIR, "bench", "live_loop.cpp")
+LIVE_LOOP_EXE = os.path.join(HOST_DIR, "bench", "live_loop")
+
+
+def build_host_tools(force: bool = False, verbose: bool = False) -> str:
+    """host/bench/live_loop: the C++ drivers (host/ellhip/*.hpp) around the C ABI with a host oracle -- what bench.py times as
+    `live_loop`.  Plain g++: the host side links libellhip.so and nothing else."""
+    deps = [LIVE_LOOP_SRC, LIB_PATH] + [os.path.join(HOST_DIR, "ellhip", f) for f in os.listdir(os.path.join(HOST_DIR, "ellhip"))] + \
+           [os.path.join(REPO_ROOT, "include", f) for f in PUBLIC_HEADERS]
+    if not force and os.path.exists(LIVE_LOOP_EXE) and all(os.path.getmtime(d) <= os.path.getmtime(LIVE_LOOP_EXE) for d in deps):
+        return LIVE_LOOP_EXE
+    cmd = ["g++", "-std=c++17", "-O2", "-Wall", "-o", LIVE_LOOP_EXE, LIVE_LOOP_SRC, "-L" + PKG_DIR, "-lellhip",
+           "-Wl,-rpath," + PKG_DIR, "-Wl,-rpath,$ORIGIN/../..", "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib"]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIVE_LOOP_EXE
+
+
 if __name__ == "__main__":
     print(build(force=True, verbose=True))
+    print(build_host_tools(force=True, verbose=True))

@@ -1118,6 +1118,32 @@ __global__ __launch_bounds__(256) void k_symm_mfma(const double* __restrict__ Q,
     }
 }
 
+// ----------------------------------------------------------------------------------- k_publish ---
+// The live SearchSpace loop (src/cutting_plane.rs:299-311: xc() -> oracle -> update_*_cut) needs, after every update, the
+// cut's status / tsq (the caller's next branch, :308) and the new centre (the oracle's next argument, :300) -- and nothing
+// else: the shrink of Q may still be running when the call returns.  One workgroup, right behind the scalar stage, writes
+// the 128 KiB centre and the scalar state straight into pinned host memory (fine-grained) and then the update's sequence
+// number with a system-scope release; the host polls that word instead of issuing a device-to-host copy and waiting for
+// the whole stream (ellhip_update_end / ellhip_cut: live_publish, live_wait).
+struct LiveMirror {
+    DevState st;
+    unsigned long long seq;
+};
+static_assert(sizeof(DevState) % sizeof(long long) == 0, "k_publish copies DevState in 8-byte words");
+__global__ __launch_bounds__(1024) void k_publish(const DevState* __restrict__ st, const double* __restrict__ xc, long long n,
+                                                  LiveMirror* __restrict__ m, double* __restrict__ h_xc,
+                                                  unsigned long long seq) {
+    const long long n2 = n / 2;
+    for (long long i = threadIdx.x; i < n2; i += 1024)
+        *reinterpret_cast<double2_t*>(h_xc + 2 * i) = *reinterpret_cast<const double2_t*>(xc + 2 * i);
+    if ((n & 1) && threadIdx.x == 0) h_xc[n - 1] = xc[n - 1];
+    if (threadIdx.x < (int)(sizeof(DevState) / sizeof(long long)))
+        reinterpret_cast<long long*>(&m->st)[threadIdx.x] = reinterpret_cast<const long long*>(st)[threadIdx.x];
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(&m->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // After a flush: forget the pending updates (unused slots must read as exact zeros).
 __global__ __launch_bounds__(256) void k_pend_reset(double* __restrict__ pend, double* __restrict__ cpend,
                                                     long long total, DevState* __restrict__ st) {

@@ -172,6 +172,12 @@ struct ellhip_space {
 
     double* h_stage[2] = {nullptr, nullptr};  // pinned, n doubles each
     DevState* h_result = nullptr;             // pinned
+    // live updates (ellhip_update / ellhip_cut): k_publish writes the scalar state and the centre into these right behind
+    // the scalar stage and the host polls the sequence number -- no device-to-host copy, no wait for the whole stream
+    LiveMirror* h_live = nullptr;             // pinned, fine-grained
+    double* h_xc = nullptr;                   // pinned, fine-grained: the centre as of the last published update
+    unsigned long long live_seq = 0;
+    bool xc_host_valid = false;               // h_xc equals d_xc (nothing has written the centre on the device since)
 
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
@@ -736,6 +742,7 @@ int do_prime(ellhip_space* s, const double* g_dev, int slot) {
 // scalar stage of the primed cut (asynchronous; the caller reads the state back if it needs it)
 int do_cut(ellhip_space* s, const double* g_dev, const CutParams* cp_dev, CutParams cp_val, int queue_mode, int* qst,
            double* qtsq) {
+    s->xc_host_valid = false;  // the scalar stage moves the centre
     if (s->variant != ELLHIP_SPACE_ELL) return ellstable_issue(s, g_dev, cp_dev, cp_val, queue_mode, qst, qtsq);
     // The dot products a prime left in d_partial belong to THIS cut only: whatever path the cut takes (also the
     // non-deferred one, after a depth switch between prime and cut) they are spent now, and a gradient primed later
@@ -840,6 +847,44 @@ int read_back(ellhip_space* s) {
         return fail(ELLHIP_E_HIP, "a bounded in-launch wait of an EllStable persistent solve timed out; this handle now uses one "
                                   "launch per block (no inter-workgroup waits)");
     }
+    return 0;
+}
+
+// ---- live updates: what the caller's next statement needs, and no more ---------------------------------------------
+// live_publish is enqueued right behind the scalar stage of a direct update; live_wait returns as soon as that update's
+// status / tsq / kappa and the new centre are in host memory.  Whatever the update still has in flight behind it (the
+// rank-1 pass, an apply pass of the recorded schedule) keeps running: the next call on the handle is ordered after it by
+// the stream.  Same observable contract as read_back (h_result, kappa, tsq, the solve_err protocol).
+int live_publish(ellhip_space* s) {
+    s->live_seq += 1;
+    hipLaunchKernelGGL(k_publish, dim3(1), dim3(1024), 0, s->stream, (const DevState*)s->d_st, (const double*)s->d_xc, s->n,
+                       s->h_live, s->h_xc, s->live_seq);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+int live_wait(ellhip_space* s) {
+    const unsigned long long want = s->live_seq;
+    const unsigned long long* seq = &s->h_live->seq;
+    for (unsigned spin = 1;; ++spin) {
+        if (__atomic_load_n(seq, __ATOMIC_ACQUIRE) == want) break;
+        if ((spin & 0x3fffu) == 0) {  // now and then: is the stream still alive?
+            const hipError_t q = hipStreamQuery(s->stream);
+            if (q == hipSuccess) {    // drained: the word must be there
+                if (__atomic_load_n(seq, __ATOMIC_ACQUIRE) == want) break;
+                return fail(ELLHIP_E_HIP, "live update: the stream drained without publishing its result");
+            }
+            if (q != hipErrorNotReady) return fail(ELLHIP_E_HIP, "live update", q);
+        }
+#if defined(__x86_64__)
+        __builtin_ia32_pause();
+#endif
+    }
+    *s->h_result = s->h_live->st;
+    s->kappa = s->h_result->kappa;
+    s->tsq = s->h_result->tsq;
+    s->scalars_stale = false;
+    s->xc_host_valid = true;
+    if (s->h_result->solve_err) return read_back(s);  // (rare: the full protocol, with the stream drained)
     return 0;
 }
 
@@ -998,6 +1043,9 @@ int alloc_common(ellhip_space* s) {
         HIPCHK(hipGetLastError());
     }
     HIPCHK(hipHostMalloc(&s->h_result, sizeof(DevState), hipHostMallocDefault));
+    HIPCHK(hipHostMalloc(&s->h_live, sizeof(LiveMirror), hipHostMallocCoherent | hipHostMallocMapped));
+    HIPCHK(hipHostMalloc(&s->h_xc, vbytes, hipHostMallocCoherent | hipHostMallocMapped));
+    memset(s->h_live, 0, sizeof(LiveMirror));
     return 0;
 }
 
@@ -1543,6 +1591,7 @@ int queue_run_multi(ellhip_space* s, long long first, long long count) {
             // starts, then the vectors in one elementwise pass
             drop_prime(s);
             s->dots_np = 0;
+            s->xc_host_valid = false;
             rc = qdepth == MAXPEND ? group_stage_go<MAXPEND>(s, i, (int)g, half)
                : qdepth == 24 ? group_stage_go<24>(s, i, (int)g, half)
                : qdepth == 16 ? group_stage_go<16>(s, i, (int)g, half) : group_stage_go<8>(s, i, (int)g, half);
@@ -1651,6 +1700,7 @@ int resident_run(ellhip_space* s, long long first, long long count) {
         if (rc) return rc;
     }
     drop_prime(s);
+    s->xc_host_valid = false;
     ResidentArgs A{};
     A.Q = s->d_Q;
     A.ld = s->ld;
@@ -1798,6 +1848,8 @@ void ellhip_destroy(ellhip_space* s) {
     if (s->d_flags) (void)hipFree(s->d_flags);
     if (s->d_st) (void)hipFree(s->d_st);
     if (s->h_result) (void)hipHostFree(s->h_result);
+    if (s->h_live) (void)hipHostFree(s->h_live);
+    if (s->h_xc) (void)hipHostFree(s->h_xc);
     if (s->ev_fork) (void)hipEventDestroy(s->ev_fork);
     if (s->ev_join) (void)hipEventDestroy(s->ev_join);
     if (s->aux_stream) (void)hipStreamDestroy(s->aux_stream);
@@ -1920,8 +1972,8 @@ int ellhip_cut(ellhip_space* s, int kind, double beta0, int has_beta1, double be
     int rc = make_params(kind, beta0, has_beta1, beta1, cp);
     if (rc) return rc;
     rc = do_cut(s, s->g_cur, nullptr, cp, 0, nullptr, nullptr);
-    if (rc) return rc;
-    rc = read_back(s);
+    if (!rc) rc = live_publish(s);
+    if (!rc) rc = live_wait(s);
     if (rc) return rc;
     const int status = s->h_result->status;
     s->npend = s->h_result->npend;  // deferred mode: a failed cut records nothing
@@ -1978,12 +2030,16 @@ int ellhip_update_end(ellhip_space* s) {
     s->in_two_phase = false;
     int rc = do_cut(s, s->g_cur, nullptr, s->two_phase_cp, 0, nullptr, nullptr);
     if (rc) return rc;
-    // the rank-1 pass is skipped on the device when the cut failed, so it can be issued before the
-    // status is known: one host synchronisation per update
+    // status, tsq, kappa and the new centre are final after the scalar stage: they go to the host from there
+    rc = live_publish(s);
+    if (rc) return rc;
+    // the rank-1 pass (or, on the recorded schedule, the apply pass when the slots are full) is skipped on the device when
+    // the cut failed, so it is issued before the status is known -- and nobody waits for it: the caller's next statements
+    // (status test, tsq, xc(), its oracle) run beside it, the next update on this handle is ordered behind it by the stream
     rc = do_commit(s, true, nullptr);
     if (rc) return rc;
     drop_prime(s);
-    rc = read_back(s);
+    rc = live_wait(s);
     if (rc) return rc;
     const int status = s->h_result->status;
     if (s->variant == ELLHIP_SPACE_ELL && s->npend > 0 && status != ELLHIP_SUCCESS && s->h_result->npend < s->npend)
@@ -2022,6 +2078,10 @@ int64_t ellhip_ndim(const ellhip_space* s) { return s ? s->n : 0; }
 
 int ellhip_get_xc(const ellhip_space* s, double* xc_out) {
     if (!s || !xc_out) return fail(ELLHIP_E_INVALID, "NULL argument");
+    if (s->xc_host_valid) {  // published by the last direct update (k_publish): no device call at all
+        memcpy(xc_out, s->h_xc, (size_t)s->n * sizeof(double));
+        return 0;
+    }
     DeviceGuard guard(s->device);
     HIPCHK(hipMemcpyAsync(xc_out, s->d_xc, (size_t)s->n * sizeof(double), hipMemcpyDeviceToHost, s->stream));
     HIPCHK(hipStreamSynchronize(s->stream));
@@ -2032,6 +2092,7 @@ int ellhip_set_xc(ellhip_space* s, const double* xc) {
     if (!s || !xc) return fail(ELLHIP_E_INVALID, "NULL argument");
     DeviceGuard guard(s->device);
     // staged through the slot that is NOT holding a primed gradient
+    s->xc_host_valid = false;
     const int slot = s->cur ^ 1;
     HIPCHK(hipStreamSynchronize(s->stream));
     memcpy(s->h_stage[slot], xc, (size_t)s->n * sizeof(double));

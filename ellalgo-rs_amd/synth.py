@@ -102,3 +102,16 @@ def stable_factor(n: int, seed: int = 0x5EEDFAC7, chunk_rows: int = 1024) -> np.
     d = 0.5 + uniform01(seed ^ 0xD1A6, n)
     m[np.arange(n), np.arange(n)] = d
     return m
+
+
+def write_cuts_bin(path: str, kinds, grads, beta0, beta1) -> None:
+    """The cut file host/bench/live_loop.cpp reads: int64 n, int64 k, int32 kinds[k], f64 beta0[k], f64 beta1[k] (NaN: none),
+    f64 grads[k][n]."""
+    grads = np.ascontiguousarray(grads, dtype=np.float64)
+    k, n = grads.shape
+    with open(path, "wb") as f:
+        np.array([n, k], dtype=np.int64).tofile(f)
+        np.ascontiguousarray(kinds, dtype=np.int32)[:k].tofile(f)
+        np.ascontiguousarray(beta0, dtype=np.float64)[:k].tofile(f)
+        np.ascontiguousarray(beta1, dtype=np.float64)[:k].tofile(f)
+        grads.tofile(f)
