@@ -1130,18 +1130,41 @@ struct LiveMirror {
     unsigned long long seq;
 };
 static_assert(sizeof(DevState) % sizeof(long long) == 0, "k_publish copies DevState in 8-byte words");
-__global__ __launch_bounds__(1024) void k_publish(const DevState* __restrict__ st, const double* __restrict__ xc, long long n,
-                                                  LiveMirror* __restrict__ m, double* __restrict__ h_xc,
-                                                  unsigned long long seq) {
+constexpr int PUB_WGS = 16;  // one workgroup pushes ~12 GB/s over PCIe (11.4 us for the 128 KiB centre at n = 16384); 16: ~3 us
+__global__ __launch_bounds__(256) void k_publish(const DevState* __restrict__ st, const double* __restrict__ xc, long long n,
+                                                 LiveMirror* __restrict__ m, double* __restrict__ h_xc,
+                                                 unsigned long long seq, unsigned* __restrict__ arrived) {
+    __shared__ int last;
     const long long n2 = n / 2;
-    for (long long i = threadIdx.x; i < n2; i += 1024)
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n2; i += (long long)gridDim.x * 256)
         *reinterpret_cast<double2_t*>(h_xc + 2 * i) = *reinterpret_cast<const double2_t*>(xc + 2 * i);
-    if ((n & 1) && threadIdx.x == 0) h_xc[n - 1] = xc[n - 1];
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) h_xc[n - 1] = xc[n - 1];
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned old = __hip_atomic_fetch_add(arrived, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        last = (old + 1 == gridDim.x);
+        if (last) __hip_atomic_store(arrived, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
+    }
+    __syncthreads();
+    if (!last) return;
+    // the last workgroup to arrive: every slice of the centre is in host memory; the scalar state, then the sequence number
     if (threadIdx.x < (int)(sizeof(DevState) / sizeof(long long)))
         reinterpret_cast<long long*>(&m->st)[threadIdx.x] = reinterpret_cast<const long long*>(st)[threadIdx.x];
     __threadfence_system();
     __syncthreads();
     if (threadIdx.x == 0) __hip_atomic_store(&m->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// Host gradient in: the caller's n doubles sit in a pinned staging buffer; the chip pulls them over PCIe itself.  A copy
+// engine transfer (hipMemcpyAsync) costs 7.8 us + 8 us of cross-engine hand-over before the GEMV can start; this launch
+// sits in the same queue as the GEMV behind it (profiles/r04/live_loop_timeline_*.txt).
+constexpr int STAGE_WGS = 32;
+__global__ __launch_bounds__(256) void k_stage(const double* __restrict__ h_src, double* __restrict__ dst, long long n) {
+    const long long n2 = n / 2;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n2; i += (long long)gridDim.x * 256)
+        *reinterpret_cast<double2_t*>(dst + 2 * i) = *reinterpret_cast<const double2_t*>(h_src + 2 * i);
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) dst[n - 1] = h_src[n - 1];
 }
 
 // After a flush: forget the pending updates (unused slots must read as exact zeros).

@@ -177,6 +177,7 @@ struct ellhip_space {
     LiveMirror* h_live = nullptr;             // pinned, fine-grained
     double* h_xc = nullptr;                   // pinned, fine-grained: the centre as of the last published update
     unsigned long long live_seq = 0;
+    unsigned* d_pub_arrived = nullptr;        // k_publish: workgroups that have pushed their slice of the centre
     bool xc_host_valid = false;               // h_xc equals d_xc (nothing has written the centre on the device since)
 
     hipStream_t own_stream = nullptr;
@@ -857,8 +858,9 @@ int read_back(ellhip_space* s) {
 // the stream.  Same observable contract as read_back (h_result, kappa, tsq, the solve_err protocol).
 int live_publish(ellhip_space* s) {
     s->live_seq += 1;
-    hipLaunchKernelGGL(k_publish, dim3(1), dim3(1024), 0, s->stream, (const DevState*)s->d_st, (const double*)s->d_xc, s->n,
-                       s->h_live, s->h_xc, s->live_seq);
+    const unsigned wgs = (unsigned)std::max<long long>(1, std::min<long long>(PUB_WGS, s->n / 1024));
+    hipLaunchKernelGGL(k_publish, dim3(wgs), dim3(256), 0, s->stream, (const DevState*)s->d_st, (const double*)s->d_xc, s->n,
+                       s->h_live, s->h_xc, s->live_seq, s->d_pub_arrived);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -893,7 +895,10 @@ int stage_grad(ellhip_space* s, const double* grad, int slot) {
     if (!grad) return fail(ELLHIP_E_INVALID, "grad is NULL");
     const size_t bytes = (size_t)s->n * sizeof(double);
     memcpy(s->h_stage[slot], grad, bytes);
-    HIPCHK(hipMemcpyAsync(s->d_stage[slot], s->h_stage[slot], bytes, hipMemcpyHostToDevice, s->stream));
+    // (the chip pulls the staging buffer over PCIe itself: no copy engine, no cross-engine hand-over in front of the GEMV)
+    const unsigned wgs = (unsigned)std::max<long long>(1, std::min<long long>(STAGE_WGS, s->n / 512));
+    hipLaunchKernelGGL(k_stage, dim3(wgs), dim3(256), 0, s->stream, (const double*)s->h_stage[slot], s->d_stage[slot], s->n);
+    HIPCHK(hipGetLastError());
     return 0;
 }
 
@@ -976,7 +981,7 @@ int alloc_common(ellhip_space* s) {
         HIPCHK(hipMalloc(&s->d_stage[k], vbytes));
         HIPCHK(hipMalloc(&s->d_gt_own[k], vbytes));
         s->d_gt[k] = s->d_gt_own[k];
-        HIPCHK(hipHostMalloc(&s->h_stage[k], vbytes, hipHostMallocDefault));
+        HIPCHK(hipHostMalloc(&s->h_stage[k], vbytes, hipHostMallocCoherent | hipHostMallocMapped));  // (k_stage reads it from the device)
         HIPCHK(hipMemsetAsync(s->d_gt_own[k], 0, vbytes, s->stream));
     }
     HIPCHK(hipMalloc(&s->d_st, sizeof(DevState)));
@@ -1046,6 +1051,8 @@ int alloc_common(ellhip_space* s) {
     HIPCHK(hipHostMalloc(&s->h_live, sizeof(LiveMirror), hipHostMallocCoherent | hipHostMallocMapped));
     HIPCHK(hipHostMalloc(&s->h_xc, vbytes, hipHostMallocCoherent | hipHostMallocMapped));
     memset(s->h_live, 0, sizeof(LiveMirror));
+    HIPCHK(hipMalloc(&s->d_pub_arrived, sizeof(unsigned)));
+    HIPCHK(hipMemsetAsync(s->d_pub_arrived, 0, sizeof(unsigned), s->stream));
     return 0;
 }
 
@@ -1850,6 +1857,7 @@ void ellhip_destroy(ellhip_space* s) {
     if (s->h_result) (void)hipHostFree(s->h_result);
     if (s->h_live) (void)hipHostFree(s->h_live);
     if (s->h_xc) (void)hipHostFree(s->h_xc);
+    if (s->d_pub_arrived) (void)hipFree(s->d_pub_arrived);
     if (s->ev_fork) (void)hipEventDestroy(s->ev_fork);
     if (s->ev_join) (void)hipEventDestroy(s->ev_join);
     if (s->aux_stream) (void)hipStreamDestroy(s->aux_stream);
