@@ -482,6 +482,39 @@ def symv_kernel_name(pkg, space, symv_mode: bool, n: int, fused: bool = True) ->
     return "k_symv_multi" if look > 1 else "k_symv"
 
 
+def run_live_loop(pkg, synth, gen, n: int, kinds, grads, b0, b1, variant: str, steps: int, warm: int = 48):
+    """The reference's hot loop `xc() -> oracle -> update_*_cut` (src/cutting_plane.rs:299-311) as an ellalgo-rs user runs it:
+    the C++ mirrors of the drivers (host/ellhip/cutting_plane.hpp `cutting_plane_optim`, ell_hip.hpp
+    `cutting_plane_optim_pipelined`) over the C ABI, a host oracle that reads the centre (O(n)) and returns synthetic cut k --
+    a child process (host/bench/live_loop, plain C++: no Python between the calls), on a fresh handle of the same size.
+    The gradient of iteration k + 1 does not exist before update k has returned: no lookahead, no replay."""
+    import subprocess
+    import tempfile
+    need = warm + steps + 1
+    if len(kinds) < need:   # (a short run of the queue workloads: the same seeded sequence, longer)
+        kinds, grads, b0, b1 = gen(n, need)
+    try:
+        exe = pkg.build.build_host_tools()
+    except Exception as e:   # noqa: BLE001 -- reported, the headline does not depend on it
+        return {"skipped": f"host/bench/live_loop could not be built: {e}"}
+    tmpdir = "/dev/shm" if os.path.isdir("/dev/shm") else None
+    with tempfile.TemporaryDirectory(dir=tmpdir) as d:
+        path = os.path.join(d, "cuts.bin")
+        synth.write_cuts_bin(path, kinds[:need], grads[:need], b0[:need], b1[:need])
+        try:
+            r = subprocess.run([exe, path, str(warm), str(steps), "ell" if variant == "ell" else "ellstable"],
+                               capture_output=True, text=True, timeout=600)
+        except subprocess.TimeoutExpired:
+            return {"skipped": "host/bench/live_loop timed out"}
+    for line in r.stdout.splitlines():
+        if line.startswith("{"):
+            out = json.loads(line)
+            out.pop("case", None)
+            out["rc"] = r.returncode
+            return out
+    return {"skipped": f"host/bench/live_loop printed nothing (rc {r.returncode}): {r.stderr[-300:]}"}
+
+
 def settle(space) -> None:
     """After a handle with gigabytes of device memory has been destroyed and the next one created, ONE stream synchronisation
     of the new handle within the next few hundred milliseconds takes 75-85 ms longer although the GPU timeline shows its
@@ -605,6 +638,9 @@ def main() -> None:
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     ap.add_argument("--host-path-steps", type=int, default=64,
                     help="extra synchronous ellhip_update() calls from host buffers (PCIe-inclusive rate)")
+    ap.add_argument("--live-loop-steps", type=int, default=200,
+                    help="iterations of the live loop (xc -> host oracle -> update through the C++ drivers, a child process); "
+                         "0 = skip")
     ap.add_argument("--schedule", choices=["pipelined", "two-pass"], default="pipelined",
                     help="pipelined: one pass over Q per update (shrink of cut k fused with the GEMV of cut k+1, "
                          "16*n^2 B); two-pass: GEMV pass + rank-1 pass per update (24*n^2 B). Same results.")
@@ -922,6 +958,12 @@ def main() -> None:
             rate = (per - warm) / (time.perf_counter() - t2)
             host_path["updates_per_s" if dep == 1 else f"updates_per_s_depth{dep}"] = rate
 
+    # ---- the live loop: xc() -> host oracle -> update, through the C++ drivers over the C ABI (N = 1 only)
+    live_loop = None
+    if H > 0 and args.live_loop_steps > 0:
+        live_loop = run_live_loop(pkg, synth, synth.parallel_cuts if cutgen == "parallel" else synth.deep_cuts, n, kinds, grads,
+                                  b0, b1, variant, args.live_loop_steps)
+
     if rank != 0:
         dist.barrier()
         dist.destroy_process_group()
@@ -1084,6 +1126,31 @@ def main() -> None:
         out["other_schedules"] = others
     if host_path:
         out["host_call_path"] = host_path
+    if live_loop:
+        out["live_loop"] = live_loop
+    # What a SearchSpace caller can reach, copied into the two objects a record keeper is sure to keep (`config`, `roofline`):
+    # the headline `value` replays a QUEUE and forms the products of up to `lookahead` FUTURE gradients per pass over Q, which a
+    # live cutting-plane loop can never supply (src/cutting_plane.rs:299-311: gradient k + 1 comes from the oracle at the centre
+    # update k produced).
+    reach = {}
+    if variant == "ell" and fused and lookahead > 1 and not resident_run:
+        reach["value_requires_future_gradients"] = lookahead
+    elif resident_run:
+        reach["value_requires_a_queued_batch"] = K
+    if live_loop and "plain_iterations_per_s" in live_loop:
+        reach["live_loop_updates_per_s"] = live_loop["plain_iterations_per_s"]
+        reach["live_loop_pipelined_updates_per_s"] = live_loop["pipelined_iterations_per_s"]
+    if host_path:
+        key = f"updates_per_s_depth{depth}" if (variant == "ell" and depth != 1) else "updates_per_s"
+        if key in host_path:
+            reach["host_call_updates_per_s"] = host_path[key]
+    for o in others:
+        if o["schedule"].endswith("lookahead 1"):
+            reach["lookahead1_updates_per_s"] = o["updates_per_s"]
+        if o["schedule"] == "two-pass" and o["defer_depth"] == 1:
+            roofline["canonical_24n2_updates_per_s"] = o["updates_per_s"]
+            roofline["canonical_24n2_frac"] = o["whole_update"]["frac"]
+    out["config"].update(reach)
     if world == 1 and not args.no_cpu_baseline:
         log("[rank 0] timing the CPU oracle (bounded sample) ...")
         out["cpu_baseline"] = cpu_baseline(n, variant, kinds, grads, b0, b1, args.cpu_budget)

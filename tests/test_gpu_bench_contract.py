@@ -37,7 +37,7 @@ def check_common(d, steps, warmup):
 
 def test_headline_workload_contract():
     d = run_bench("--steps", "16", "--warmup", "8", "--compare-steps", "0", "--profile-steps", "8", "--host-path-steps", "4",
-                  "--cpu-budget", "2")
+                  "--cpu-budget", "2", "--live-loop-steps", "30")
     check_common(d, 16, 8)
     assert d["metric"].startswith("ellipsoid updates/sec at n=16384") and d["unit"] == "updates/s"
     assert d["config"]["workload"] == "n16384-parallel" and d["scaling"] == "strong"
@@ -49,6 +49,15 @@ def test_headline_workload_contract():
     assert c["kind"] == "port" and c["cores"] == 1 and c["unit"] == "updates/s" and c["value"] > 0 and c["sample"]
     assert c["all_cores"]["threads"] >= 1 and "NOT the reference" in c["all_cores"]["note"]
     assert d["host_call_path"]["updates_per_s"] > 0
+    # the live loop (C++ drivers over the C ABI, host oracle) and what a SearchSpace caller can reach, in the objects a record
+    # keeper keeps: the headline needs 16 future gradients per pass, the live figures none
+    ll = d["live_loop"]
+    assert ll["steps"] == 30 and ll["rc"] == 0 and ll["plain_niter"] == ll["pipelined_niter"] == 78
+    assert ll["plain_iterations_per_s"] > 1000 and ll["pipelined_iterations_per_s"] > 1000 and ll["defer_depth"] == 24
+    cfg = d["config"]
+    assert cfg["value_requires_future_gradients"] == 16 and cfg["live_loop_updates_per_s"] == ll["plain_iterations_per_s"]
+    assert cfg["host_call_updates_per_s"] == d["host_call_path"]["updates_per_s_depth24"]
+    assert cfg["live_loop_updates_per_s"] < d["value"]
     assert r["traffic_measured_in_this_run"] is False and r["per_kernel"]["symv"]["avg_ms"] > 0
     # the as-run figure (the next group's products overlap this group's stage) and the kernel by itself
     assert r["isolated"]["kernel"] == "k_symm_mfma" and 0.3 < r["isolated"]["frac"] < 1.0
