@@ -70,7 +70,7 @@ struct Defaults {
     int overlap = 1;           // ELLHIP_OPT_OVERLAP
     int lookahead = 16;        // ELLHIP_OPT_LOOKAHEAD
     int queue_depth = 48;      // ELLHIP_OPT_QUEUE_DEPTH
-    int stable_solve = 2;      // ELLHIP_OPT_STABLE_SOLVE
+    int stable_solve = 3;      // ELLHIP_OPT_STABLE_SOLVE
     int stable_factor = 2;     // ELLHIP_OPT_STABLE_FACTOR
     int pad = -1;              // ELLHIP_OPT_PAD: extra doubles per row of Q; -1 = by size (create_impl)
     int lp_grid = 0;           // ELLHIP_OPT_LP_GRID: workgroups per LowpassOracle scan launch; 0 = by size
@@ -101,7 +101,7 @@ struct ellhip_space {
     double* d_work = nullptr;        // EllStable vectors: w, z, gg, q, beta2
     double* d_hpart = nullptr;       // EllStable forward solve with helper workgroups: the helpers' hand-over buffer (n)
     // EllStable kernel forms (ellhip_set_option: ELLHIP_OPT_STABLE_SOLVE / ELLHIP_OPT_STABLE_FACTOR)
-    int stable_solve = 2;            // 0: one launch per block; 1: persistent solves; 2: persistent + helper workgroups
+    int stable_solve = 3;            // 0: one launch per block; 1: persistent solves; 2: persistent + helper workgroups; 3: 2 on the mirrored layout
     int stable_factor = 2;           // 0: tile kernel that reads the scratch triangle; 1: row kernel from U alone, beside the
                                      // backward solve; 2: factor tiles pulled inside the helped backward solve's launch
     int* d_fnext = nullptr;          // queue position of the factor tiles (reset by k_st_post before every launch)
@@ -109,6 +109,12 @@ struct ellhip_space {
     int nftiles16 = 0;
     double* d_qhpart = nullptr;      // ... and the backward helpers' hand-over buffer (n)
     int persist_cap_h = 0;           // resident-workgroup limit of the helped solves (CU count x occupancy of k_st_fwd_helped)
+    // EllStable, ELLHIP_OPT_STABLE_SOLVE = 3: the mirrored layout (ellstable_kernels.hpp, StPend)
+    bool st_mirrored = false;        // host view: the handle's solves run on the mirrored layout (the device's own flag, StPend.mirrored,
+                                     // says whether the lower triangle really holds the mirrored factor: not after a halted queue)
+    StPend* d_stpend = nullptr;
+    double* d_fb2 = nullptr;         // [2][n] beta2 of the factor updates the triangles may still lack
+    double* d_fw = nullptr;          // [2][n] ... and the w they go with
     double* d_partial = nullptr;     // per-workgroup partial sums of omega (64)
     double* d_pend = nullptr;        // deferred mode: MAXPEND pending gt vectors (n each)
     double* d_cpend = nullptr;       // deferred mode: their coefficients sigma/omega
@@ -489,6 +495,38 @@ int launch_mirror_if_needed(ellhip_space* s) {
     return 0;
 }
 
+// EllStable, mirrored layout (ELLHIP_OPT_STABLE_SOLVE = 3; ellstable_kernels.hpp, StPend): entering copies the factor below
+// the diagonal (one 8 n^2-byte pass, once); leaving -- before anything observes the buffer (get_mq, clone), on a mode switch,
+// when a halted queue's results are read -- rebuilds the scratch triangle of the last forward solve from U and that solve's
+// w, then applies the factor update U may still lack: the buffer is then exactly what the eager kernels leave.
+int stable_mirror_enter(ellhip_space* s) {
+    const unsigned t = (unsigned)((s->n + 63) / 64);
+    hipLaunchKernelGGL(k_st_mirror_enter, dim3(t, t), dim3(256), 0, s->stream, s->d_Q, s->ld, s->n, (const DevState*)s->d_st);
+    hipLaunchKernelGGL(k_st_mirror_mark, dim3(1), dim3(1), 0, s->stream, s->d_stpend, (const DevState*)s->d_st);
+    HIPCHK(hipGetLastError());
+    s->st_mirrored = true;
+    return 0;
+}
+int stable_mirror_leave(ellhip_space* s) {
+    if (!s->st_mirrored) return 0;
+    const long long n = s->n;
+    const unsigned t = (unsigned)((n + 63) / 64);
+    const double* w0 = s->d_work;
+    const double* w1 = w0 + 6 * n;
+    hipLaunchKernelGGL(k_st_mirror_leave, dim3(t, t), dim3(256), 0, s->stream, s->d_Q, s->ld, n, (const StPend*)s->d_stpend, w0, w1);
+    const unsigned gy = (unsigned)((n + FROW_H - 1) / FROW_H);
+    if (n >= 8192)
+        hipLaunchKernelGGL((k_st_factor_rows_pend<2048, 2>), dim3(gy, (unsigned)((n + 2047) / 2048)), dim3(256), 0, s->stream,
+                           s->d_Q, s->ld, n, (const StPend*)s->d_stpend, (const double*)s->d_fb2, (const double*)s->d_fw);
+    else
+        hipLaunchKernelGGL((k_st_factor_rows_pend<512, 4>), dim3(gy, (unsigned)((n + 511) / 512)), dim3(256), 0, s->stream,
+                           s->d_Q, s->ld, n, (const StPend*)s->d_stpend, (const double*)s->d_fb2, (const double*)s->d_fw);
+    hipLaunchKernelGGL(k_st_mirror_clear, dim3(1), dim3(1), 0, s->stream, s->d_stpend);
+    HIPCHK(hipGetLastError());
+    s->st_mirrored = false;
+    return 0;
+}
+
 // EllStable::update_core as a fixed sequence of launches (ellstable_kernels.hpp).
 int ellstable_issue(ellhip_space* s, const double* g_dev, const CutParams* cp_dev, CutParams cp_val, int queue_mode,
                     int* qst, double* qtsq) {
@@ -518,14 +556,27 @@ int ellstable_issue(ellhip_space* s, const double* g_dev, const CutParams* cp_de
     double* w = (persist && (s->epoch & 1)) ? w1 : w0;
     double* w_next = (persist && (s->epoch & 1)) ? w0 : w1;
     int* err = reinterpret_cast<int*>(reinterpret_cast<char*>(s->d_st) + offsetof(DevState, solve_err));
+    // the helped backward solve (with or without factor tiles) needs its tile list / hand-over buffer and both grids resident
+    const bool helped_b = helped && s->d_ftiles16 && s->d_fnext && s->d_qhpart && 2 * nb <= s->persist_cap1;
+    // the mirrored layout (STABLE_SOLVE = 3): no scratch triangle, no factor pass -- both helped solves in their MIRROR form
+    const bool mirror = helped_b && s->stable_solve >= 3 && s->d_stpend;
     // factor update inside the backward solve's launch: needs the helped form and the row-wise (U alone) arithmetic
-    const bool fused_h = helped && s->stable_factor >= 2 && s->d_ftiles16 && s->d_fnext && s->d_qhpart &&
-                         2 * nb <= s->persist_cap1;
+    const bool fused_h = helped_b && !mirror && s->stable_factor >= 2;
+    if (mirror != s->st_mirrored) {
+        int mrc = mirror ? stable_mirror_enter(s) : stable_mirror_leave(s);
+        if (mrc) return mrc;
+    }
+    const StPend* pend_c = mirror ? s->d_stpend : nullptr;
     {
         ProfScope ps(s, CLS_ST_FWD);
-        if (helped) {
-            hipLaunchKernelGGL(k_st_fwd_helped, dim3((unsigned)(2 * nb)), dim3(256), 0, st, s->d_Q, ld, n, g_dev, w,
-                               s->d_hpart, z, gg, s->d_flags, err, s->epoch, s->d_st);
+        if (mirror) {
+            hipLaunchKernelGGL(k_st_fwd_helped<true>, dim3((unsigned)(2 * nb)), dim3(256), 0, st, s->d_Q, ld, n, g_dev, w,
+                               s->d_hpart, z, gg, s->d_flags, err, s->epoch, (const DevState*)s->d_st, pend_c,
+                               (const double*)s->d_fb2, (const double*)s->d_fw);
+        } else if (helped) {
+            hipLaunchKernelGGL(k_st_fwd_helped<false>, dim3((unsigned)(2 * nb)), dim3(256), 0, st, s->d_Q, ld, n, g_dev, w,
+                               s->d_hpart, z, gg, s->d_flags, err, s->epoch, (const DevState*)s->d_st, (const StPend*)nullptr,
+                               (const double*)nullptr, (const double*)nullptr);
         } else if (persist) {
             hipLaunchKernelGGL(k_st_fwd_persist, dim3((unsigned)nb), dim3(256), 0, st, s->d_Q, ld, n, g_dev, w, z, gg,
                                s->d_flags, err, s->epoch, s->d_st);
@@ -544,23 +595,28 @@ int ellstable_issue(ellhip_space* s, const double* g_dev, const CutParams* cp_de
         ProfScope ps(s, CLS_SCALAR);
         EllCalcDev calc = EllCalcDev::make(n, s->use_parallel_cut);
         hipLaunchKernelGGL(k_st_mid, dim3(1), dim3(ST_MID_T), 0, st, n, (const double*)gg, cpre, s->d_st, calc, cp_dev,
-                           cp_val, queue_mode, qst, qtsq);
+                           cp_val, queue_mode, qst, qtsq, mirror ? s->d_stpend : (StPend*)nullptr, (w == w1) ? 1 : 0);
         hipLaunchKernelGGL(k_st_post, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, s->d_Q, ld, n,
                            (const double*)z, (const double*)gg, (const double*)cpre, q, beta2,
                            persist ? qpub : (double*)nullptr, persist ? w_next : (double*)nullptr,
                            (const DevState*)s->d_st, helped ? s->d_hpart : (double*)nullptr, s->d_fnext,
-                           fused_h ? s->d_qhpart : (double*)nullptr);
+                           (fused_h || mirror) ? s->d_qhpart : (double*)nullptr, pend_c, s->d_fb2, s->d_fw, (const double*)w);
         HIPCHK(hipGetLastError());
     }
     // The factor update (rewrites U) and the backward solve (reads S, writes q) are independent.  Helped form: the
     // factor tiles are pulled inside the backward solve's launch by whoever is idle.  Otherwise, with the persistent
     // backward solve (latency-bound) the bandwidth-bound factor update runs beside it on the auxiliary stream,
     // launched AFTER it so the solve's workgroups are placed first; the streams join before anything else touches Q.
-    const bool overlap = persist && !fused_h;
+    const bool overlap = persist && !fused_h && !mirror;
     if (overlap) HIPCHK(hipEventRecord(s->ev_fork, st));
     {
         ProfScope ps(s, CLS_ST_BWD);
-        if (fused_h) {
+        if (mirror) {
+            hipLaunchKernelGGL((k_st_bwd_factor_helped<2048, 8, true>), dim3((unsigned)(2 * nb)), dim3(256), 0, st, s->d_Q, ld, n, q,
+                               qpub, s->d_qhpart, err, (const DevState*)s->d_st, nb, (const double*)beta2, (const double*)w,
+                               (const int*)s->d_ftiles16, s->nftiles16, s->d_fnext, nb + 1, pend_c, (const double*)s->d_fb2,
+                               (const double*)s->d_fw);
+        } else if (fused_h) {
             const unsigned grid = (unsigned)(2 * nb);
             // before their turn the chain workgroups pull factor tiles only when the matrix is on-die (n < 8192): from HBM
             // it made them late for their own block (n = 16384: stop distance 6 / 12 / 24 / 48+ blocks: 785 / 731 / 710 /
@@ -588,7 +644,7 @@ int ellstable_issue(ellhip_space* s, const double* g_dev, const CutParams* cp_de
         hipLaunchKernelGGL(k_st_xc, dim3(gx < 256 ? gx : 256), dim3(256), 0, st, n, q, s->d_xc, s->d_st);
         HIPCHK(hipGetLastError());
     }
-    if (!fused_h) {
+    if (!fused_h && !mirror) {
         hipStream_t fs = overlap ? s->aux_stream : st;
         if (overlap) HIPCHK(hipStreamWaitEvent(fs, s->ev_fork, 0));
         {
@@ -845,6 +901,7 @@ int read_back(ellhip_space* s) {
             return fail(ELLHIP_E_HIP, "a bounded in-launch wait timed out on an Ell handle; resident batches are now off on it");
         }
         s->stable_solve = 0;
+        (void)stable_mirror_leave(s);  // (flags only matter from here on: the buffer is what the failed update left)
         return fail(ELLHIP_E_HIP, "a bounded in-launch wait of an EllStable persistent solve timed out; this handle now uses one "
                                   "launch per block (no inter-workgroup waits)");
     }
@@ -942,6 +999,10 @@ int refresh_prime(ellhip_space* s) {
 
 // For observers of Q itself (get_mq, clone, mode switches): also apply what deferred mode has recorded.
 int make_q_current(ellhip_space* s) {
+    if (s->variant == ELLHIP_SPACE_ELL_STABLE) {  // (the buffer in the reference's layout)
+        const int erc = ensure_committed(s);
+        return erc ? erc : stable_mirror_leave(s);
+    }
     const bool uncut = prime_is_uncut(s);
     int rc = ensure_committed(s);
     if (rc) return rc;
@@ -1008,7 +1069,8 @@ int alloc_common(ellhip_space* s) {
                 return std::min(a, b) * prop.multiProcessorCount;
             };
             s->persist_cap1 = cap((const void*)k_st_fwd_persist, (const void*)k_st_bwd_persist, 256);
-            s->persist_cap_h = cap((const void*)k_st_fwd_helped, (const void*)k_st_bwd_factor_helped<2048, 8>, 256);
+            s->persist_cap_h = std::min(cap((const void*)k_st_fwd_helped<false>, (const void*)k_st_bwd_factor_helped<2048, 8>, 256),
+                                        cap((const void*)k_st_fwd_helped<true>, (const void*)k_st_bwd_factor_helped<2048, 8, true>, 256));
         }
         {   // the 16-row factor tiles of k_st_bwd_factor_helped: the active tiles of the strict upper triangle, full ones first
             const long long seg = (n >= 8192) ? 2048 : 512;
@@ -1045,6 +1107,10 @@ int alloc_common(ellhip_space* s) {
         hipLaunchKernelGGL(k_st_arm, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream, s->d_work + 6 * n, n);
         HIPCHK(hipMalloc(&s->d_hpart, vbytes));
         hipLaunchKernelGGL(k_st_arm, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream, s->d_hpart, n);
+        HIPCHK(hipMalloc(&s->d_stpend, sizeof(StPend)));
+        HIPCHK(hipMalloc(&s->d_fb2, 2 * vbytes));
+        HIPCHK(hipMalloc(&s->d_fw, 2 * vbytes));
+        hipLaunchKernelGGL(k_st_mirror_clear, dim3(1), dim3(1), 0, s->stream, s->d_stpend);
         HIPCHK(hipGetLastError());
     }
     HIPCHK(hipHostMalloc(&s->h_result, sizeof(DevState), hipHostMallocDefault));
@@ -1826,6 +1892,9 @@ void ellhip_destroy(ellhip_space* s) {
     }
     if (s->d_work) (void)hipFree(s->d_work);
     if (s->d_hpart) (void)hipFree(s->d_hpart);
+    if (s->d_stpend) (void)hipFree(s->d_stpend);
+    if (s->d_fb2) (void)hipFree(s->d_fb2);
+    if (s->d_fw) (void)hipFree(s->d_fw);
     if (s->d_fnext) (void)hipFree(s->d_fnext);
     if (s->d_ftiles16) (void)hipFree(s->d_ftiles16);
     if (s->d_qhpart) (void)hipFree(s->d_qhpart);
@@ -2206,7 +2275,8 @@ int option_ok(int key, long long v) {
         case ELLHIP_OPT_QUEUE_DEPTH: return (v == 0 || v == 48) ? 0 : fail(ELLHIP_E_INVALID, "ELLHIP_OPT_QUEUE_DEPTH: 0 or 48");
         case ELLHIP_OPT_RESIDENT_FAULT: return v >= -1 ? 0 : fail(ELLHIP_E_INVALID, "ELLHIP_OPT_RESIDENT_FAULT: -1 or a cut index");
         case ELLHIP_OPT_SYMV_MIN_N: return v >= 512 ? 0 : fail(ELLHIP_E_INVALID, "ELLHIP_OPT_SYMV_MIN_N must be >= 512");
-        case ELLHIP_OPT_STABLE_SOLVE: case ELLHIP_OPT_STABLE_FACTOR:
+        case ELLHIP_OPT_STABLE_SOLVE: return (v >= 0 && v <= 3) ? 0 : fail(ELLHIP_E_INVALID, "ELLHIP_OPT_STABLE_SOLVE: 0 .. 3");
+        case ELLHIP_OPT_STABLE_FACTOR:
             return (v >= 0 && v <= 2) ? 0 : fail(ELLHIP_E_INVALID, "option value must be 0, 1 or 2");
         case ELLHIP_OPT_PAD: return (v >= -1 && v <= 4096) ? 0 : fail(ELLHIP_E_INVALID, "ELLHIP_OPT_PAD: -1 .. 4096");
         case ELLHIP_OPT_LP_GRID: return (v >= 0 && v <= 65536) ? 0 : fail(ELLHIP_E_INVALID, "ELLHIP_OPT_LP_GRID: 0 .. 65536");
@@ -2319,6 +2389,8 @@ int ellhip_set_option(ellhip_space* s, int key, int64_t value) {
         }
         case ELLHIP_OPT_STABLE_SOLVE: case ELLHIP_OPT_STABLE_FACTOR:
             if (ell) return fail(ELLHIP_E_INVALID, "this option exists on EllStable only");
+            rc = stable_mirror_leave(s);  // (the next update enters the layout its options ask for)
+            if (rc) return rc;
             HIPCHK(hipStreamSynchronize(s->stream));
             if (key == ELLHIP_OPT_STABLE_SOLVE) s->stable_solve = (int)value; else s->stable_factor = (int)value;
             return 0;
@@ -2507,6 +2579,11 @@ int ellhip_queue_results(ellhip_space* s, int32_t* status_out, double* tsq_out) 
             }
     }
     // a halted queue stays halted until its results have been read; then direct updates work again
+    if (s->h_result->halted && s->variant == ELLHIP_SPACE_ELL_STABLE) {
+        // (mirrored layout: a k_st_mirror_enter issued while the queue was halted did nothing; host and device agree again)
+        rc = stable_mirror_leave(s);
+        if (rc) return rc;
+    }
     if (s->h_result->halted) {
         s->h_result->halted = 0;
         s->h_result->stop = STOP_NONE;

@@ -316,6 +316,7 @@ __device__ __forceinline__ void st_fwd_diag_cols(const double* __restrict__ lds,
         for (int j = 0; j < SH; ++j) u[j] = mine[j * BLK_PITCH + lane];
     }
 }
+template <bool STORE = true>
 __device__ __forceinline__ void st_fwd_diag_block_pre(double* __restrict__ M, long long ld, long long n, long long J0,
                                                       double* __restrict__ lds, const double* __restrict__ dlds,
                                                       const double* __restrict__ wpart, double* __restrict__ w,
@@ -367,6 +368,7 @@ __device__ __forceinline__ void st_fwd_diag_block_pre(double* __restrict__ M, lo
             gg[c] = zi * wB;
         }
     }
+    if constexpr (!STORE) return;  // mirrored layout: nobody parks the products (the scratch triangle is not kept)
     // parked products: piece[lane][j] (transposed in place; every lane read its whole column long ago)
     if (wave == 0 || (has_b && wave == 2)) {
         double* mine = wave == 0 ? pAA : pBB;
@@ -384,6 +386,38 @@ __device__ __forceinline__ void st_fwd_diag_block_pre(double* __restrict__ M, lo
     if (has_b) {
         st_store_piece(M, ld, n, J0 + SH, J0, pAB, false, threadIdx.x);        // S[B][A], full
         st_store_piece(M, ld, n, J0 + SH, J0 + SH, pBB, true, threadIdx.x);    // S[B][B], strict lower
+    }
+}
+
+// Mirrored layout: the pending factor update on one 64 x 64 piece of a diagonal block held in registers (rows R0 + r,
+// columns C0 + 2 cp, + 1 as st_load_piece laid them out).  UPPER: the piece lies in the factor's triangle, the scaling is
+// per ROW (fb2[row], fw[row]) and applies right of the diagonal; otherwise it lies in the mirrored triangle, the scaling
+// is per COLUMN and applies below the diagonal.  Scaled elements are stored back in place; the rest is left alone.
+template <bool UPPER>
+__device__ __forceinline__ void st_scale_piece(double* __restrict__ M, long long ld, long long n, long long R0,
+                                               long long C0, double2_t (&v)[8], const double* __restrict__ fb2,
+                                               const double* __restrict__ fw, int tid) {
+    const int tr = tid >> 5, cp = tid & 31;
+    const long long c = C0 + 2 * cp;
+    double bc0 = 0.0, wc0 = 0.0, bc1 = 0.0, wc1 = 0.0;
+    if (!UPPER) {
+        if (c < n) bc0 = fb2[c], wc0 = fw[c];
+        if (c + 1 < n) bc1 = fb2[c + 1], wc1 = fw[c + 1];
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const long long r = R0 + tr + 8 * k;
+        if (r >= n || c >= n) continue;
+        double b0 = bc0, w0 = wc0, b1 = bc1, w1 = wc1;
+        if (UPPER) b0 = b1 = fb2[r], w0 = w1 = fw[r];
+        const bool in0 = UPPER ? c > r : c < r;
+        const bool in1 = (c + 1 < n) && (UPPER ? c + 1 > r : c + 1 < r);
+        if (in0) v[k].x = v[k].x + b0 * (v[k].x * w0);
+        if (in1) v[k].y = v[k].y + b1 * (v[k].y * w1);
+        double* p = M + r * ld + c;
+        if (in0 && in1) *reinterpret_cast<double2_t*>(p) = v[k];
+        else if (in0) p[0] = v[k].x;
+        else if (in1) p[1] = v[k].y;
     }
 }
 
@@ -406,6 +440,36 @@ __device__ __forceinline__ void st_prefetch_block(const double* __restrict__ M, 
 }
 
 constexpr int ST_LDS_DOUBLES = 3 * SH * BLK_PITCH;  // 96 KiB: the three parked pieces (the panel tile aliases it)
+
+// ------------------------------------------------------------------ the mirrored layout (ELLHIP_OPT_STABLE_SOLVE = 3) ---
+// The reference moves 24 n^2 bytes per update, the eager kernels above 20 n^2, and both solves are chains in which the
+// scratch triangle is pure overhead: the forward solve WRITES S[i][j] = fl(U[j][i] w[j]) (src/ell_stable.rs:66, transposed
+// through LDS: what paces its helper workgroups), the backward solve reads it back (:96), the factor update reads or
+// recomputes it a third time (:116).  Nothing else ever looks at S.  In the mirrored layout the engine's PRIVATE buffer
+// holds the factor twice -- U[j][i] above the diagonal and the same number again at [i][j] below it (L = U') -- and the
+// scratch triangle exists only when somebody observes the buffer (get_mq, clone: k_st_transpose_lower rebuilds it exactly
+// from U and the last forward solve's w):
+//   forward   reads tiles of U exactly as before, forms the products in registers, sums them, stores nothing;
+//   backward  reads the SAME addresses it used to read S from and finds L[j][t] = U[t][j] there: the product the reference
+//             parked is fl(L[j][t] w[t]) -- w[t] a per-LANE constant (the lane owns column t) -- so the solve is the old
+//             kernel with one more multiply per element, same sums in the same order: identical bits;
+//   factor    U[j][l] += beta2[j] fl(U[j][l] w[j]) (:107-121) is a per-ROW scaling of U = a per-COLUMN scaling of L, and
+//             it is not run at all: the NEXT forward solve applies it to every tile of U it loads (row constants, store in
+//             place), the next backward solve to every tile of L (lane constants, store in place).  Bit for bit the value
+//             k_st_factor_rows stores: the same two roundings on the same operands.
+// Per update: forward R 4 n^2 + W 4 n^2, backward R 4 n^2 + W 4 n^2 = 16 n^2 bytes, no transposes, no third pass, every
+// tile touched by exactly one workgroup per solve.  Which (beta2, w) pair each triangle still lacks is device state
+// (StPend, kept by k_st_mid): a failed cut applies nothing new, a halted queue touches nothing.
+struct StPend {
+    int fcur;     // buffer (0 / 1) of fb2 / fw that holds the most recent successful update's (beta2, w)
+    int u_lacks;  // the upper triangle has not received that update's scaling yet (the next forward solve applies it)
+    int l_lacks;  // ... nor has the mirrored lower triangle (the next backward solve applies it)
+    int l_apply;  // what the backward solve of the update in flight must apply first: a buffer index, or -1
+    int mirrored; // the lower triangle holds the mirrored factor (set by k_st_mirror_enter; 0: it holds the scratch triangle)
+    int have_w;   // a forward solve has run since: w_last says which of the two w buffers holds its result
+    int w_last;
+    int pad_;
+};
 
 __global__ __launch_bounds__(256) void k_st_fwd_first(double* __restrict__ M, long long ld, long long n,
                                                       const double* __restrict__ g, double* __restrict__ w,
@@ -685,13 +749,29 @@ constexpr long long ST_DUTY_STOP = 5;  // the chain workgroup of block s stops w
 #ifndef ST_HELPER_WRITES
 #define ST_HELPER_WRITES 3             // the helper writes every 3rd row block's products, the chain workgroup the others
 #endif
+// MIRROR: the mirrored layout (see StPend above) -- no product is stored, every tile of U this launch loads first receives
+// the pending factor update (per row: fb2[row], fw[row] of buffer pend->fcur) and is stored back in place.  Each tile is
+// loaded by exactly one workgroup here (helper s: row blocks 0 .. s - 2, chain s: row block s - 1 and the diagonal block).
+template <bool MIRROR = false>
 __global__ __launch_bounds__(256) void k_st_fwd_helped(double* __restrict__ M, long long ld, long long n,
                                                        const double* __restrict__ g, double* __restrict__ w,
                                                        double* __restrict__ hpart, double* __restrict__ z,
                                                        double* __restrict__ gg, int* __restrict__ flags,
                                                        int* __restrict__ err, int epoch,
-                                                       const DevState* __restrict__ st) {
+                                                       const DevState* __restrict__ st,
+                                                       const StPend* __restrict__ pend = nullptr,
+                                                       const double* __restrict__ fb2_all = nullptr,
+                                                       const double* __restrict__ fw_all = nullptr) {
     if (st->halted) return;
+    __shared__ double pb[SB], pw[SB];  // MIRROR: the pending update's (beta2, w) on the row block being applied
+    bool scale = false;
+    const double* fb2 = nullptr;
+    const double* fw = nullptr;
+    if constexpr (MIRROR) {
+        scale = pend->u_lacks != 0;
+        fb2 = fb2_all + (long long)pend->fcur * n;
+        fw = fw_all + (long long)pend->fcur * n;
+    }
     __shared__ __attribute__((aligned(16))) double lds[ST_LDS_DOUBLES];  // panel tiles / the parked pieces
     __shared__ double part[4][SPANEL];
     __shared__ double wstrip[SPANEL];
@@ -714,6 +794,33 @@ __global__ __launch_bounds__(256) void k_st_fwd_helped(double* __restrict__ M, l
             const long long r0 = J0 + 32 * wv + 16 * h;
 #pragma unroll
             for (int r = 0; r < 16; ++r) u[h][r] = *reinterpret_cast<const double2_t*>(M + (r0 + r) * ld + cl);
+        }
+    };
+    // MIRROR: request the pending update's coefficients of row block J0 (LDS; complete at the caller's next barrier)
+    auto load_pending = [&](long long J0) __attribute__((always_inline)) {
+        if constexpr (MIRROR) {
+            if (scale && threadIdx.x < SB) {
+                pb[threadIdx.x] = fb2[J0 + threadIdx.x];
+                pw[threadIdx.x] = fw[J0 + threadIdx.x];
+            }
+        }
+    };
+    // MIRROR: U[row][c..] <- U + fb2[row] * fl(U * fw[row]) on the rows just loaded (src/ell_stable.rs:114-117, the
+    // factor update of the PREVIOUS successful cut), stored back in place
+    auto scale_rows = [&](long long J0, double2_t (&u)[2][16]) __attribute__((always_inline)) {
+        if constexpr (MIRROR) {
+            if (!scale) return;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int rr = 32 * wv + 16 * h + r;
+                    const double bj = pb[rr], wj = pw[rr];
+                    u[h][r].x = u[h][r].x + bj * (u[h][r].x * wj);
+                    u[h][r].y = u[h][r].y + bj * (u[h][r].y * wj);
+                    if (c < n) *reinterpret_cast<double2_t*>(M + (J0 + rr) * ld + c) = u[h][r];
+                }
+            }
         }
     };
     // products (u <- u .* w of the row block in wblk); SUMS: also the strip's partial w (leaves with them applied)
@@ -778,6 +885,7 @@ __global__ __launch_bounds__(256) void k_st_fwd_helped(double* __restrict__ M, l
         // loads return in order, a request in front of the poll would delay the poll's answer by its own latency), apply.
         auto step = [&](long long kb, double2_t (&cur)[2][16], double2_t (&nxt)[2][16]) __attribute__((always_inline)) -> bool {
             ST_STAMP(kb, 0);
+            load_pending(kb * SB);
             if (threadIdx.x == 0) ok = st_wait_flag(flags + kb, epoch) ? 1 : 0;
             __syncthreads();
             if (!ok) return false;
@@ -785,6 +893,7 @@ __global__ __launch_bounds__(256) void k_st_fwd_helped(double* __restrict__ M, l
             if (threadIdx.x < SB) wblk[threadIdx.x] = st_published_load(w + kb * SB + threadIdx.x);
             __syncthreads();
             ST_STAMP(kb, 2);
+            scale_rows(kb * SB, cur);
             apply_rows(cur, std::true_type{});
             if (kb == last && threadIdx.x < SPANEL && c0 + threadIdx.x < n)
                 st_publish_store(hpart + c0 + threadIdx.x, wstrip[threadIdx.x]);  // the value is its own flag
@@ -792,7 +901,7 @@ __global__ __launch_bounds__(256) void k_st_fwd_helped(double* __restrict__ M, l
             // would delay the poll's answer by its own latency) and after the sums (issuing 128 KB of loads takes ~1 us)
             load_rows(((kb + 1 <= last) ? kb + 1 : last) * SB, nxt);  // (past the end: row block `last` again, unused)
             ST_STAMP(kb, 3);
-            if (kb % ST_HELPER_WRITES == 0) write_back(kb * SB, cur);
+            if (!MIRROR && kb % ST_HELPER_WRITES == 0) write_back(kb * SB, cur);
             else __syncthreads();  // part / wblk are rewritten by the next step
             ST_STAMP(kb, 4);
             return true;
@@ -811,7 +920,7 @@ __global__ __launch_bounds__(256) void k_st_fwd_helped(double* __restrict__ M, l
     double2_t u[2][16];
     // (1) writing duty: the products of the row blocks the helper leaves out, up to sblk - 5, until block sblk - 5 is solved
     long long duty_next = 0;  // the chain workgroup's row blocks below this one have their products in S (uniform)
-    {
+    if constexpr (!MIRROR) {
         const long long dlast = sblk - ST_DUTY_STOP;
         for (; duty_next <= dlast; ++duty_next) {
             const long long kb = duty_next;
@@ -841,7 +950,17 @@ __global__ __launch_bounds__(256) void k_st_fwd_helped(double* __restrict__ M, l
     Blk3 blk;
     double dreg = 0.0;
     st_prefetch_block(M, ld, n, c0, blk, dreg);
-    if (sblk > 0) load_rows((sblk - 1) * SB, u);
+    if (sblk > 0) {
+        load_rows((sblk - 1) * SB, u);
+        load_pending((sblk - 1) * SB);
+    }
+    if constexpr (MIRROR) {
+        if (scale) {  // the own diagonal block's factor entries (right of the diagonal) receive the pending update as well
+            st_scale_piece<true>(M, ld, n, c0, c0, blk.aa, fb2, fw, threadIdx.x);
+            st_scale_piece<true>(M, ld, n, c0, c0 + SH, blk.ab, fb2, fw, threadIdx.x);
+            st_scale_piece<true>(M, ld, n, c0 + SH, c0 + SH, blk.bb, fb2, fw, threadIdx.x);
+        }
+    }
     st_fwd_park(blk, dreg, lds, dlds);
     if (threadIdx.x == 0) ok = 1;
     __syncthreads();
@@ -867,11 +986,13 @@ __global__ __launch_bounds__(256) void k_st_fwd_helped(double* __restrict__ M, l
             return;
         }
         ST_STAMP(sblk, 2);
+        scale_rows((sblk - 1) * SB, u);
         apply_rows(u, std::true_type{});
     }
     __syncthreads();
     ST_STAMP(sblk, 3);
-    st_fwd_diag_block_pre(M, ld, n, c0, lds, dlds, wstrip, w, z, gg, flags + sblk, epoch, ucol);
+    st_fwd_diag_block_pre<!MIRROR>(M, ld, n, c0, lds, dlds, wstrip, w, z, gg, flags + sblk, epoch, ucol);
+    if constexpr (MIRROR) return;
     // (3) the products not written yet, off the chain (every w they need is published): the remaining odd row blocks and
     // row block sblk - 1 (the helper stops at sblk - 2)
     __syncthreads();  // the parked pieces have been written back: `lds` is free for the transposes
@@ -904,7 +1025,8 @@ __global__ __launch_bounds__(ST_MID_T) void k_st_mid(long long n, const double* 
                                                      double* __restrict__ cpre, DevState* __restrict__ st,
                                                      EllCalcDev calc, const CutParams* __restrict__ cp_dev,
                                                      CutParams cp_val, int queue_mode, int* __restrict__ q_status,
-                                                     double* __restrict__ q_tsq) {
+                                                     double* __restrict__ q_tsq, StPend* __restrict__ pend = nullptr,
+                                                     int w_sel = 0) {
     __shared__ double red[16];
     const int tid = threadIdx.x;
     if (st->halted) {
@@ -964,6 +1086,20 @@ __global__ __launch_bounds__(ST_MID_T) void k_st_mid(long long n, const double* 
             *q_tsq = tsq;
         }
         cpre[ST_MID_T] = t0;
+        if (pend) {
+            // mirrored layout: the forward solve of this update has just applied whatever the upper triangle lacked.  A
+            // successful cut produces a new factor update (k_st_post fills buffer fcur ^ 1): both triangles lack it from now
+            // on, and the backward solve of THIS update first applies the one the lower triangle still lacked.
+            pend->u_lacks = 0;
+            pend->have_w = 1;
+            pend->w_last = w_sel;
+            if (status == ST_SUCCESS) {
+                pend->l_apply = pend->l_lacks ? pend->fcur : -1;
+                pend->fcur ^= 1;
+                pend->u_lacks = 1;
+                pend->l_lacks = 1;
+            }
+        }
     }
 }
 
@@ -981,7 +1117,10 @@ __global__ __launch_bounds__(256) void k_st_post(double* __restrict__ M, long lo
                                                  double* __restrict__ w_rearm, const DevState* __restrict__ st,
                                                  double* __restrict__ hpart_rearm = nullptr,
                                                  int* __restrict__ fnext_reset = nullptr,
-                                                 double* __restrict__ qhpart_rearm = nullptr) {
+                                                 double* __restrict__ qhpart_rearm = nullptr,
+                                                 const StPend* __restrict__ pend = nullptr,
+                                                 double* __restrict__ fb2_all = nullptr, double* __restrict__ fw_all = nullptr,
+                                                 const double* __restrict__ w_cur = nullptr) {
     const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n) return;
     if (qhpart_rearm) qhpart_rearm[j] = st_sentinel();  // the backward helpers' hand-over buffer (k_st_bwd_factor_helped)
@@ -998,9 +1137,14 @@ __global__ __launch_bounds__(256) void k_st_post(double* __restrict__ M, long lo
     for (long long i = lo; i < j; ++i) told = told + gg[i];  // :111, left to right inside the chunk
     const double tnew = told + gg[j];       // :111
     const double zj = z[j];
-    beta2[j] = zj / tnew;                   // :112
+    const double b2 = zj / tnew;            // :112
+    beta2[j] = b2;
     M[j * ld + j] = M[j * ld + j] * (told / tnew);  // :113 / :121
     q[j] = zj;                              // :93
+    if (pend) {  // mirrored layout: this update's factor update, kept for the solves that will apply it (k_st_mid chose fcur)
+        fb2_all[(long long)pend->fcur * n + j] = b2;
+        fw_all[(long long)pend->fcur * n + j] = w_cur[j];
+    }
 }
 
 // ------------------------------------------------------------------------------ backward ------
@@ -1335,6 +1479,73 @@ __global__ __launch_bounds__(256) void k_st_xc(long long n, const double* __rest
         xc[i] = xc[i] - roo * q[i];
 }
 
+// Mirrored layout: a piece of L turned into the products the reference parked, S[j][t] = fl(L[j][t] w[t]) (per column).
+__device__ __forceinline__ void st_mul_piece_cols(long long n, long long C0, double2_t (&v)[8], const double* __restrict__ w,
+                                                  int tid) {
+    const long long c = C0 + 2 * (tid & 31);
+    const double w0 = (c < n) ? w[c] : 0.0, w1 = (c + 1 < n) ? w[c + 1] : 0.0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        v[k].x = v[k].x * w0;
+        v[k].y = v[k].y * w1;
+    }
+}
+
+// Between the two layouts: lower[i][j] = fl(U[j][i] * w[j]) for i > j (w != NULL: the scratch triangle exactly as the
+// forward solve with that w stored it, src/ell_stable.rs:66) or = U[j][i] (w == NULL: the mirrored copy of the factor).
+// 64 x 64 tiles transposed through LDS; grid (tiles, tiles), tiles left of the diagonal leave at once.
+__device__ __forceinline__ void st_transpose_lower_tile(double* __restrict__ M, long long ld, long long n,
+                                                        const double* __restrict__ w) {
+    const long long tj = blockIdx.y, ti = blockIdx.x;  // source tile rows j (tj), columns i (ti); destination rows i, columns j
+    if (ti < tj) return;
+    __shared__ double tile[64][65];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;  // 4 rows per pass
+    const long long j0 = tj * 64, i0 = ti * 64;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const long long j = j0 + ty + 4 * k, i = i0 + tx;
+        double v = 0.0;
+        if (j < n && i < n && i > j) {
+            v = M[j * ld + i];
+            if (w) v = v * w[j];
+        }
+        tile[ty + 4 * k][tx] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const long long i = i0 + ty + 4 * k, j = j0 + tx;
+        if (i < n && j < n && i > j) M[i * ld + j] = tile[tx][ty + 4 * k];
+    }
+}
+// reference layout -> mirrored layout.  Not on a halted queue (every solve behind it is a no-op as well, and the scratch
+// triangle of the failing cut has to survive until its results are read); whether it ran is device state (pend->mirrored,
+// set by k_st_mirror_mark behind it).
+__global__ __launch_bounds__(256) void k_st_mirror_enter(double* __restrict__ M, long long ld, long long n,
+                                                         const DevState* __restrict__ st) {
+    if (st->halted) return;
+    st_transpose_lower_tile(M, ld, n, nullptr);
+}
+__global__ void k_st_mirror_mark(StPend* __restrict__ pend, const DevState* __restrict__ st) {
+    StPend p;
+    p.fcur = 0, p.u_lacks = 0, p.l_lacks = 0, p.l_apply = -1, p.mirrored = st->halted ? 0 : 1, p.have_w = 0, p.w_last = 0, p.pad_ = 0;
+    *pend = p;
+}
+// mirrored layout -> reference layout, for an observer of the buffer: the scratch triangle of the last forward solve from U
+// as that solve saw it (U in memory: the solve stored what it scaled) and its w; the pending factor update on U follows
+// (k_st_factor_rows_pend), then k_st_mirror_clear.
+__global__ __launch_bounds__(256) void k_st_mirror_leave(double* __restrict__ M, long long ld, long long n,
+                                                         const StPend* __restrict__ pend, const double* __restrict__ w0,
+                                                         const double* __restrict__ w1) {
+    if (!pend->mirrored || !pend->have_w) return;
+    st_transpose_lower_tile(M, ld, n, pend->w_last ? w1 : w0);
+}
+__global__ void k_st_mirror_clear(StPend* __restrict__ pend) {
+    StPend p;
+    p.fcur = 0, p.u_lacks = 0, p.l_lacks = 0, p.l_apply = -1, p.mirrored = 0, p.have_w = 0, p.w_last = 0, p.pad_ = 0;
+    *pend = p;
+}
+
 // -------------------------------------------------------------------------------- factor ------
 // U[j][l] += beta2[j] * S[l][j] for l > j (src/ell_stable.rs:114-117), 64x64 tiles: tile (tj, tl),
 // tl >= tj, reads S rows l in tile tl / columns j in tile tj, transposes through LDS and updates the
@@ -1511,6 +1722,17 @@ __global__ __launch_bounds__(256) void k_st_factor_rows(double* __restrict__ M, 
     st_factor_tile<SEG, RW>(M, ld, n, beta2, w, (long long)blockIdx.x, (long long)blockIdx.y);
 }
 
+// The factor update the upper triangle of a mirrored buffer still lacks (leaving the mirrored layout)
+template <int SEG, int RW>
+__global__ __launch_bounds__(256) void k_st_factor_rows_pend(double* __restrict__ M, long long ld, long long n,
+                                                             const StPend* __restrict__ pend,
+                                                             const double* __restrict__ fb2_all,
+                                                             const double* __restrict__ fw_all) {
+    if (!pend->mirrored || !pend->u_lacks) return;
+    st_factor_tile<SEG, RW>(M, ld, n, fb2_all + (long long)pend->fcur * n, fw_all + (long long)pend->fcur * n,
+                            (long long)blockIdx.x, (long long)blockIdx.y);
+}
+
 // The same launch with a HELPER workgroup per block (as in k_st_fwd_helped) and no dedicated factor workers: 2 * nblk
 // workgroups, one per CU.  helper s: the strip's partial sums over the row blocks nblk-1 .. s+2, handed to chain s
 // (qhpart, all-sentinel at launch); chain s: own block parked, columns and the rows of row block s+1 in registers before
@@ -1521,7 +1743,12 @@ __global__ __launch_bounds__(256) void k_st_factor_rows(double* __restrict__ M, 
 // of waiting, and the chain itself has nothing in front of it when its turn comes.
 constexpr int FQ_H = 16;
 constexpr long long FQ_STOP = 6;
-template <int SEG, int RW>
+// MIRROR (the mirrored layout, see StPend): the addresses the scratch triangle used to occupy hold L[j][t] = U[t][j]; every
+// element loaded first receives the pending factor update of the update BEFORE this one (per column: the lane's constants
+// fb2[t], fw[t] of buffer pend->l_apply) and is stored back in place, then becomes the product the reference parked,
+// fl(L[j][t] w[t]) with this update's w (src/ell_stable.rs:66), and enters the same sums in the same order.  No factor
+// tiles: this update's factor update is applied by the NEXT forward / backward solve.
+template <int SEG, int RW, bool MIRROR = false>
 __global__ __launch_bounds__(256) void k_st_bwd_factor_helped(double* __restrict__ M, long long ld, long long n,
                                                               double* __restrict__ q, double* __restrict__ qpub,
                                                               double* __restrict__ qhpart, int* __restrict__ err,
@@ -1529,7 +1756,10 @@ __global__ __launch_bounds__(256) void k_st_bwd_factor_helped(double* __restrict
                                                               const double* __restrict__ beta2,
                                                               const double* __restrict__ w,
                                                               const int* __restrict__ ftiles, int nftiles,
-                                                              int* __restrict__ fnext, long long fq_stop) {
+                                                              int* __restrict__ fnext, long long fq_stop,
+                                                              const StPend* __restrict__ pend = nullptr,
+                                                              const double* __restrict__ fb2_all = nullptr,
+                                                              const double* __restrict__ fw_all = nullptr) {
     if (!st->apply) return;
     __shared__ double lds[ST_LDS_DOUBLES_B];
     __shared__ double part[4][SPANEL];
@@ -1543,9 +1773,30 @@ __global__ __launch_bounds__(256) void k_st_bwd_factor_helped(double* __restrict
     const long long c0 = sblk * SB;
     const long long c = c0 + 2 * lane;  // columns c, c+1 < c0 + 128 <= J0 of every row block applied here
     const bool has_b = c0 + SH < n;
+    // MIRROR: this lane's two columns t = c, c + 1: w[t] of the update in flight, and the pending update's (beta2, w)[t]
+    double wc0 = 0.0, wc1 = 0.0, bp0 = 0.0, bp1 = 0.0, wp0 = 0.0, wp1 = 0.0;
+    bool scale = false;
+    const double* fb2 = nullptr;
+    const double* fw = nullptr;
+    if constexpr (MIRROR) {
+        scale = pend->l_apply >= 0;
+        if (scale) {
+            fb2 = fb2_all + (long long)pend->l_apply * n;
+            fw = fw_all + (long long)pend->l_apply * n;
+        }
+        if (c < n) {
+            wc0 = w[c];
+            if (scale) bp0 = fb2[c], wp0 = fw[c];
+        }
+        if (c + 1 < n) {
+            wc1 = w[c + 1];
+            if (scale) bp1 = fb2[c + 1], wp1 = fw[c + 1];
+        }
+    }
 
     // factor tiles until the queue is empty or (deadline >= 0) block `deadline` has been solved
     auto work = [&](long long deadline) __attribute__((always_inline)) {
+        if constexpr (MIRROR) return;
         for (;;) {
             if (threadIdx.x == 0) {
                 int stop = 0;
@@ -1572,6 +1823,25 @@ __global__ __launch_bounds__(256) void k_st_bwd_factor_helped(double* __restrict
                 long long row = r0 + r;
                 if (row > n - 1) row = n - 1;
                 sv[h][r] = *reinterpret_cast<const double2_t*>(M + row * ld + c);
+            }
+        }
+    };
+    // MIRROR: the rows just loaded hold L[j][t]; pending update (stored back in place), then the parked product fl(L w[t])
+    auto mirror_rows = [&](long long J0, double2_t (&sv)[2][16]) __attribute__((always_inline)) {
+        if constexpr (MIRROR) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const long long row = J0 + 32 * wv + 16 * h + r;
+                    if (scale) {
+                        sv[h][r].x = sv[h][r].x + bp0 * (sv[h][r].x * wp0);
+                        sv[h][r].y = sv[h][r].y + bp1 * (sv[h][r].y * wp1);
+                        if (row < n && c < n) *reinterpret_cast<double2_t*>(M + row * ld + c) = sv[h][r];
+                    }
+                    sv[h][r].x = sv[h][r].x * wc0;
+                    sv[h][r].y = sv[h][r].y * wc1;
+                }
             }
         }
     };
@@ -1626,6 +1896,7 @@ __global__ __launch_bounds__(256) void k_st_bwd_factor_helped(double* __restrict
                 if (threadIdx.x == 0) atomicExch(err, 2);
                 return;
             }
+            mirror_rows(kb * SB, sv);
             apply_rows(sv);
         }
         if (sblk + 2 <= nblk - 1 && threadIdx.x < SPANEL && c0 + threadIdx.x < n)
@@ -1641,6 +1912,16 @@ __global__ __launch_bounds__(256) void k_st_bwd_factor_helped(double* __restrict
     double2_t sv[2][16];
     st_prefetch_block_bwd(M, ld, n, c0, blk);
     if (sblk + 1 <= nblk - 1) load_rows((sblk + 1) * SB, sv);
+    if constexpr (MIRROR) {  // the own diagonal block: pending update below the diagonal (in place), then the parked products
+        if (scale) {
+            st_scale_piece<false>(M, ld, n, c0 + SH, c0 + SH, blk.bb, fb2, fw, threadIdx.x);
+            st_scale_piece<false>(M, ld, n, c0 + SH, c0, blk.ba, fb2, fw, threadIdx.x);
+            st_scale_piece<false>(M, ld, n, c0, c0, blk.aa, fb2, fw, threadIdx.x);
+        }
+        st_mul_piece_cols(n, c0 + SH, blk.bb, w, threadIdx.x);
+        st_mul_piece_cols(n, c0, blk.ba, w, threadIdx.x);
+        st_mul_piece_cols(n, c0, blk.aa, w, threadIdx.x);
+    }
     st_park_piece(lds, blk.bb, threadIdx.x);
     st_park_piece(lds + SH * BLK_PITCH, blk.ba, threadIdx.x);
     st_park_piece(lds + 2 * SH * BLK_PITCH, blk.aa, threadIdx.x);
@@ -1656,6 +1937,7 @@ __global__ __launch_bounds__(256) void k_st_bwd_factor_helped(double* __restrict
             if (threadIdx.x == 0) atomicExch(err, 2);
             return;
         }
+        mirror_rows((sblk + 1) * SB, sv);
         apply_rows(sv);
     }
     __syncthreads();

@@ -254,8 +254,16 @@ int ellhip_set_shard_symmetric(ellhip_space *s, int flag);
  *                                                    stage is sized for it): half as many apply passes; on return fewer
  *                                                    than the handle's depth are left, as everywhere else.  0: never
  *                                                    more than the handle's depth
- *   ELLHIP_OPT_STABLE_SOLVE      0 / 1 / 2  2        EllStable: 0 = one launch per 128-block (no in-launch waits),
- *                                                    1 = persistent solves, 2 = persistent + helper workgroups
+ *   ELLHIP_OPT_STABLE_SOLVE      0 .. 3     3        EllStable: 0 = one launch per 128-block (no in-launch waits),
+ *                                                    1 = persistent solves, 2 = persistent + helper workgroups,
+ *                                                    3 = 2 on the MIRRORED layout: the handle's private buffer holds the
+ *                                                    factor on both sides of the diagonal, the scratch triangle
+ *                                                    (src/ell_stable.rs:66) is not kept and the factor update (:107-121)
+ *                                                    is applied by the next forward / backward solve to the tiles they
+ *                                                    load -- 16 n^2 bytes per update instead of 20 n^2, no third pass;
+ *                                                    ellhip_get_mq / ellhip_clone see the reference's buffer (rebuilt
+ *                                                    exactly: identical bits to 0 / 1 / 2).  Where the helper form does
+ *                                                    not fit the device (n > 16384 on 256 CUs) 3 runs as 1
  *   ELLHIP_OPT_STABLE_FACTOR     0 / 1 / 2  2        EllStable factor update: 0 = tile kernel reading the scratch
  *                                                    triangle (the reference's data flow, 12 n^2 bytes), 1 = row kernel
  *                                                    from U alone (8 n^2) beside the backward solve, 2 = pulled inside

@@ -560,7 +560,7 @@ def test_every_per_handle_option_round_trips(gpu):
     assert e.defer_depth == 24
     e.set_option(capi.OPT_SYMV, 0)      # the lower-triangle schedule is gone: depth 24 falls back to 8
     assert e.defer_depth == 8
-    st_keys = {"STABLE_SOLVE": [0, 1, 2], "STABLE_FACTOR": [0, 1, 2]}
+    st_keys = {"STABLE_SOLVE": [0, 1, 2, 3], "STABLE_FACTOR": [0, 1, 2]}
     s = gpu.EllStable.new_with_scalar(1.0, np.zeros(64))
     for name, values in st_keys.items():
         for v in values:

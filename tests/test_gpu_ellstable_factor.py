@@ -14,6 +14,7 @@ import pytest
 from util import TOL, assert_state_close, random_factor, rel_inf, run_mixed_stable, set_default
 
 pytestmark = pytest.mark.gpu
+DEFAULT_SOLVE = 3   # what a new EllStable handle starts with (ELLHIP_OPT_STABLE_SOLVE)
 
 # block edges of the 64-wide halves and the 128-wide blocks of the solves, ragged last blocks, several blocks
 SIZES = [2, 3, 63, 64, 65, 127, 128, 129, 257, 1000, 2048]
@@ -29,12 +30,18 @@ def _offdiag_nonzeros(m):
     return int(np.count_nonzero(m - np.diag(np.diag(m))))
 
 
+@pytest.mark.parametrize("solve,every", [(2, 4), (3, 4), (3, 0)])
 @pytest.mark.parametrize("n", SIZES)
-def test_mixed_sequence_on_random_factor_matches_oracle(gpu, orc, n):
-    """All six EllCalc entry points incl. a failing cut every 8th step (it rewrites the scratch triangle only)."""
+def test_mixed_sequence_on_random_factor_matches_oracle(gpu, orc, n, solve, every):
+    """All six EllCalc entry points incl. a failing cut every 8th step (it rewrites the scratch triangle only).
+    solve = 3: the mirrored layout (no scratch triangle, the factor update applied by the next solves); every = 4: the buffer
+    is observed every 4th cut (the layout is left -- scratch triangle rebuilt, pending factor update applied -- and entered
+    again), every = 0: only at the end, after up to 24 cuts inside the layout."""
+    set_default("STABLE_SOLVE", solve)
     g, o, f = _pair(gpu, orc, n, 9000 + n)
+    assert g.get_option(gpu.capi.OPT_STABLE_SOLVE) == solve
     k = 24 if n <= 1000 else 16
-    nsucc = run_mixed_stable(g, o, k, seed=700 + n, check_every=4)
+    nsucc = run_mixed_stable(g, o, k, seed=700 + n, check_every=every)
     assert nsucc >= k // 2
     assert_state_close(g, o, what=f"n={n} final")
     m = g.mq
@@ -93,17 +100,19 @@ def test_persistent_equals_per_block_launches_on_random_factor(gpu, n):
 @pytest.mark.parametrize("n", [2, 63, 64, 65, 129, 300, 513, 1000, 2048, 2048 + 128, 2049, 8192, 8200, 8191])
 def test_default_solves_and_factor_update_equal_the_plain_kernels(gpu, n):
     """Every EllStable kernel form must give the bits of the plain path (one launch per block, factor update reading the
-    scratch triangle through LDS transposes): the default -- both solves with a helper workgroup per block
+    scratch triangle through LDS transposes): both solves with a helper workgroup per block
     (k_st_fwd_helped, k_st_bwd_factor_helped) and the factor update computed from U alone inside the backward solve's
     launch (the scratch entry it would read IS fl(U * w)) --, the persistent solves without helpers with the row-wise
-    factor kernel beside them (k_st_fwd_persist, k_st_bwd_persist, k_st_factor_rows), and the forms switched on an
-    existing handle with ellhip_set_option.  Odd and even n, ragged last blocks, one block, a failing cut in the middle;
+    factor kernel beside them (k_st_fwd_persist, k_st_bwd_persist, k_st_factor_rows), the MIRRORED layout (STABLE_SOLVE = 3:
+    no scratch triangle inside the loop, the factor update applied by the next forward / backward solve to the tiles they
+    load; the reference's buffer rebuilt when it is observed), and the forms switched on an
+    existing handle with ellhip_set_option.  Odd and even n, ragged last blocks, one block, failing cuts in the middle;
     8191 / 8192 / 8200 straddle the size where the factor tiles switch from 512- to 2048-column segments and the chain
     workgroups stop pulling tiles before their turn."""
     capi = gpu.capi
     f = random_factor(n, 271 + n)
     a = gpu.EllStable.new_with_matrix(1.0, f, np.zeros(n))
-    assert a.get_option(capi.OPT_STABLE_SOLVE) == 2 and a.get_option(capi.OPT_STABLE_FACTOR) == 2
+    assert a.get_option(capi.OPT_STABLE_SOLVE) == DEFAULT_SOLVE and a.get_option(capi.OPT_STABLE_FACTOR) == 2
     set_default("STABLE_SOLVE", 0)
     set_default("STABLE_FACTOR", 0)
     b = gpu.EllStable.new_with_matrix(1.0, f, np.zeros(n))
@@ -114,26 +123,33 @@ def test_default_solves_and_factor_update_equal_the_plain_kernels(gpu, n):
     set_default("STABLE_SOLVE", 2)
     set_default("STABLE_FACTOR", 2)
     d = gpu.EllStable.new_with_matrix(1.0, f, np.zeros(n))   # walks through the forms, one per cut
-    forms = [(0, 0), (1, 0), (1, 1), (2, 1), (2, 2), (0, 1), (2, 0), (1, 2)]
+    e2 = gpu.EllStable.new_with_matrix(1.0, f, np.zeros(n))  # helped solves + pulled factor tiles throughout
+    set_default("STABLE_SOLVE", 3)
+    e3 = gpu.EllStable.new_with_matrix(1.0, f, np.zeros(n))  # the mirrored layout throughout (observed once, in the middle)
+    forms = [(0, 0), (1, 0), (3, 1), (3, 1), (3, 2), (3, 0), (2, 1), (2, 2), (3, 2), (0, 1), (3, 0), (3, 0), (1, 2), (3, 1)]
+    fails = (5, 10)          # (both inside a stretch of the mirrored layout: the scratch triangle of a failed cut is lazy too)
     rng = np.random.default_rng(13 * n)
-    for i in range(8):
+    for i in range(len(forms)):
         gr = rng.standard_normal(n)
         gr /= np.linalg.norm(gr)
-        beta = 5.0 if i == 5 else 0.05 * rng.random()
+        beta = 5.0 if i in fails else 0.05 * rng.random()
         d.set_option(capi.OPT_STABLE_SOLVE, forms[i][0])
         d.set_option(capi.OPT_STABLE_FACTOR, forms[i][1])
-        sa, sb, sc, sd = (int(x.update_bias_cut((gr, beta))) for x in (a, b, c, d))
-        assert sa == sb == sc == sd == (1 if i == 5 else 0)
-        assert a.tsq() == b.tsq() == c.tsq() == d.tsq() and a.kappa == b.kappa == c.kappa == d.kappa
+        stats = [int(x.update_bias_cut((gr, beta))) for x in (a, b, c, d, e2, e3)]
+        assert stats == [1 if i in fails else 0] * 6, (i, stats)
+        assert a.tsq() == b.tsq() == c.tsq() == d.tsq() == e2.tsq() == e3.tsq()
+        assert a.kappa == b.kappa == c.kappa == d.kappa == e2.kappa == e3.kappa
+        if i in (3, 5, 8):   # the mirrored handle observed after a success, right after a failing cut, and again
+            assert np.array_equal(e3.mq, b.mq), f"mirrored layout, buffer after cut {i}"
     qb = b.mq
-    for x in (a, c, d):
+    for x in (a, c, d, e2, e3):
         assert np.array_equal(x.xc(), b.xc()) and np.array_equal(x.mq, qb)
     with pytest.raises(capi.EllHipError):
         gpu.Ell.new_with_scalar(1.0, np.zeros(8)).set_option(capi.OPT_STABLE_SOLVE, 1)   # an EllStable option
     with pytest.raises(capi.EllHipError):
         a.set_option(capi.OPT_SYMV, 0)                                                   # an Ell option
     with pytest.raises(capi.EllHipError):
-        a.set_option(capi.OPT_STABLE_SOLVE, 3)
+        a.set_option(capi.OPT_STABLE_SOLVE, 4)
 
 
 def test_failed_cut_in_the_middle_of_a_sequence(gpu, orc):
@@ -151,8 +167,10 @@ def test_failed_cut_in_the_middle_of_a_sequence(gpu, orc):
         assert_state_close(g, o, what=f"cut {i}")
 
 
-def test_clone_and_queue_on_random_factor(gpu, orc):
+@pytest.mark.parametrize("solve", [2, 3])
+def test_clone_and_queue_on_random_factor(gpu, orc, solve):
     from ellalgo_rs_amd import synth
+    set_default("STABLE_SOLVE", solve)
     n, k = 320, 10
     kinds, grads, b0, b1 = synth.deep_cuts(n, k)
     f = random_factor(n, 99)
@@ -193,3 +211,34 @@ def test_synth_stable_factor_long_run(gpu, orc):
         assert abs(ts[i] - o.tsq) <= TOL * abs(o.tsq), i
     assert np.all(st == 0)
     assert_state_close(g, o, what="120 cuts")
+
+
+@pytest.mark.parametrize("n", [200, 1000, 2176])
+def test_halted_queue_in_the_mirrored_layout(gpu, orc, n):
+    """A queue whose cut 7 fails, on the mirrored layout: the forward solve of the failing cut has already applied the factor
+    update of cut 6 to U (in place) and produced the w the failed cut's scratch triangle is made of; every kernel behind it is
+    a no-op; reading the results leaves the layout (scratch triangle of cut 7, nothing pending on U); a second run on the
+    still-halted queue must not touch the buffer; direct updates afterwards enter the layout again."""
+    from ellalgo_rs_amd import synth
+    set_default("STABLE_SOLVE", 3)
+    k, bad = 14, 7
+    kinds, grads, b0, b1 = synth.deep_cuts(n, k)
+    b0 = b0.copy()
+    b0[bad] = 1e6
+    f = random_factor(n, 555 + n)
+    g = gpu.EllStable.new_with_matrix(1.0, f, np.zeros(n))
+    o = orc.OracleEllStable.new_with_matrix(1.0, f, np.zeros(n))
+    g.queue_upload(kinds, grads, b0, b1)
+    g.queue_run(0, 10)
+    g.queue_run(10, 4)          # halted: nothing runs
+    st, ts = g.queue_results()
+    for i in range(bad + 1):
+        assert o.update(0, grads[i], b0[i]) == (1 if i == bad else 0)
+        assert abs(ts[i] - o.tsq) <= TOL * abs(o.tsq)
+    assert list(st[:bad]) == [0] * bad and int(st[bad]) == 1 and all(int(x) == 3 for x in st[bad + 1:])
+    assert_state_close(g, o, what="after the halt")
+    assert rel_inf(np.tril(g.mq, -1), np.tril(o.mq, -1)) <= TOL      # the failing cut's scratch triangle
+    for i in range(bad + 1, k):
+        b0[i] = 0.02
+        assert int(g.update_bias_cut((grads[i], b0[i]))) == o.update(0, grads[i], b0[i]) == 0
+    assert_state_close(g, o, what="direct updates after the halt")

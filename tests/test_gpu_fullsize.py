@@ -173,7 +173,8 @@ def test_ell_default_schedule_matches_oracle_at_full_size(gpu, orc):
     assert np.array_equal(qg[:2048, :2048], qg[:2048, :2048].T)
 
 
-def test_ellstable_matches_oracle_at_full_size(gpu, orc):
+@pytest.mark.parametrize("solve", [2, 3])
+def test_ellstable_matches_oracle_at_full_size(gpu, orc, solve):
     """BASELINE config 5 (n = 16384 EllStable, deep cuts) from the NON-trivial factor bench.py uses
     (synth.stable_factor: random unit-upper-triangular factor, random positive diagonal, junk in the scratch
     triangle -- from the identity the off-diagonal part of the buffer stays exactly zero and the comparison would be
@@ -184,6 +185,7 @@ def test_ellstable_matches_oracle_at_full_size(gpu, orc):
     k = 3
     kinds, grads, b0, _ = synth.deep_cuts(N, k)
     f = synth.stable_factor(N)
+    set_default("STABLE_SOLVE", solve)   # 3: the mirrored layout (three cuts inside it, the buffer rebuilt for the comparison)
     e = gpu.EllStable.new_with_matrix(1.0, f, np.zeros(N))
     o = orc.OracleEllStable.new_with_matrix(1.0, f, np.zeros(N))
     del f
