@@ -572,7 +572,11 @@ def brief_config(pkg, synth, torch, workload: str, K: int, W: int, P: int, devic
     look = space.get_option(pkg.capi.OPT_LOOKAHEAD) if (variant == "ell" and symv_mode) else 1
     qd = space.get_option(pkg.capi.OPT_QUEUE_DEPTH) if (variant == "ell" and symv_mode) else 0
     dep_eff = qd if (variant == "ell" and symv_mode and lower_apply and look > 3 and n % 64 == 0 and depth == 24 and qd > depth) else depth
-    if variant != "ell":
+    if variant != "ell" and space.get_option(pkg.capi.OPT_STABLE_MIRRORED):
+        alg["stable_fwd"], alg["stable_bwd"], alg["stable_factor"] = 8.0 * n2, 8.0 * n2, 0.0
+        bytes_update, model = 16.0 * n2, ("16*n^2 B per update (EllStable, mirrored layout: each solve reads its triangle and stores "
+                                          "it back with the previous cut's factor update applied, 8 + 8)")
+    elif variant != "ell":
         fb = 8.0 if space.get_option(pkg.capi.OPT_STABLE_FACTOR) != 0 else 12.0
         alg["stable_factor"] = fb * n2
         if prof.get("stable_factor", (0.0, 0))[1] == 0:   # pulled inside the backward solve's launch
@@ -987,6 +991,10 @@ def main() -> None:
         alg["stable_factor"] = (8.0 if rows else 12.0) * n * n
         if prof and prof.get("stable_factor", (0.0, 0))[1] == 0:
             alg["stable_bwd"] = 4.0 * n * n + alg["stable_factor"]
+        if space.get_option(pkg.capi.OPT_STABLE_MIRRORED):
+            # mirrored layout: each solve reads its triangle and stores it back with the previous cut's factor update applied
+            # (4 + 4), nothing else moves: no scratch triangle, no factor pass
+            alg["stable_fwd"], alg["stable_bwd"], alg["stable_factor"] = 8.0 * n * n, 8.0 * n * n, 0.0
 
     lookahead, queue_depth = 1, 0
     if variant == "ell" and symv_mode and not sharded:
@@ -1022,7 +1030,10 @@ def main() -> None:
     # bytes one update moves under the schedule that was timed (each schedule has its OWN byte model;
     # nothing is credited against the 24*n^2 two-pass model)
     resident_run = variant == "ell" and bool(prof) and prof.get("resident", (0.0, 0))[1] > 0
-    if variant != "ell":
+    if variant != "ell" and space.get_option(pkg.capi.OPT_STABLE_MIRRORED):
+        bytes_update, model = 16.0 * n * n, ("16*n^2 B per update (EllStable, mirrored layout: each solve reads its triangle and "
+                                             "stores it back with the previous cut's factor update applied, 8 + 8)")
+    elif variant != "ell":
         fb = alg["stable_factor"] / (n * n)
         bytes_update, model = (12.0 + fb) * n * n, f"{12.0 + fb:g}*n^2 B per update (EllStable: fwd 8 + bwd 4 + factor {fb:g})"
     elif resident_run:

@@ -113,8 +113,11 @@ struct ellhip_space {
     bool st_mirrored = false;        // host view: the handle's solves run on the mirrored layout (the device's own flag, StPend.mirrored,
                                      // says whether the lower triangle really holds the mirrored factor: not after a halted queue)
     StPend* d_stpend = nullptr;
-    double* d_fb2 = nullptr;         // [2][n] beta2 of the factor updates the triangles may still lack
-    double* d_fw = nullptr;          // [2][n] ... and the w they go with
+    double* d_rbuf = nullptr;        // [2][n] running row scales of the factor (two buffers: StPend says who reads which)
+    double* d_wkeep = nullptr;       // [n] w of the last forward solve that really ran (what the scratch triangle is made of)
+    int st_since_enter = 0;          // updates issued since the layout was entered (re-entered every ST_MIRROR_PERIOD)
+    bool st_prev_persist = true;     // the previous update ran the persistent / helped solves: its k_st_post re-armed their
+    bool st_prev_helped = true;      // hand-over buffers for this one (true at creation: alloc_common arms them all)
     double* d_partial = nullptr;     // per-workgroup partial sums of omega (64)
     double* d_pend = nullptr;        // deferred mode: MAXPEND pending gt vectors (n each)
     double* d_cpend = nullptr;       // deferred mode: their coefficients sigma/omega
@@ -496,31 +499,29 @@ int launch_mirror_if_needed(ellhip_space* s) {
 }
 
 // EllStable, mirrored layout (ELLHIP_OPT_STABLE_SOLVE = 3; ellstable_kernels.hpp, StPend): entering copies the factor below
-// the diagonal (one 8 n^2-byte pass, once); leaving -- before anything observes the buffer (get_mq, clone), on a mode switch,
-// when a halted queue's results are read -- rebuilds the scratch triangle of the last forward solve from U and that solve's
-// w, then applies the factor update U may still lack: the buffer is then exactly what the eager kernels leave.
+// the diagonal and sets every row scale to 1 (one 8 n^2-byte pass); leaving -- before anything observes the buffer (get_mq,
+// clone), on a mode switch, when a halted queue's results are read, and every ST_MIRROR_PERIOD updates so that the running
+// scales stay products of few factors -- rebuilds the scratch triangle of the last forward solve and scales U: the buffer is
+// then what the eager kernels leave (to rounding: one rounding per element where they had two per update).
+constexpr int ST_MIRROR_PERIOD = 256;
 int stable_mirror_enter(ellhip_space* s) {
     const unsigned t = (unsigned)((s->n + 63) / 64);
-    hipLaunchKernelGGL(k_st_mirror_enter, dim3(t, t), dim3(256), 0, s->stream, s->d_Q, s->ld, s->n, (const DevState*)s->d_st);
+    hipLaunchKernelGGL(k_st_mirror_enter, dim3(t, t), dim3(256), 0, s->stream, s->d_Q, s->ld, s->n, (const DevState*)s->d_st,
+                       s->d_rbuf);
     hipLaunchKernelGGL(k_st_mirror_mark, dim3(1), dim3(1), 0, s->stream, s->d_stpend, (const DevState*)s->d_st);
     HIPCHK(hipGetLastError());
     s->st_mirrored = true;
+    s->st_since_enter = 0;
     return 0;
 }
 int stable_mirror_leave(ellhip_space* s) {
     if (!s->st_mirrored) return 0;
     const long long n = s->n;
     const unsigned t = (unsigned)((n + 63) / 64);
-    const double* w0 = s->d_work;
-    const double* w1 = w0 + 6 * n;
-    hipLaunchKernelGGL(k_st_mirror_leave, dim3(t, t), dim3(256), 0, s->stream, s->d_Q, s->ld, n, (const StPend*)s->d_stpend, w0, w1);
-    const unsigned gy = (unsigned)((n + FROW_H - 1) / FROW_H);
-    if (n >= 8192)
-        hipLaunchKernelGGL((k_st_factor_rows_pend<2048, 2>), dim3(gy, (unsigned)((n + 2047) / 2048)), dim3(256), 0, s->stream,
-                           s->d_Q, s->ld, n, (const StPend*)s->d_stpend, (const double*)s->d_fb2, (const double*)s->d_fw);
-    else
-        hipLaunchKernelGGL((k_st_factor_rows_pend<512, 4>), dim3(gy, (unsigned)((n + 511) / 512)), dim3(256), 0, s->stream,
-                           s->d_Q, s->ld, n, (const StPend*)s->d_stpend, (const double*)s->d_fb2, (const double*)s->d_fw);
+    hipLaunchKernelGGL(k_st_mirror_leave, dim3(t, t), dim3(256), 0, s->stream, s->d_Q, s->ld, n, (const StPend*)s->d_stpend,
+                       (const double*)s->d_rbuf, (const double*)s->d_wkeep);
+    hipLaunchKernelGGL(k_st_unscale_upper, dim3((unsigned)std::min<long long>(16, (n + 255) / 256), (unsigned)n), dim3(256), 0,
+                       s->stream, s->d_Q, s->ld, n, (const StPend*)s->d_stpend, (const double*)s->d_rbuf);
     hipLaunchKernelGGL(k_st_mirror_clear, dim3(1), dim3(1), 0, s->stream, s->d_stpend);
     HIPCHK(hipGetLastError());
     s->st_mirrored = false;
@@ -556,27 +557,43 @@ int ellstable_issue(ellhip_space* s, const double* g_dev, const CutParams* cp_de
     double* w = (persist && (s->epoch & 1)) ? w1 : w0;
     double* w_next = (persist && (s->epoch & 1)) ? w0 : w1;
     int* err = reinterpret_cast<int*>(reinterpret_cast<char*>(s->d_st) + offsetof(DevState, solve_err));
+    // The hand-over buffers of the in-launch waits are re-armed (all-sentinel) by the k_st_post of the update BEFORE the one
+    // that polls them.  After a switch of forms (ellhip_set_option between two updates) that update may have run a form that
+    // does not: its solve then left real values in w, and a consumer polling "the value is its own flag" would take the old
+    // block for the new one.  Arm what this update polls and the previous one did not arm.
+    {
+        const unsigned ga = (unsigned)((n + 255) / 256);
+        if (persist && !s->st_prev_persist) hipLaunchKernelGGL(k_st_arm, dim3(ga), dim3(256), 0, st, w, n);
+        if (helped && !s->st_prev_helped) hipLaunchKernelGGL(k_st_arm, dim3(ga), dim3(256), 0, st, s->d_hpart, n);
+        s->st_prev_persist = persist;
+        s->st_prev_helped = helped;
+    }
     // the helped backward solve (with or without factor tiles) needs its tile list / hand-over buffer and both grids resident
     const bool helped_b = helped && s->d_ftiles16 && s->d_fnext && s->d_qhpart && 2 * nb <= s->persist_cap1;
     // the mirrored layout (STABLE_SOLVE = 3): no scratch triangle, no factor pass -- both helped solves in their MIRROR form
     const bool mirror = helped_b && s->stable_solve >= 3 && s->d_stpend;
     // factor update inside the backward solve's launch: needs the helped form and the row-wise (U alone) arithmetic
     const bool fused_h = helped_b && !mirror && s->stable_factor >= 2;
+    if (mirror && s->st_mirrored && s->st_since_enter >= ST_MIRROR_PERIOD) {
+        int mrc = stable_mirror_leave(s);  // (and in again below: the row scales start from 1)
+        if (mrc) return mrc;
+    }
     if (mirror != s->st_mirrored) {
         int mrc = mirror ? stable_mirror_enter(s) : stable_mirror_leave(s);
         if (mrc) return mrc;
     }
+    if (mirror) s->st_since_enter += 1;
     const StPend* pend_c = mirror ? s->d_stpend : nullptr;
     {
         ProfScope ps(s, CLS_ST_FWD);
         if (mirror) {
             hipLaunchKernelGGL(k_st_fwd_helped<true>, dim3((unsigned)(2 * nb)), dim3(256), 0, st, s->d_Q, ld, n, g_dev, w,
                                s->d_hpart, z, gg, s->d_flags, err, s->epoch, (const DevState*)s->d_st, pend_c,
-                               (const double*)s->d_fb2, (const double*)s->d_fw);
+                               (const double*)s->d_rbuf);
         } else if (helped) {
             hipLaunchKernelGGL(k_st_fwd_helped<false>, dim3((unsigned)(2 * nb)), dim3(256), 0, st, s->d_Q, ld, n, g_dev, w,
                                s->d_hpart, z, gg, s->d_flags, err, s->epoch, (const DevState*)s->d_st, (const StPend*)nullptr,
-                               (const double*)nullptr, (const double*)nullptr);
+                               (const double*)nullptr);
         } else if (persist) {
             hipLaunchKernelGGL(k_st_fwd_persist, dim3((unsigned)nb), dim3(256), 0, st, s->d_Q, ld, n, g_dev, w, z, gg,
                                s->d_flags, err, s->epoch, s->d_st);
@@ -595,12 +612,12 @@ int ellstable_issue(ellhip_space* s, const double* g_dev, const CutParams* cp_de
         ProfScope ps(s, CLS_SCALAR);
         EllCalcDev calc = EllCalcDev::make(n, s->use_parallel_cut);
         hipLaunchKernelGGL(k_st_mid, dim3(1), dim3(ST_MID_T), 0, st, n, (const double*)gg, cpre, s->d_st, calc, cp_dev,
-                           cp_val, queue_mode, qst, qtsq, mirror ? s->d_stpend : (StPend*)nullptr, (w == w1) ? 1 : 0);
+                           cp_val, queue_mode, qst, qtsq, mirror ? s->d_stpend : (StPend*)nullptr);
         hipLaunchKernelGGL(k_st_post, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, s->d_Q, ld, n,
                            (const double*)z, (const double*)gg, (const double*)cpre, q, beta2,
                            persist ? qpub : (double*)nullptr, persist ? w_next : (double*)nullptr,
                            (const DevState*)s->d_st, helped ? s->d_hpart : (double*)nullptr, s->d_fnext,
-                           (fused_h || mirror) ? s->d_qhpart : (double*)nullptr, pend_c, s->d_fb2, s->d_fw, (const double*)w);
+                           (fused_h || mirror) ? s->d_qhpart : (double*)nullptr, pend_c, s->d_rbuf, (const double*)w, s->d_wkeep);
         HIPCHK(hipGetLastError());
     }
     // The factor update (rewrites U) and the backward solve (reads S, writes q) are independent.  Helped form: the
@@ -614,8 +631,7 @@ int ellstable_issue(ellhip_space* s, const double* g_dev, const CutParams* cp_de
         if (mirror) {
             hipLaunchKernelGGL((k_st_bwd_factor_helped<2048, 8, true>), dim3((unsigned)(2 * nb)), dim3(256), 0, st, s->d_Q, ld, n, q,
                                qpub, s->d_qhpart, err, (const DevState*)s->d_st, nb, (const double*)beta2, (const double*)w,
-                               (const int*)s->d_ftiles16, s->nftiles16, s->d_fnext, nb + 1, pend_c, (const double*)s->d_fb2,
-                               (const double*)s->d_fw);
+                               (const int*)s->d_ftiles16, s->nftiles16, s->d_fnext, nb + 1, pend_c, (const double*)s->d_rbuf);
         } else if (fused_h) {
             const unsigned grid = (unsigned)(2 * nb);
             // before their turn the chain workgroups pull factor tiles only when the matrix is on-die (n < 8192): from HBM
@@ -1108,8 +1124,8 @@ int alloc_common(ellhip_space* s) {
         HIPCHK(hipMalloc(&s->d_hpart, vbytes));
         hipLaunchKernelGGL(k_st_arm, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream, s->d_hpart, n);
         HIPCHK(hipMalloc(&s->d_stpend, sizeof(StPend)));
-        HIPCHK(hipMalloc(&s->d_fb2, 2 * vbytes));
-        HIPCHK(hipMalloc(&s->d_fw, 2 * vbytes));
+        HIPCHK(hipMalloc(&s->d_rbuf, 2 * vbytes));
+        HIPCHK(hipMalloc(&s->d_wkeep, vbytes));
         hipLaunchKernelGGL(k_st_mirror_clear, dim3(1), dim3(1), 0, s->stream, s->d_stpend);
         HIPCHK(hipGetLastError());
     }
@@ -1893,8 +1909,8 @@ void ellhip_destroy(ellhip_space* s) {
     if (s->d_work) (void)hipFree(s->d_work);
     if (s->d_hpart) (void)hipFree(s->d_hpart);
     if (s->d_stpend) (void)hipFree(s->d_stpend);
-    if (s->d_fb2) (void)hipFree(s->d_fb2);
-    if (s->d_fw) (void)hipFree(s->d_fw);
+    if (s->d_rbuf) (void)hipFree(s->d_rbuf);
+    if (s->d_wkeep) (void)hipFree(s->d_wkeep);
     if (s->d_fnext) (void)hipFree(s->d_fnext);
     if (s->d_ftiles16) (void)hipFree(s->d_ftiles16);
     if (s->d_qhpart) (void)hipFree(s->d_qhpart);
@@ -2415,6 +2431,7 @@ int ellhip_get_option(const ellhip_space* s, int key, int64_t* value) {
         case ELLHIP_OPT_RESIDENT_ABANDONED: *value = s->rs_abandoned; break;
         case ELLHIP_OPT_STABLE_SOLVE: *value = s->stable_solve; break;
         case ELLHIP_OPT_STABLE_FACTOR: *value = s->stable_factor; break;
+        case ELLHIP_OPT_STABLE_MIRRORED: *value = s->st_mirrored ? 1 : 0; break;
         case ELLHIP_OPT_PAD: *value = s->ld - s->n; break;
         default: return fail(ELLHIP_E_INVALID, "not a per-handle option");
     }

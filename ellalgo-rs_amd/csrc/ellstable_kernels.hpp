@@ -389,35 +389,19 @@ __device__ __forceinline__ void st_fwd_diag_block_pre(double* __restrict__ M, lo
     }
 }
 
-// Mirrored layout: the pending factor update on one 64 x 64 piece of a diagonal block held in registers (rows R0 + r,
-// columns C0 + 2 cp, + 1 as st_load_piece laid them out).  UPPER: the piece lies in the factor's triangle, the scaling is
-// per ROW (fb2[row], fw[row]) and applies right of the diagonal; otherwise it lies in the mirrored triangle, the scaling
-// is per COLUMN and applies below the diagonal.  Scaled elements are stored back in place; the rest is left alone.
-template <bool UPPER>
-__device__ __forceinline__ void st_scale_piece(double* __restrict__ M, long long ld, long long n, long long R0,
-                                               long long C0, double2_t (&v)[8], const double* __restrict__ fb2,
-                                               const double* __restrict__ fw, int tid) {
-    const int tr = tid >> 5, cp = tid & 31;
-    const long long c = C0 + 2 * cp;
-    double bc0 = 0.0, wc0 = 0.0, bc1 = 0.0, wc1 = 0.0;
-    if (!UPPER) {
-        if (c < n) bc0 = fb2[c], wc0 = fw[c];
-        if (c + 1 < n) bc1 = fb2[c + 1], wc1 = fw[c + 1];
-    }
+// Mirrored layout: a 64 x 64 piece of a diagonal block held in registers (rows R0 + r, column pairs as st_load_piece laid
+// them out) times the row scales r[row] -- the factor entries the eager kernels would have found in memory.  Entries on or
+// left of the diagonal get multiplied too; the chains never look at them.
+__device__ __forceinline__ void st_mul_piece_rows(long long n, long long R0, double2_t (&v)[8], const double* __restrict__ rs,
+                                                  int tid) {
+    const int tr = tid >> 5;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-        const long long r = R0 + tr + 8 * k;
-        if (r >= n || c >= n) continue;
-        double b0 = bc0, w0 = wc0, b1 = bc1, w1 = wc1;
-        if (UPPER) b0 = b1 = fb2[r], w0 = w1 = fw[r];
-        const bool in0 = UPPER ? c > r : c < r;
-        const bool in1 = (c + 1 < n) && (UPPER ? c + 1 > r : c + 1 < r);
-        if (in0) v[k].x = v[k].x + b0 * (v[k].x * w0);
-        if (in1) v[k].y = v[k].y + b1 * (v[k].y * w1);
-        double* p = M + r * ld + c;
-        if (in0 && in1) *reinterpret_cast<double2_t*>(p) = v[k];
-        else if (in0) p[0] = v[k].x;
-        else if (in1) p[1] = v[k].y;
+        long long r = R0 + tr + 8 * k;
+        if (r > n - 1) r = n - 1;
+        const double x = rs[r];
+        v[k].x = v[k].x * x;
+        v[k].y = v[k].y * x;
     }
 }
 
@@ -442,33 +426,34 @@ __device__ __forceinline__ void st_prefetch_block(const double* __restrict__ M, 
 constexpr int ST_LDS_DOUBLES = 3 * SH * BLK_PITCH;  // 96 KiB: the three parked pieces (the panel tile aliases it)
 
 // ------------------------------------------------------------------ the mirrored layout (ELLHIP_OPT_STABLE_SOLVE = 3) ---
-// The reference moves 24 n^2 bytes per update, the eager kernels above 20 n^2, and both solves are chains in which the
-// scratch triangle is pure overhead: the forward solve WRITES S[i][j] = fl(U[j][i] w[j]) (src/ell_stable.rs:66, transposed
-// through LDS: what paces its helper workgroups), the backward solve reads it back (:96), the factor update reads or
-// recomputes it a third time (:116).  Nothing else ever looks at S.  In the mirrored layout the engine's PRIVATE buffer
-// holds the factor twice -- U[j][i] above the diagonal and the same number again at [i][j] below it (L = U') -- and the
-// scratch triangle exists only when somebody observes the buffer (get_mq, clone: k_st_transpose_lower rebuilds it exactly
-// from U and the last forward solve's w):
-//   forward   reads tiles of U exactly as before, forms the products in registers, sums them, stores nothing;
-//   backward  reads the SAME addresses it used to read S from and finds L[j][t] = U[t][j] there: the product the reference
-//             parked is fl(L[j][t] w[t]) -- w[t] a per-LANE constant (the lane owns column t) -- so the solve is the old
-//             kernel with one more multiply per element, same sums in the same order: identical bits;
-//   factor    U[j][l] += beta2[j] fl(U[j][l] w[j]) (:107-121) is a per-ROW scaling of U = a per-COLUMN scaling of L, and
-//             it is not run at all: the NEXT forward solve applies it to every tile of U it loads (row constants, store in
-//             place), the next backward solve to every tile of L (lane constants, store in place).  Bit for bit the value
-//             k_st_factor_rows stores: the same two roundings on the same operands.
-// Per update: forward R 4 n^2 + W 4 n^2, backward R 4 n^2 + W 4 n^2 = 16 n^2 bytes, no transposes, no third pass, every
-// tile touched by exactly one workgroup per solve.  Which (beta2, w) pair each triangle still lacks is device state
-// (StPend, kept by k_st_mid): a failed cut applies nothing new, a halted queue touches nothing.
+// The reference moves 24 n^2 bytes per update, the eager kernels above 20 n^2, and in both solves the scratch triangle is
+// pure overhead: the forward solve WRITES S[i][j] = fl(U[j][i] w[j]) (src/ell_stable.rs:66, transposed through LDS: what
+// paces its helper workgroups), the backward solve reads it back (:96), the factor update reads or recomputes it a third
+// time (:116) and rewrites U.  Two observations remove all of that:
+//   (1) the factor update is a ROW SCALING.  U[j][l] += beta2[j] S[l][j] = beta2[j] fl(U[j][l] w[j]) (:107-121) multiplies
+//       row j of U by (1 + beta2[j] w[j]) -- the same factor for the whole row.  So the matrix need not be rewritten at all:
+//       the handle keeps U_base and one running product per row, r[j] <- r[j] (1 + beta2[j] w[j]) (k_st_post, O(n)), and
+//       every kernel that loads a tile uses fl(U_base[j][l] r[j]).  One rounding per use instead of two per update: the
+//       factor the solves see differs from the eager kernels' by ~1e-16 relative per update (not bit-identical; the states
+//       stay within the parity tolerance of the CPU path by five orders of magnitude, tests/test_gpu_ellstable_factor.py).
+//   (2) the backward solve's operand S[j][t] = fl(U[t][j] w[t]) is a COLUMN of U: with the factor stored a second time below
+//       the diagonal (L[j][t] = U[t][j], copied once when the layout is entered -- U_base never changes afterwards) the solve
+//       reads the addresses it used to read S from, with the lane's own constants r[t] and w[t]: the old kernel with two more
+//       multiplies per element, the same sums in the same order.
+// Per update: forward reads 4 n^2, backward reads 4 n^2 -- 8 n^2 bytes, nothing is written but O(n) vectors; every tile is
+// loaded by exactly one workgroup per solve.  The reference's buffer (U scaled, scratch triangle of the last forward solve)
+// is materialised when somebody observes it (k_st_mirror_leave, k_st_unscale_upper) and the layout entered again by the
+// next update; the host does the same every 256 updates so that r stays a product of few factors.
+// Which r buffer each kernel reads is device state (StPend, kept by k_st_mid): the backward solve of a successful cut still
+// needs the scales its forward solve used, while k_st_post already writes the next ones.
 struct StPend {
-    int fcur;     // buffer (0 / 1) of fb2 / fw that holds the most recent successful update's (beta2, w)
-    int u_lacks;  // the upper triangle has not received that update's scaling yet (the next forward solve applies it)
-    int l_lacks;  // ... nor has the mirrored lower triangle (the next backward solve applies it)
-    int l_apply;  // what the backward solve of the update in flight must apply first: a buffer index, or -1
-    int mirrored; // the lower triangle holds the mirrored factor (set by k_st_mirror_enter; 0: it holds the scratch triangle)
-    int have_w;   // a forward solve has run since: w_last says which of the two w buffers holds its result
-    int w_last;
-    int pad_;
+    int rsel;        // r buffer (0 / 1) the next forward solve reads (k_st_post of a successful cut writes it)
+    int r_bwd;       // r buffer the solves of the update in flight read (set by k_st_mid)
+    int r_fwd_last;  // r buffer the last forward solve that really ran read: the scratch triangle is made of it and w_keep
+    int mirrored;    // the lower triangle holds the mirrored factor (k_st_mirror_mark; 0: it holds the scratch triangle)
+    int have_w;      // a forward solve has run since the layout was entered: w_keep holds its result
+    int keep_now;    // the update in flight ran its forward solve (not a no-op of a halted queue): k_st_post keeps its w
+    int pad_[2];
 };
 
 __global__ __launch_bounds__(256) void k_st_fwd_first(double* __restrict__ M, long long ld, long long n,
@@ -749,9 +734,9 @@ constexpr long long ST_DUTY_STOP = 5;  // the chain workgroup of block s stops w
 #ifndef ST_HELPER_WRITES
 #define ST_HELPER_WRITES 3             // the helper writes every 3rd row block's products, the chain workgroup the others
 #endif
-// MIRROR: the mirrored layout (see StPend above) -- no product is stored, every tile of U this launch loads first receives
-// the pending factor update (per row: fb2[row], fw[row] of buffer pend->fcur) and is stored back in place.  Each tile is
-// loaded by exactly one workgroup here (helper s: row blocks 0 .. s - 2, chain s: row block s - 1 and the diagonal block).
+// MIRROR: the mirrored layout (see StPend above) -- nothing is stored but the vectors: every tile of U_base this launch loads
+// is multiplied by its rows' running scales r[row] (buffer pend->rsel) and used.  Each tile is loaded by exactly one
+// workgroup (helper s: row blocks 0 .. s - 2, chain s: row block s - 1 and the diagonal block).
 template <bool MIRROR = false>
 __global__ __launch_bounds__(256) void k_st_fwd_helped(double* __restrict__ M, long long ld, long long n,
                                                        const double* __restrict__ g, double* __restrict__ w,
@@ -760,18 +745,11 @@ __global__ __launch_bounds__(256) void k_st_fwd_helped(double* __restrict__ M, l
                                                        int* __restrict__ err, int epoch,
                                                        const DevState* __restrict__ st,
                                                        const StPend* __restrict__ pend = nullptr,
-                                                       const double* __restrict__ fb2_all = nullptr,
-                                                       const double* __restrict__ fw_all = nullptr) {
+                                                       const double* __restrict__ rbuf = nullptr) {
     if (st->halted) return;
-    __shared__ double pb[SB], pw[SB];  // MIRROR: the pending update's (beta2, w) on the row block being applied
-    bool scale = false;
-    const double* fb2 = nullptr;
-    const double* fw = nullptr;
-    if constexpr (MIRROR) {
-        scale = pend->u_lacks != 0;
-        fb2 = fb2_all + (long long)pend->fcur * n;
-        fw = fw_all + (long long)pend->fcur * n;
-    }
+    __shared__ double pr[SB];  // MIRROR: the running row scales on the row block being applied
+    const double* rs = nullptr;
+    if constexpr (MIRROR) rs = rbuf + (long long)pend->rsel * n;
     __shared__ __attribute__((aligned(16))) double lds[ST_LDS_DOUBLES];  // panel tiles / the parked pieces
     __shared__ double part[4][SPANEL];
     __shared__ double wstrip[SPANEL];
@@ -796,29 +774,23 @@ __global__ __launch_bounds__(256) void k_st_fwd_helped(double* __restrict__ M, l
             for (int r = 0; r < 16; ++r) u[h][r] = *reinterpret_cast<const double2_t*>(M + (r0 + r) * ld + cl);
         }
     };
-    // MIRROR: request the pending update's coefficients of row block J0 (LDS; complete at the caller's next barrier)
+    // MIRROR: request the row scales of row block J0 (LDS; complete at the caller's next barrier)
     auto load_pending = [&](long long J0) __attribute__((always_inline)) {
         if constexpr (MIRROR) {
-            if (scale && threadIdx.x < SB) {
-                pb[threadIdx.x] = fb2[J0 + threadIdx.x];
-                pw[threadIdx.x] = fw[J0 + threadIdx.x];
-            }
+            if (threadIdx.x < SB) pr[threadIdx.x] = rs[J0 + threadIdx.x];
         }
     };
-    // MIRROR: U[row][c..] <- U + fb2[row] * fl(U * fw[row]) on the rows just loaded (src/ell_stable.rs:114-117, the
-    // factor update of the PREVIOUS successful cut), stored back in place
-    auto scale_rows = [&](long long J0, double2_t (&u)[2][16]) __attribute__((always_inline)) {
+    // MIRROR: the factor entries as the eager kernels would have found them, fl(U_base[row][c] r[row]) (src/ell_stable.rs:114-117
+    // folded into one running product per row)
+    auto scale_rows = [&](double2_t (&u)[2][16]) __attribute__((always_inline)) {
         if constexpr (MIRROR) {
-            if (!scale) return;
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int rr = 32 * wv + 16 * h + r;
-                    const double bj = pb[rr], wj = pw[rr];
-                    u[h][r].x = u[h][r].x + bj * (u[h][r].x * wj);
-                    u[h][r].y = u[h][r].y + bj * (u[h][r].y * wj);
-                    if (c < n) *reinterpret_cast<double2_t*>(M + (J0 + rr) * ld + c) = u[h][r];
+                    const double x = pr[32 * wv + 16 * h + r];
+                    u[h][r].x = u[h][r].x * x;
+                    u[h][r].y = u[h][r].y * x;
                 }
             }
         }
@@ -893,7 +865,7 @@ __global__ __launch_bounds__(256) void k_st_fwd_helped(double* __restrict__ M, l
             if (threadIdx.x < SB) wblk[threadIdx.x] = st_published_load(w + kb * SB + threadIdx.x);
             __syncthreads();
             ST_STAMP(kb, 2);
-            scale_rows(kb * SB, cur);
+            scale_rows(cur);
             apply_rows(cur, std::true_type{});
             if (kb == last && threadIdx.x < SPANEL && c0 + threadIdx.x < n)
                 st_publish_store(hpart + c0 + threadIdx.x, wstrip[threadIdx.x]);  // the value is its own flag
@@ -954,12 +926,10 @@ __global__ __launch_bounds__(256) void k_st_fwd_helped(double* __restrict__ M, l
         load_rows((sblk - 1) * SB, u);
         load_pending((sblk - 1) * SB);
     }
-    if constexpr (MIRROR) {
-        if (scale) {  // the own diagonal block's factor entries (right of the diagonal) receive the pending update as well
-            st_scale_piece<true>(M, ld, n, c0, c0, blk.aa, fb2, fw, threadIdx.x);
-            st_scale_piece<true>(M, ld, n, c0, c0 + SH, blk.ab, fb2, fw, threadIdx.x);
-            st_scale_piece<true>(M, ld, n, c0 + SH, c0 + SH, blk.bb, fb2, fw, threadIdx.x);
-        }
+    if constexpr (MIRROR) {  // the own diagonal block's factor entries, scaled like every other tile
+        st_mul_piece_rows(n, c0, blk.aa, rs, threadIdx.x);
+        st_mul_piece_rows(n, c0, blk.ab, rs, threadIdx.x);
+        st_mul_piece_rows(n, c0 + SH, blk.bb, rs, threadIdx.x);
     }
     st_fwd_park(blk, dreg, lds, dlds);
     if (threadIdx.x == 0) ok = 1;
@@ -986,7 +956,7 @@ __global__ __launch_bounds__(256) void k_st_fwd_helped(double* __restrict__ M, l
             return;
         }
         ST_STAMP(sblk, 2);
-        scale_rows((sblk - 1) * SB, u);
+        scale_rows(u);
         apply_rows(u, std::true_type{});
     }
     __syncthreads();
@@ -1025,12 +995,12 @@ __global__ __launch_bounds__(ST_MID_T) void k_st_mid(long long n, const double* 
                                                      double* __restrict__ cpre, DevState* __restrict__ st,
                                                      EllCalcDev calc, const CutParams* __restrict__ cp_dev,
                                                      CutParams cp_val, int queue_mode, int* __restrict__ q_status,
-                                                     double* __restrict__ q_tsq, StPend* __restrict__ pend = nullptr,
-                                                     int w_sel = 0) {
+                                                     double* __restrict__ q_tsq, StPend* __restrict__ pend = nullptr) {
     __shared__ double red[16];
     const int tid = threadIdx.x;
     if (st->halted) {
         if (tid == 0) {
+            if (pend) pend->keep_now = 0;
             st->apply = 0;  // a tolerance stop leaves apply = 1 for the update that triggered it only
             if (q_status) {
                 *q_status = ST_UNKNOWN;
@@ -1087,17 +1057,14 @@ __global__ __launch_bounds__(ST_MID_T) void k_st_mid(long long n, const double* 
         }
         cpre[ST_MID_T] = t0;
         if (pend) {
-            // mirrored layout: the forward solve of this update has just applied whatever the upper triangle lacked.  A
-            // successful cut produces a new factor update (k_st_post fills buffer fcur ^ 1): both triangles lack it from now
-            // on, and the backward solve of THIS update first applies the one the lower triangle still lacked.
-            pend->u_lacks = 0;
+            // mirrored layout: the forward solve of this update read the r buffer `rsel`; its backward solve (a successful cut
+            // only) must read the same one, while k_st_post writes the scales the NEXT update sees into the other buffer
             pend->have_w = 1;
-            pend->w_last = w_sel;
+            pend->keep_now = 1;
+            pend->r_fwd_last = pend->rsel;
             if (status == ST_SUCCESS) {
-                pend->l_apply = pend->l_lacks ? pend->fcur : -1;
-                pend->fcur ^= 1;
-                pend->u_lacks = 1;
-                pend->l_lacks = 1;
+                pend->r_bwd = pend->rsel;
+                pend->rsel ^= 1;
             }
         }
     }
@@ -1118,9 +1085,8 @@ __global__ __launch_bounds__(256) void k_st_post(double* __restrict__ M, long lo
                                                  double* __restrict__ hpart_rearm = nullptr,
                                                  int* __restrict__ fnext_reset = nullptr,
                                                  double* __restrict__ qhpart_rearm = nullptr,
-                                                 const StPend* __restrict__ pend = nullptr,
-                                                 double* __restrict__ fb2_all = nullptr, double* __restrict__ fw_all = nullptr,
-                                                 const double* __restrict__ w_cur = nullptr) {
+                                                 const StPend* __restrict__ pend = nullptr, double* __restrict__ rbuf = nullptr,
+                                                 const double* __restrict__ w_cur = nullptr, double* __restrict__ w_keep = nullptr) {
     const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n) return;
     if (qhpart_rearm) qhpart_rearm[j] = st_sentinel();  // the backward helpers' hand-over buffer (k_st_bwd_factor_helped)
@@ -1129,6 +1095,10 @@ __global__ __launch_bounds__(256) void k_st_post(double* __restrict__ M, long lo
     // the publish buffer of the NEXT persistent forward solve: armed whatever happened to this update (a failed cut and
     // a halted loop still alternate the buffers, see ellstable_issue)
     if (w_rearm) w_rearm[j] = st_sentinel();
+    // mirrored layout: the w of the forward solve that has just run (successful cut or not) is what the scratch triangle
+    // would hold products of, should somebody ask for it (the solves' own two w buffers are re-armed in turn by every later
+    // update, also by the no-op updates of a halted queue)
+    if (pend && pend->keep_now) w_keep[j] = w_cur[j];
     if (!st->apply) return;  // failed cut / halted loop: nothing below runs, and neither does the backward solve
     if (qpub_rearm) qpub_rearm[j] = st_sentinel();
     const long long m = (n + ST_MID_T - 1) / ST_MID_T;
@@ -1141,10 +1111,8 @@ __global__ __launch_bounds__(256) void k_st_post(double* __restrict__ M, long lo
     beta2[j] = b2;
     M[j * ld + j] = M[j * ld + j] * (told / tnew);  // :113 / :121
     q[j] = zj;                              // :93
-    if (pend) {  // mirrored layout: this update's factor update, kept for the solves that will apply it (k_st_mid chose fcur)
-        fb2_all[(long long)pend->fcur * n + j] = b2;
-        fw_all[(long long)pend->fcur * n + j] = w_cur[j];
-    }
+    if (pend)  // mirrored layout: the factor update U[j][l] += beta2[j] fl(U[j][l] w[j]), l > j (:114-117) as row j's running scale
+        rbuf[(long long)pend->rsel * n + j] = rbuf[(long long)pend->r_bwd * n + j] * (1.0 + b2 * w_cur[j]);
 }
 
 // ------------------------------------------------------------------------------ backward ------
@@ -1479,7 +1447,8 @@ __global__ __launch_bounds__(256) void k_st_xc(long long n, const double* __rest
         xc[i] = xc[i] - roo * q[i];
 }
 
-// Mirrored layout: a piece of L turned into the products the reference parked, S[j][t] = fl(L[j][t] w[t]) (per column).
+// Mirrored layout: a piece of L times a vector of per-COLUMN constants (the row scales r[t], then w[t]: together the products
+// the reference parked, S[j][t] = fl(fl(L[j][t] r[t]) w[t])).
 __device__ __forceinline__ void st_mul_piece_cols(long long n, long long C0, double2_t (&v)[8], const double* __restrict__ w,
                                                   int tid) {
     const long long c = C0 + 2 * (tid & 31);
@@ -1491,11 +1460,11 @@ __device__ __forceinline__ void st_mul_piece_cols(long long n, long long C0, dou
     }
 }
 
-// Between the two layouts: lower[i][j] = fl(U[j][i] * w[j]) for i > j (w != NULL: the scratch triangle exactly as the
-// forward solve with that w stored it, src/ell_stable.rs:66) or = U[j][i] (w == NULL: the mirrored copy of the factor).
-// 64 x 64 tiles transposed through LDS; grid (tiles, tiles), tiles left of the diagonal leave at once.
+// Between the two layouts: lower[i][j] = fl(fl(U[j][i] r[j]) w[j]) for i > j (r, w != NULL: the scratch triangle exactly as a
+// forward solve on the scaled factor with that w stores it, src/ell_stable.rs:66) or = U[j][i] (r = w = NULL: the mirrored
+// copy of the factor).  64 x 64 tiles transposed through LDS; grid (tiles, tiles), tiles left of the diagonal leave at once.
 __device__ __forceinline__ void st_transpose_lower_tile(double* __restrict__ M, long long ld, long long n,
-                                                        const double* __restrict__ w) {
+                                                        const double* __restrict__ r, const double* __restrict__ w) {
     const long long tj = blockIdx.y, ti = blockIdx.x;  // source tile rows j (tj), columns i (ti); destination rows i, columns j
     if (ti < tj) return;
     __shared__ double tile[64][65];
@@ -1507,6 +1476,7 @@ __device__ __forceinline__ void st_transpose_lower_tile(double* __restrict__ M, 
         double v = 0.0;
         if (j < n && i < n && i > j) {
             v = M[j * ld + i];
+            if (r) v = v * r[j];
             if (w) v = v * w[j];
         }
         tile[ty + 4 * k][tx] = v;
@@ -1518,31 +1488,43 @@ __device__ __forceinline__ void st_transpose_lower_tile(double* __restrict__ M, 
         if (i < n && j < n && i > j) M[i * ld + j] = tile[tx][ty + 4 * k];
     }
 }
-// reference layout -> mirrored layout.  Not on a halted queue (every solve behind it is a no-op as well, and the scratch
-// triangle of the failing cut has to survive until its results are read); whether it ran is device state (pend->mirrored,
-// set by k_st_mirror_mark behind it).
+// reference layout -> mirrored layout: the factor copied below the diagonal, every row scale 1.  Not on a halted queue (every
+// solve behind it is a no-op as well, and the scratch triangle of the failing cut has to survive until its results are
+// read); whether it ran is device state (pend->mirrored, set by k_st_mirror_mark behind it).
 __global__ __launch_bounds__(256) void k_st_mirror_enter(double* __restrict__ M, long long ld, long long n,
-                                                         const DevState* __restrict__ st) {
+                                                         const DevState* __restrict__ st, double* __restrict__ rbuf) {
     if (st->halted) return;
-    st_transpose_lower_tile(M, ld, n, nullptr);
+    if (blockIdx.x == blockIdx.y && threadIdx.x < 64) {
+        const long long j = (long long)blockIdx.y * 64 + threadIdx.x;
+        if (j < n) rbuf[j] = 1.0, rbuf[n + j] = 1.0;
+    }
+    st_transpose_lower_tile(M, ld, n, nullptr, nullptr);
 }
 __global__ void k_st_mirror_mark(StPend* __restrict__ pend, const DevState* __restrict__ st) {
     StPend p;
-    p.fcur = 0, p.u_lacks = 0, p.l_lacks = 0, p.l_apply = -1, p.mirrored = st->halted ? 0 : 1, p.have_w = 0, p.w_last = 0, p.pad_ = 0;
+    p.rsel = 0, p.r_bwd = 0, p.r_fwd_last = 0, p.mirrored = st->halted ? 0 : 1, p.have_w = 0, p.keep_now = 0, p.pad_[0] = p.pad_[1] = 0;
     *pend = p;
 }
-// mirrored layout -> reference layout, for an observer of the buffer: the scratch triangle of the last forward solve from U
-// as that solve saw it (U in memory: the solve stored what it scaled) and its w; the pending factor update on U follows
-// (k_st_factor_rows_pend), then k_st_mirror_clear.
+// mirrored layout -> reference layout, for an observer of the buffer: first the scratch triangle of the last forward solve
+// (from U_base, the scales that solve used and its w), then U itself as the eager kernels would hold it, fl(U_base[j][l] r[j])
+// with the current scales (k_st_unscale_upper), then k_st_mirror_clear.
 __global__ __launch_bounds__(256) void k_st_mirror_leave(double* __restrict__ M, long long ld, long long n,
-                                                         const StPend* __restrict__ pend, const double* __restrict__ w0,
-                                                         const double* __restrict__ w1) {
+                                                         const StPend* __restrict__ pend, const double* __restrict__ rbuf,
+                                                         const double* __restrict__ w_keep) {
     if (!pend->mirrored || !pend->have_w) return;
-    st_transpose_lower_tile(M, ld, n, pend->w_last ? w1 : w0);
+    st_transpose_lower_tile(M, ld, n, rbuf + (long long)pend->r_fwd_last * n, w_keep);
+}
+__global__ __launch_bounds__(256) void k_st_unscale_upper(double* __restrict__ M, long long ld, long long n,
+                                                          const StPend* __restrict__ pend, const double* __restrict__ rbuf) {
+    if (!pend->mirrored) return;
+    const long long j = blockIdx.y;
+    const double x = rbuf[(long long)pend->rsel * n + j];
+    for (long long l = j + 1 + (long long)blockIdx.x * 256 + threadIdx.x; l < n; l += (long long)gridDim.x * 256)
+        M[j * ld + l] = M[j * ld + l] * x;
 }
 __global__ void k_st_mirror_clear(StPend* __restrict__ pend) {
     StPend p;
-    p.fcur = 0, p.u_lacks = 0, p.l_lacks = 0, p.l_apply = -1, p.mirrored = 0, p.have_w = 0, p.w_last = 0, p.pad_ = 0;
+    p.rsel = 0, p.r_bwd = 0, p.r_fwd_last = 0, p.mirrored = 0, p.have_w = 0, p.keep_now = 0, p.pad_[0] = p.pad_[1] = 0;
     *pend = p;
 }
 
@@ -1722,17 +1704,6 @@ __global__ __launch_bounds__(256) void k_st_factor_rows(double* __restrict__ M, 
     st_factor_tile<SEG, RW>(M, ld, n, beta2, w, (long long)blockIdx.x, (long long)blockIdx.y);
 }
 
-// The factor update the upper triangle of a mirrored buffer still lacks (leaving the mirrored layout)
-template <int SEG, int RW>
-__global__ __launch_bounds__(256) void k_st_factor_rows_pend(double* __restrict__ M, long long ld, long long n,
-                                                             const StPend* __restrict__ pend,
-                                                             const double* __restrict__ fb2_all,
-                                                             const double* __restrict__ fw_all) {
-    if (!pend->mirrored || !pend->u_lacks) return;
-    st_factor_tile<SEG, RW>(M, ld, n, fb2_all + (long long)pend->fcur * n, fw_all + (long long)pend->fcur * n,
-                            (long long)blockIdx.x, (long long)blockIdx.y);
-}
-
 // The same launch with a HELPER workgroup per block (as in k_st_fwd_helped) and no dedicated factor workers: 2 * nblk
 // workgroups, one per CU.  helper s: the strip's partial sums over the row blocks nblk-1 .. s+2, handed to chain s
 // (qhpart, all-sentinel at launch); chain s: own block parked, columns and the rows of row block s+1 in registers before
@@ -1743,11 +1714,10 @@ __global__ __launch_bounds__(256) void k_st_factor_rows_pend(double* __restrict_
 // of waiting, and the chain itself has nothing in front of it when its turn comes.
 constexpr int FQ_H = 16;
 constexpr long long FQ_STOP = 6;
-// MIRROR (the mirrored layout, see StPend): the addresses the scratch triangle used to occupy hold L[j][t] = U[t][j]; every
-// element loaded first receives the pending factor update of the update BEFORE this one (per column: the lane's constants
-// fb2[t], fw[t] of buffer pend->l_apply) and is stored back in place, then becomes the product the reference parked,
-// fl(L[j][t] w[t]) with this update's w (src/ell_stable.rs:66), and enters the same sums in the same order.  No factor
-// tiles: this update's factor update is applied by the NEXT forward / backward solve.
+// MIRROR (the mirrored layout, see StPend): the addresses the scratch triangle used to occupy hold L[j][t] = U_base[t][j]; every
+// element loaded becomes the product the reference parked there, fl(fl(L[j][t] r[t]) w[t]) -- the lane's own constants: the
+// running scale of row t of the factor (the buffer this update's forward solve read, pend->r_bwd) and this update's w
+// (src/ell_stable.rs:66) -- and enters the same sums in the same order.  Nothing is stored, there are no factor tiles.
 template <int SEG, int RW, bool MIRROR = false>
 __global__ __launch_bounds__(256) void k_st_bwd_factor_helped(double* __restrict__ M, long long ld, long long n,
                                                               double* __restrict__ q, double* __restrict__ qpub,
@@ -1758,8 +1728,7 @@ __global__ __launch_bounds__(256) void k_st_bwd_factor_helped(double* __restrict
                                                               const int* __restrict__ ftiles, int nftiles,
                                                               int* __restrict__ fnext, long long fq_stop,
                                                               const StPend* __restrict__ pend = nullptr,
-                                                              const double* __restrict__ fb2_all = nullptr,
-                                                              const double* __restrict__ fw_all = nullptr) {
+                                                              const double* __restrict__ rbuf = nullptr) {
     if (!st->apply) return;
     __shared__ double lds[ST_LDS_DOUBLES_B];
     __shared__ double part[4][SPANEL];
@@ -1773,25 +1742,13 @@ __global__ __launch_bounds__(256) void k_st_bwd_factor_helped(double* __restrict
     const long long c0 = sblk * SB;
     const long long c = c0 + 2 * lane;  // columns c, c+1 < c0 + 128 <= J0 of every row block applied here
     const bool has_b = c0 + SH < n;
-    // MIRROR: this lane's two columns t = c, c + 1: w[t] of the update in flight, and the pending update's (beta2, w)[t]
-    double wc0 = 0.0, wc1 = 0.0, bp0 = 0.0, bp1 = 0.0, wp0 = 0.0, wp1 = 0.0;
-    bool scale = false;
-    const double* fb2 = nullptr;
-    const double* fw = nullptr;
+    // MIRROR: this lane's two columns t = c, c + 1: the running scale r[t] and w[t] of the update in flight
+    double wc0 = 0.0, wc1 = 0.0, rc0 = 0.0, rc1 = 0.0;
+    const double* rb = nullptr;
     if constexpr (MIRROR) {
-        scale = pend->l_apply >= 0;
-        if (scale) {
-            fb2 = fb2_all + (long long)pend->l_apply * n;
-            fw = fw_all + (long long)pend->l_apply * n;
-        }
-        if (c < n) {
-            wc0 = w[c];
-            if (scale) bp0 = fb2[c], wp0 = fw[c];
-        }
-        if (c + 1 < n) {
-            wc1 = w[c + 1];
-            if (scale) bp1 = fb2[c + 1], wp1 = fw[c + 1];
-        }
+        rb = rbuf + (long long)pend->r_bwd * n;
+        if (c < n) wc0 = w[c], rc0 = rb[c];
+        if (c + 1 < n) wc1 = w[c + 1], rc1 = rb[c + 1];
     }
 
     // factor tiles until the queue is empty or (deadline >= 0) block `deadline` has been solved
@@ -1826,21 +1783,15 @@ __global__ __launch_bounds__(256) void k_st_bwd_factor_helped(double* __restrict
             }
         }
     };
-    // MIRROR: the rows just loaded hold L[j][t]; pending update (stored back in place), then the parked product fl(L w[t])
-    auto mirror_rows = [&](long long J0, double2_t (&sv)[2][16]) __attribute__((always_inline)) {
+    // MIRROR: the rows just loaded hold L[j][t] = U_base[t][j]: the parked product fl(fl(L r[t]) w[t])
+    auto mirror_rows = [&](double2_t (&sv)[2][16]) __attribute__((always_inline)) {
         if constexpr (MIRROR) {
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const long long row = J0 + 32 * wv + 16 * h + r;
-                    if (scale) {
-                        sv[h][r].x = sv[h][r].x + bp0 * (sv[h][r].x * wp0);
-                        sv[h][r].y = sv[h][r].y + bp1 * (sv[h][r].y * wp1);
-                        if (row < n && c < n) *reinterpret_cast<double2_t*>(M + row * ld + c) = sv[h][r];
-                    }
-                    sv[h][r].x = sv[h][r].x * wc0;
-                    sv[h][r].y = sv[h][r].y * wc1;
+                    sv[h][r].x = (sv[h][r].x * rc0) * wc0;
+                    sv[h][r].y = (sv[h][r].y * rc1) * wc1;
                 }
             }
         }
@@ -1896,7 +1847,7 @@ __global__ __launch_bounds__(256) void k_st_bwd_factor_helped(double* __restrict
                 if (threadIdx.x == 0) atomicExch(err, 2);
                 return;
             }
-            mirror_rows(kb * SB, sv);
+            mirror_rows(sv);
             apply_rows(sv);
         }
         if (sblk + 2 <= nblk - 1 && threadIdx.x < SPANEL && c0 + threadIdx.x < n)
@@ -1912,12 +1863,10 @@ __global__ __launch_bounds__(256) void k_st_bwd_factor_helped(double* __restrict
     double2_t sv[2][16];
     st_prefetch_block_bwd(M, ld, n, c0, blk);
     if (sblk + 1 <= nblk - 1) load_rows((sblk + 1) * SB, sv);
-    if constexpr (MIRROR) {  // the own diagonal block: pending update below the diagonal (in place), then the parked products
-        if (scale) {
-            st_scale_piece<false>(M, ld, n, c0 + SH, c0 + SH, blk.bb, fb2, fw, threadIdx.x);
-            st_scale_piece<false>(M, ld, n, c0 + SH, c0, blk.ba, fb2, fw, threadIdx.x);
-            st_scale_piece<false>(M, ld, n, c0, c0, blk.aa, fb2, fw, threadIdx.x);
-        }
+    if constexpr (MIRROR) {  // the own diagonal block: scaled, then the parked products
+        st_mul_piece_cols(n, c0 + SH, blk.bb, rb, threadIdx.x);
+        st_mul_piece_cols(n, c0, blk.ba, rb, threadIdx.x);
+        st_mul_piece_cols(n, c0, blk.aa, rb, threadIdx.x);
         st_mul_piece_cols(n, c0 + SH, blk.bb, w, threadIdx.x);
         st_mul_piece_cols(n, c0, blk.ba, w, threadIdx.x);
         st_mul_piece_cols(n, c0, blk.aa, w, threadIdx.x);
@@ -1937,7 +1886,7 @@ __global__ __launch_bounds__(256) void k_st_bwd_factor_helped(double* __restrict
             if (threadIdx.x == 0) atomicExch(err, 2);
             return;
         }
-        mirror_rows((sblk + 1) * SB, sv);
+        mirror_rows(sv);
         apply_rows(sv);
     }
     __syncthreads();

@@ -294,6 +294,7 @@ int ellhip_set_shard_symmetric(ellhip_space *s, int flag);
 #define ELLHIP_OPT_QUEUE_DEPTH 16
 #define ELLHIP_OPT_RESIDENT_FAULT 17
 #define ELLHIP_OPT_RESIDENT_ABANDONED 18
+#define ELLHIP_OPT_STABLE_MIRRORED 19   /* read only, EllStable: 1 while the handle's buffer is in the mirrored layout */
 int ellhip_set_option(ellhip_space *s, int key, int64_t value);
 int ellhip_get_option(const ellhip_space *s, int key, int64_t *value);
 int ellhip_set_default_option(int key, int64_t value);

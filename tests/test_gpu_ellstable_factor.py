@@ -80,6 +80,7 @@ def test_persistent_equals_per_block_launches_on_random_factor(gpu, n):
     """The flag-chained single-launch solves against one launch per block (no inter-workgroup hand-off): same
     arithmetic in the same order, so the same bits -- now on data where an indexing slip would show."""
     f = random_factor(n, 77 + n)
+    set_default("STABLE_SOLVE", 2)
     a = gpu.EllStable.new_with_matrix(1.0, f, np.zeros(n))
     set_default("STABLE_SOLVE", 0)
     b = gpu.EllStable.new_with_matrix(1.0, f, np.zeros(n))
@@ -97,21 +98,32 @@ def test_persistent_equals_per_block_launches_on_random_factor(gpu, n):
     assert _offdiag_nonzeros(a.mq) > 0
 
 
+def _same_to_rounding(x, ref, tol=1e-12, what=""):
+    """The mirrored layout against an eager form: every part of the state on its own scale, far inside the parity tolerance."""
+    mx, mr = x.mq, ref.mq
+    assert rel_inf(np.triu(mx, 1), np.triu(mr, 1)) <= tol, f"{what}: factor"
+    assert rel_inf(np.tril(mx, -1), np.tril(mr, -1)) <= tol, f"{what}: scratch triangle"
+    assert rel_inf(np.diag(mx), np.diag(mr)) <= tol, f"{what}: diagonal"
+    assert rel_inf(x.xc(), ref.xc()) <= tol and abs(x.kappa - ref.kappa) <= tol * abs(ref.kappa), f"{what}: xc / kappa"
+    assert abs(x.tsq() - ref.tsq()) <= tol * abs(ref.tsq()), f"{what}: tsq"
+
+
 @pytest.mark.parametrize("n", [2, 63, 64, 65, 129, 300, 513, 1000, 2048, 2048 + 128, 2049, 8192, 8200, 8191])
 def test_default_solves_and_factor_update_equal_the_plain_kernels(gpu, n):
-    """Every EllStable kernel form must give the bits of the plain path (one launch per block, factor update reading the
-    scratch triangle through LDS transposes): both solves with a helper workgroup per block
-    (k_st_fwd_helped, k_st_bwd_factor_helped) and the factor update computed from U alone inside the backward solve's
-    launch (the scratch entry it would read IS fl(U * w)) --, the persistent solves without helpers with the row-wise
-    factor kernel beside them (k_st_fwd_persist, k_st_bwd_persist, k_st_factor_rows), the MIRRORED layout (STABLE_SOLVE = 3:
-    no scratch triangle inside the loop, the factor update applied by the next forward / backward solve to the tiles they
-    load; the reference's buffer rebuilt when it is observed), and the forms switched on an
-    existing handle with ellhip_set_option.  Odd and even n, ragged last blocks, one block, failing cuts in the middle;
-    8191 / 8192 / 8200 straddle the size where the factor tiles switch from 512- to 2048-column segments and the chain
-    workgroups stop pulling tiles before their turn."""
+    """Every EAGER EllStable kernel form must give the bits of the plain path (one launch per block, factor update reading the
+    scratch triangle through LDS transposes): both solves with a helper workgroup per block (k_st_fwd_helped,
+    k_st_bwd_factor_helped) and the factor update computed from U alone inside the backward solve's launch (the scratch entry
+    it would read IS fl(U * w)), the persistent solves without helpers with the row-wise factor kernel beside them
+    (k_st_fwd_persist, k_st_bwd_persist, k_st_factor_rows), and the forms switched on an existing handle with
+    ellhip_set_option.  The MIRRORED layout (STABLE_SOLVE = 3, the default: no scratch triangle inside the loop, the factor
+    update kept as one running scale per row) rounds once per use where the eager forms round twice per update: it must agree
+    with them to 1e-12 on every part of the state, also when it is entered and left between cuts, observed right after a
+    failing cut, or mixed with the eager forms on one handle.  Odd and even n, ragged last blocks, one block, failing cuts in
+    the middle; 8191 / 8192 / 8200 straddle the size where the factor tiles switch from 512- to 2048-column segments and the
+    chain workgroups stop pulling tiles before their turn."""
     capi = gpu.capi
     f = random_factor(n, 271 + n)
-    a = gpu.EllStable.new_with_matrix(1.0, f, np.zeros(n))
+    a = gpu.EllStable.new_with_matrix(1.0, f, np.zeros(n))     # the default: the mirrored layout throughout, never observed
     assert a.get_option(capi.OPT_STABLE_SOLVE) == DEFAULT_SOLVE and a.get_option(capi.OPT_STABLE_FACTOR) == 2
     set_default("STABLE_SOLVE", 0)
     set_default("STABLE_FACTOR", 0)
@@ -122,28 +134,34 @@ def test_default_solves_and_factor_update_equal_the_plain_kernels(gpu, n):
     c = gpu.EllStable.new_with_matrix(1.0, f, np.zeros(n))
     set_default("STABLE_SOLVE", 2)
     set_default("STABLE_FACTOR", 2)
-    d = gpu.EllStable.new_with_matrix(1.0, f, np.zeros(n))   # walks through the forms, one per cut
+    d = gpu.EllStable.new_with_matrix(1.0, f, np.zeros(n))   # walks through the eager forms, one per cut
     e2 = gpu.EllStable.new_with_matrix(1.0, f, np.zeros(n))  # helped solves + pulled factor tiles throughout
     set_default("STABLE_SOLVE", 3)
-    e3 = gpu.EllStable.new_with_matrix(1.0, f, np.zeros(n))  # the mirrored layout throughout (observed once, in the middle)
-    forms = [(0, 0), (1, 0), (3, 1), (3, 1), (3, 2), (3, 0), (2, 1), (2, 2), (3, 2), (0, 1), (3, 0), (3, 0), (1, 2), (3, 1)]
-    fails = (5, 10)          # (both inside a stretch of the mirrored layout: the scratch triangle of a failed cut is lazy too)
+    e3 = gpu.EllStable.new_with_matrix(1.0, f, np.zeros(n))  # the mirrored layout, observed in the middle
+    d3 = gpu.EllStable.new_with_matrix(1.0, f, np.zeros(n))  # walks through all forms, the mirrored layout among them
+    forms = [(0, 0), (1, 0), (1, 1), (2, 1), (2, 2), (0, 1), (2, 0), (1, 2), (2, 2), (0, 0), (1, 1), (2, 0), (1, 2), (2, 1)]
+    forms3 = [(0, 0), (1, 0), (3, 1), (3, 1), (3, 2), (3, 0), (2, 1), (2, 2), (3, 2), (0, 1), (3, 0), (3, 0), (1, 2), (3, 1)]
+    fails = (5, 10)          # (in forms3 both inside a stretch of the mirrored layout: a failed cut's scratch triangle is lazy too)
     rng = np.random.default_rng(13 * n)
     for i in range(len(forms)):
         gr = rng.standard_normal(n)
         gr /= np.linalg.norm(gr)
         beta = 5.0 if i in fails else 0.05 * rng.random()
-        d.set_option(capi.OPT_STABLE_SOLVE, forms[i][0])
-        d.set_option(capi.OPT_STABLE_FACTOR, forms[i][1])
-        stats = [int(x.update_bias_cut((gr, beta))) for x in (a, b, c, d, e2, e3)]
-        assert stats == [1 if i in fails else 0] * 6, (i, stats)
-        assert a.tsq() == b.tsq() == c.tsq() == d.tsq() == e2.tsq() == e3.tsq()
-        assert a.kappa == b.kappa == c.kappa == d.kappa == e2.kappa == e3.kappa
+        for h, fm in ((d, forms[i]), (d3, forms3[i])):
+            h.set_option(capi.OPT_STABLE_SOLVE, fm[0])
+            h.set_option(capi.OPT_STABLE_FACTOR, fm[1])
+        stats = [int(x.update_bias_cut((gr, beta))) for x in (a, b, c, d, e2, e3, d3)]
+        assert stats == [1 if i in fails else 0] * 7, (i, stats)
+        assert b.tsq() == c.tsq() == d.tsq() == e2.tsq() and b.kappa == c.kappa == d.kappa == e2.kappa
+        for x in (a, e3, d3):
+            assert abs(x.tsq() - b.tsq()) <= 1e-12 * abs(b.tsq()) and abs(x.kappa - b.kappa) <= 1e-12 * abs(b.kappa)
         if i in (3, 5, 8):   # the mirrored handle observed after a success, right after a failing cut, and again
-            assert np.array_equal(e3.mq, b.mq), f"mirrored layout, buffer after cut {i}"
+            _same_to_rounding(e3, b, what=f"mirrored layout, buffer after cut {i}")
     qb = b.mq
-    for x in (a, c, d, e2, e3):
+    for x in (c, d, e2):
         assert np.array_equal(x.xc(), b.xc()) and np.array_equal(x.mq, qb)
+    for name, x in (("default", a), ("observed", e3), ("mixed forms", d3)):
+        _same_to_rounding(x, b, what=f"mirrored layout ({name}) at the end")
     with pytest.raises(capi.EllHipError):
         gpu.Ell.new_with_scalar(1.0, np.zeros(8)).set_option(capi.OPT_STABLE_SOLVE, 1)   # an EllStable option
     with pytest.raises(capi.EllHipError):

@@ -281,6 +281,7 @@ def test_ellstable_n32768_persistent_equals_per_block_launches(gpu):
     n, k = 32768, 3
     kinds, grads, b0, _ = synth.deep_cuts(n, k)
     f = synth.stable_factor(n)
+    set_default("STABLE_SOLVE", 2)
     a = gpu.EllStable.new_with_matrix(1.0, f, np.zeros(n))
     set_default("STABLE_SOLVE", 0)
     b = gpu.EllStable.new_with_matrix(1.0, f, np.zeros(n))
