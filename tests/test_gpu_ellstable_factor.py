@@ -208,9 +208,16 @@ def test_clone_and_queue_on_random_factor(gpu, orc, solve):
     for i in range(k):
         assert o.update(0, grads[i], b0[i]) == 0
         assert abs(ts[i] - o.tsq) <= TOL * abs(o.tsq)
-    assert np.array_equal(a.mq, b.mq) and np.array_equal(b.mq, c.mq)
-    assert np.array_equal(a.xc(), b.xc()) and a.kappa == b.kappa == c.kappa
+    if solve == 3:
+        # taking the clone observed b's buffer (the mirrored layout was left and entered again: U = fl(U_base r) rounds once
+        # more), so the three histories agree to rounding, not to the bit
+        _same_to_rounding(b, a, what="direct + clone vs queue")
+        _same_to_rounding(c, a, what="clone vs queue")
+    else:
+        assert np.array_equal(a.mq, b.mq) and np.array_equal(b.mq, c.mq)
+        assert np.array_equal(a.xc(), b.xc()) and a.kappa == b.kappa == c.kappa
     assert_state_close(a, o, what="queue vs oracle")
+    assert_state_close(c, o, what="clone vs oracle")
 
 
 def test_synth_stable_factor_long_run(gpu, orc):
