@@ -761,6 +761,9 @@ def main() -> None:
                  and os.environ.get("ELLHIP_SHARD_SYMMETRIC", sym_default) != "0")
     if shard_sym:
         C2 = 0
+    # symmetric shards: a second timed region on the schedule BASELINE config 4 names -- one all-reduce of Q g per ITERATION
+    # (the headline region takes the queue in groups: one all-reduce per group of up to 16 queued cuts, replay only)
+    C3 = 48 if shard_sym else 0
     # alternatives measured after the main run, on the same handle: (schedule, depth)
     alts = []
     if C2 > 0:
@@ -775,7 +778,7 @@ def main() -> None:
             alts.insert(0, ("pipelined, lookahead 1", depth))
     # (a second profiled region, kernels one at a time, where the default run overlaps them: see prof_iso below)
     P_iso = P if (variant == "ell" and not sharded and args.schedule == "pipelined" and n % 64 == 0 and n >= symv_min_n and lower_ok) else 0
-    total = W + K + P + P_iso + 2 * C2 * len(alts) + H
+    total = W + K + P + P_iso + 2 * C2 * len(alts) + C3 + H
     if sharded and n % world and not shard_sym:
         raise SystemExit(f"n={n} is not divisible by {world} ranks")
 
@@ -837,7 +840,7 @@ def main() -> None:
             space = ShardedEll.new_with_scalar(1.0, np.zeros(n), device=local_rank, symmetric=shard_sym,
                                               defer_depth=depth if shard_sym else 8)
             sharded_via = "torch.distributed"
-    nq = W + K + P + P_iso + 2 * C2 * len(alts)
+    nq = W + K + P + P_iso + 2 * C2 * len(alts) + C3
     if variant == "ell" and not shard_sym:   # always explicit: a new unsharded handle may start at depth 16 by itself
         space.set_defer_depth(depth) if sharded else setattr(space, "defer_depth", depth)
     space.queue_upload(kinds[:nq], grads[:nq], b0[:nq], b1[:nq])
@@ -926,8 +929,28 @@ def main() -> None:
             space.set_option(pkg.capi.OPT_LOOKAHEAD, look_was)
         pos += 2 * C2
 
+    per_iter = None
+    if C3 > 0 and hasattr(space, "set_local_option"):
+        look_was = space.get_local_option(pkg.capi.OPT_LOOKAHEAD)
+        space.set_local_option(pkg.capi.OPT_LOOKAHEAD, 1)
+        space.flush()
+        fence()
+        t2 = time.perf_counter()
+        run(pos, C3, True)
+        space.flush()
+        fence()
+        el3 = time.perf_counter() - t2
+        t = torch.tensor([el3], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el3 = float(t.item())
+        space.set_local_option(pkg.capi.OPT_LOOKAHEAD, look_was)
+        per_iter = {"steps": C3, "updates_per_s": C3 / el3, "ms_per_step": el3 / C3 * 1e3, "collectives_per_update": 1.0,
+                    "schedule": "pipelined, one all-reduce(Q g) of n doubles per update (ELLHIP_OPT_LOOKAHEAD = 1 on the shard handle): "
+                                "the form BASELINE config 4 names; what a live cutting-plane loop over a sharded space can reach"}
+        pos += C3
+
     status, tsqs = space.queue_results()
-    ran = nq
+    ran = nq if per_iter or C3 == 0 else nq - C3
     ok = bool(np.all(status[:ran] == 0))
     if not ok:
         bad = int(np.argmax(status[:ran] != 0))
@@ -1133,6 +1156,16 @@ def main() -> None:
                    **({"collective_issued_by": sharded_via} if sharded else {})},
         "roofline": roofline,
     }
+    if sharded and variant == "ell":
+        grp = shard_sym and lookahead > 3
+        cpu_ = (gemv_passes(K, eff_depth("pipelined", depth), lookahead) / K) if grp else 1.0
+        out["config"]["collectives_per_update"] = cpu_
+        out["config"]["collective_payload_doubles"] = (n * min(lookahead, 16)) if grp else (n if shard_sym else n // world)
+        if per_iter:
+            out["per_iteration_collective"] = per_iter
+            out["config"]["per_iteration_collective_updates_per_s"] = per_iter["updates_per_s"]
+        elif not grp:
+            out["config"]["per_iteration_collective_updates_per_s"] = value   # (the headline schedule already is that form)
     if others:
         out["other_schedules"] = others
     if host_path:

@@ -968,22 +968,33 @@ __global__ __launch_bounds__(256) void k_apply_mfma(double* __restrict__ Q, long
     }
     __syncthreads();
     double* rbase = Q + (lr0 + 16 * wave + (lane >> 4)) * ld + 2 * (lane & 15);  // this lane's pair of row (lane >> 4) of the wave
-    for (long long cb = c_begin; cb < c_stop; cb += APM_ROWS) {
-        const bool more = cb + APM_ROWS < c_stop;
-        double2_t vn[SPT];
-        if (more) fetch(vn, cb + APM_ROWS);
+    // The wave's 16 x 64 block of Q for one step: two tiles (h) x four row groups (i), 16 bytes each.  The block of step
+    // s + 1 is REQUESTED before the MFMA chain of step s starts (round 3 loaded, multiplied and stored one tile after the
+    // other: the pass ran at the SUM of its HBM time and its matrix-pipe time -- 0.60 ms at rank 48, n = 16384, where the
+    // two are 0.39 and 0.16 ms; with the loads in flight behind 2 x 2 KS MFMAs they overlap).
+    auto loadq = [&](double2_t (&x)[2][4], long long cb) __attribute__((always_inline)) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const long long c = cb + 32 * h + 2 * (lane & 15);
-            double2_t x[4];
-            bool on[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const long long grow = gr0 + 16 * wave + (lane >> 4) + 4 * i;
-                on[i] = grow <= glast && c < c_stop;
-                x[i] = on[i] ? ld_stream<NT, double2_t>(rbase + (long long)(4 * i) * ld + cb + 32 * h) : double2_t{0.0, 0.0};
+                const bool on = grow <= glast && c < c_stop;
+                x[h][i] = on ? ld_stream<NT, double2_t>(rbase + (long long)(4 * i) * ld + cb + 32 * h) : double2_t{0.0, 0.0};
             }
-            double4_t ce = {x[0].x, x[1].x, x[2].x, x[3].x}, co = {x[0].y, x[1].y, x[2].y, x[3].y};
+        }
+    };
+    auto step = [&](double2_t (&x)[2][4], double2_t (&xn)[2][4], long long cb) __attribute__((always_inline)) {
+        const bool more = cb + APM_ROWS < c_stop;
+        double2_t vn[SPT];
+        if (more) {
+            loadq(xn, cb + APM_ROWS);
+            fetch(vn, cb + APM_ROWS);
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const long long c = cb + 32 * h + 2 * (lane & 15);
+            double4_t ce = {x[h][0].x, x[h][1].x, x[h][2].x, x[h][3].x}, co = {x[h][0].y, x[h][1].y, x[h][2].y, x[h][3].y};
 #pragma unroll
             for (int sidx = 0; sidx < KS; ++sidx) {
                 const double2_t b = *reinterpret_cast<const double2_t*>(&sh_v[buf][4 * sidx + (lane >> 4)][32 * h + 2 * (lane & 15)]);
@@ -992,12 +1003,21 @@ __global__ __launch_bounds__(256) void k_apply_mfma(double* __restrict__ Q, long
             }
             const double oe[4] = {ce.x, ce.y, ce.z, ce.w}, oo[4] = {co.x, co.y, co.z, co.w};
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-                if (on[i]) *reinterpret_cast<double2_t*>(rbase + (long long)(4 * i) * ld + cb + 32 * h) = double2_t{oe[i], oo[i]};
+            for (int i = 0; i < 4; ++i) {
+                const long long grow = gr0 + 16 * wave + (lane >> 4) + 4 * i;
+                if (grow <= glast && c < c_stop)
+                    *reinterpret_cast<double2_t*>(rbase + (long long)(4 * i) * ld + cb + 32 * h) = double2_t{oe[i], oo[i]};
+            }
         }
         if (more) park(buf ^ 1, vn);
         __syncthreads();  // everybody is done with sh_v[buf]; sh_v[buf ^ 1] is complete
         buf ^= 1;
+    };
+    double2_t xa[2][4], xb[2][4];
+    loadq(xa, c_begin);
+    for (long long cb = c_begin; cb < c_stop; cb += 2 * APM_ROWS) {
+        step(xa, xb, cb);
+        if (cb + APM_ROWS < c_stop) step(xb, xa, cb + APM_ROWS);
     }
 }
 
@@ -1030,6 +1050,11 @@ __global__ __launch_bounds__(256) void k_pack_grads(const double* __restrict__ g
     gT[i] = v < lv ? g[(long long)v * g_stride + c] : 0.0;
 }
 
+// Round 4 tried the cross-block register pipeline here (loads of block b + 4, and b + 8, in flight behind the 32 MFMAs of block
+// b, wave-uniform row addresses through the scalar unit): at two waves per SIMD the 256 registers do not hold a second 8 KiB
+// block beside gr / dr / the LDS reads in flight -- 336-490 bytes of scratch per lane, 0.65 ms per pass against 0.31
+// (profiles/r04/symm_mfma_pipeline_attempt.txt).  The apply pass (k_apply_mfma), whose per-step state is 16 registers, took the
+// same change and gained 15 %.
 template <bool NT, int SEG>
 __global__ __launch_bounds__(256) void k_symm_mfma(const double* __restrict__ Q, long long ld, long long n, long long row0,
                                                    long long nrows, const double* __restrict__ gT, int lv,

@@ -117,6 +117,10 @@ struct ellhip_sharded {
     ellhip_allreduce_fn user_allreduce = nullptr;
     void* user_ctx = nullptr;
     long long qk = 0;
+    // group runs of symmetric shards: 0 = not decided yet, 1 = EVERY rank holds the group buffers, -1 = some rank could not
+    // allocate them: every rank takes the cut-by-cut schedule (decided once, collectively: shard_group_agree)
+    int group_state = 0;
+    double* d_agree = nullptr;
 };
 
 namespace {
@@ -298,6 +302,7 @@ void ellhip_sharded_destroy(ellhip_sharded* s) {
         Rccl* r = rccl();
         if (r->CommDestroy) (void)r->CommDestroy(s->comm);
     }
+    if (s->d_agree) (void)hipFree(s->d_agree);
     if (s->sh) ellhip_destroy(s->sh);
     delete s;
 }
@@ -372,12 +377,48 @@ int shard_group_exchange(void* ctx, double* buf, long long count, hipStream_t st
 }
 }  // namespace
 
+namespace {
+// The group schedule issues ONE all-reduce of g n doubles per group, the cut-by-cut schedule one of n doubles per cut: the
+// ranks must take the same one or their collectives no longer match.  Whether the group buffers fit is a per-rank fact
+// (the partial-sum sets depend on the shard's rows, free memory on the device), so the decision is made collectively, once
+// per handle: every rank tries to allocate, the ok flags are summed through the handle's own collective, and unless all
+// nranks succeeded everybody frees what it got and runs cut by cut.  Returns 1 (groups), 0 (cut by cut) or an error code.
+int shard_group_agree(ellhip_sharded* s) {
+    if (s->group_state != 0) return s->group_state > 0 ? 1 : 0;
+    const int mrc = multi_setup(s->sh);
+    if (mrc < 0) return mrc;
+    double ok = (mrc == 0) ? 1.0 : 0.0, sum = ok;
+    if (s->nranks > 1) {
+        DeviceGuard guard(s->sh->device);
+        if (!s->d_agree) HIPCHK(hipMalloc(&s->d_agree, sizeof(double)));
+        HIPCHK(hipMemcpyAsync(s->d_agree, &ok, sizeof(double), hipMemcpyHostToDevice, s->sh->stream));
+        const int xrc = shard_group_exchange(s, s->d_agree, 1, s->sh->stream);
+        if (xrc) return xrc;
+        HIPCHK(hipMemcpyAsync(&sum, s->d_agree, sizeof(double), hipMemcpyDeviceToHost, s->sh->stream));
+        HIPCHK(hipStreamSynchronize(s->sh->stream));
+    }
+    const bool all = sum > (double)s->nranks - 0.5;
+    if (!all) {
+        multi_free(s->sh);
+        s->sh->lookahead = 1;
+    }
+    s->group_state = all ? 1 : -1;
+    return all ? 1 : 0;
+}
+}  // namespace
+
 int ellhip_sharded_queue_run_fused(ellhip_sharded* s, int64_t first, int64_t count) {
     if (!s || first < 0 || count < 0 || first + count > s->qk) return fail(ELLHIP_E_INVALID, "queue range");
     if (count == 0) return 0;
     int rc = 0;
-    if (s->partition == ELLHIP_SHARD_SYMMETRIC && multi_shard_ok(s->sh) && (s->user_allreduce || s->comm || s->nranks == 1) &&
-        !(s->user_allgather && !s->user_allreduce)) {
+    bool groups = s->partition == ELLHIP_SHARD_SYMMETRIC && multi_shard_ok(s->sh) && (s->user_allreduce || s->comm || s->nranks == 1) &&
+                  !(s->user_allgather && !s->user_allreduce);
+    if (groups) {
+        const int arc = shard_group_agree(s);
+        if (arc < 0) return arc;
+        groups = arc == 1;
+    }
+    if (groups) {
         // Symmetric shards look ahead like the unsharded queue run: the products of up to 16 queued
         // cuts in one pass over the local trapezoid, ONE all-reduce of the group's vectors, the group stage on every rank.
         DeviceGuard guard(s->sh->device);
@@ -394,17 +435,11 @@ int ellhip_sharded_queue_run_fused(ellhip_sharded* s, int64_t first, int64_t cou
             rc = queue_run_multi(s->sh, i, first + count - i);
             s->sh->grp_exchange = nullptr;
             s->sh->grp_exchange_ctx = nullptr;
-            if (rc == MULTI_NO_MEMORY) {  // (every rank allocates the same sizes: the same decision everywhere)
-                const int64_t end = first + count;
-                first = i;
-                count = end - i;
-                rc = 0;
-                goto cut_by_cut;
-            }
+            if (rc == MULTI_NO_MEMORY)  // (cannot happen: shard_group_agree made sure the buffers exist on every rank)
+                return fail(ELLHIP_E_NOMEM, "group run of a row shard: the group buffers are gone");
         }
         return rc;
     }
-cut_by_cut:
     // pipelined: one pass over the local rows per cut; the collective follows whichever call ran a GEMV
     if (!shard_primed(s, first)) {
         rc = ellhip_queue_prime(s->sh, first);

@@ -132,6 +132,16 @@ class ShardedEllAbi:
     def _local(self):
         return C.c_void_p(self._lib.ellhip_sharded_local(self._h))
 
+    def set_local_option(self, key: int, value: int) -> None:
+        """ellhip_set_option on this rank's shard handle (e.g. OPT_LOOKAHEAD = 1: the cut-by-cut schedule with one collective
+        per update instead of one per group of queued cuts)"""
+        capi.check(self._lib.ellhip_set_option(self._local(), int(key), int(value)), "ellhip_set_option")
+
+    def get_local_option(self, key: int) -> int:
+        v = C.c_int64()
+        capi.check(self._lib.ellhip_get_option(self._local(), int(key), C.byref(v)), "ellhip_get_option")
+        return int(v.value)
+
     def profile_enable(self, flag):
         capi.check(self._lib.ellhip_profile_enable(self._local(), int(flag)))
 
