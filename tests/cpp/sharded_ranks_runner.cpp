@@ -251,7 +251,10 @@ int run_case(const std::string& mode, const int64_t n, const int P, const int pa
     std::vector<double> otsq(K, 0.0);
     std::vector<int> ostat(K, -99);
     for (int i = 0; i <= KFAIL; ++i) {
-        ostat[i] = orc_ell_update(o, cuts.kinds[i], &cuts.grads[(size_t)i * n], cuts.b0[i], cuts.has1[i], cuts.b1[i]);
+        // (the oracle's row-parallel loop: bit-identical to the reference's loop order -- tests/test_oracle_pins.py ties the
+        // three forms together at n = 37, 257, 2048 -- and 20x faster at n = 4096, where the reference order's column-strided
+        // mirror stores took 6 s per case)
+        ostat[i] = orc_ell_update_rowwise_mt(o, cuts.kinds[i], &cuts.grads[(size_t)i * n], cuts.b0[i], cuts.has1[i], cuts.b1[i]);
         otsq[i] = orc_ell_tsq(o);
     }
 

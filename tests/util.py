@@ -52,6 +52,15 @@ def mixed_cut(i, g, tau, rng):
     return 0, 1.5 * tau, None                                          # NoSoln: state must stay intact
 
 
+def oracle_update(orc_space, kind, g, b0, b1):
+    """The oracle's update: for Ell from n = 1024 up its row-parallel loop (`update_rowwise_mt`: bit-identical to the reference's
+    loop order -- tests/test_oracle_pins.py compares the three forms bit for bit at n = 37, 257 and 2048 -- without the
+    column-strided mirror stores that make the reference order take 0.7 s per update at n = 8192)."""
+    if type(orc_space).__name__ == "OracleEll" and orc_space.n >= 1024:
+        return orc_space.update_rowwise_mt(kind, g, b0, b1)
+    return orc_space.update(kind, g, b0, b1)
+
+
 def run_mixed(gpu_space, orc_space, k, seed, g_scale=1.0, check_every=0, tol=TOL):
     """Drive both engines with the same adaptive cut sequence; statuses must agree at every step."""
     n = orc_space.n
@@ -62,7 +71,7 @@ def run_mixed(gpu_space, orc_space, k, seed, g_scale=1.0, check_every=0, tol=TOL
         g *= g_scale / np.linalg.norm(g)
         tau = float(np.sqrt(max(orc_space.kappa * (g @ (orc_space.mq @ g)), 0.0)))
         kind, b0, b1 = mixed_cut(i, g, tau, rng)
-        so = orc_space.update(kind, g, b0, b1)
+        so = oracle_update(orc_space, kind, g, b0, b1)
         sg = gpu_space._update(kind, (g, beta_of(b0, b1)))
         assert int(sg) == int(so), f"step {i}: status gpu={int(sg)} oracle={so}"
         nsucc += int(so == 0)
