@@ -21,6 +21,7 @@
 #include <atomic>
 #include <cstring>
 #include <memory>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -1769,6 +1770,10 @@ bool resident_ok(ellhip_space* s, long long count) {
     return s->rs_R > 0;
 }
 
+// one resident grid per device at a time within this process (two of them cannot both be co-resident: each wants a workgroup
+// on nearly every CU and would wait for the other's to leave); held from the launch until the batch has finished
+constexpr int RS_MAX_DEVICES = 16;
+std::mutex g_resident_mutex[RS_MAX_DEVICES];
 constexpr int RS_FALLBACK = 1;  // resident_run: the batch did not run (or was abandoned and undone): take the streamed schedule
 
 // One batch = one cooperative launch.  The call returns when the batch has finished (one stream synchronisation per
@@ -1812,14 +1817,26 @@ int resident_run(ellhip_space* s, long long first, long long count) {
     A.calc = EllCalcDev::make(s->n, s->use_parallel_cut);
     A.fault_at = s->rs_fault_at;
     const unsigned G = (unsigned)(s->rs_S * (s->rs_S + 1) / 2);
-    HIPCHK(hipMemcpyAsync(s->d_rs_xc0, s->d_xc, (size_t)s->n * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
-    HIPCHK(hipMemcpyAsync(s->d_rs_st0, s->d_st, sizeof(DevState), hipMemcpyDeviceToDevice, s->stream));
-    HIPCHK(hipMemsetAsync(s->d_rs_bar, 0, RS_BAR_WORDS * sizeof(unsigned), s->stream));
+    std::lock_guard<std::mutex> one_resident_grid_per_device(g_resident_mutex[s->device & (RS_MAX_DEVICES - 1)]);
+    hipLaunchKernelGGL(k_rs_prepare, dim3((unsigned)std::max<long long>(1, std::min<long long>(32, s->n / 256))), dim3(256), 0, s->stream,
+                       (const double*)s->d_xc, s->d_rs_xc0, s->n, (const DevState*)s->d_st, s->d_rs_st0, s->d_rs_bar);
+    HIPCHK(hipGetLastError());
     {
         ProfScope ps(s, CLS_RESIDENT);
         const void* k = s->rs_R == 1 ? (const void*)k_ell_resident<1> : (s->rs_R == 2 ? (const void*)k_ell_resident<2> : (const void*)k_ell_resident<3>);
         void* args[] = {&A};
-        const hipError_t e = hipLaunchCooperativeKernel(k, dim3(G), dim3(RS_THREADS), args, 0, s->stream);
+        // ELLHIP_OPT_RESIDENT = 1 (default): a cooperative launch -- the runtime refuses a grid that cannot be co-resident and
+        // runs one cooperative grid at a time, across processes too; measured at the plain launch's speed (n = 4096, 200 cuts
+        // per batch: 1.84 vs 1.87 ms).  2: a plain launch, for a stack without cooperative launches.  Either way the batches
+        // of this process are serialised per device by g_resident_mutex (held by the caller until the batch has finished),
+        // and whatever still keeps workgroups out ends in the bounded waits giving up: the batch is abandoned as a whole
+        // and rerun on the streamed schedule (below).
+        hipError_t e;
+        if (s->resident == 1) {
+            e = hipLaunchCooperativeKernel(k, dim3(G), dim3(RS_THREADS), args, 0, s->stream);
+        } else {
+            e = hipLaunchKernel(k, dim3(G), dim3(RS_THREADS), args, 0, s->stream);
+        }
         if (e != hipSuccess) {
             // not co-resident on this device (partitioned, CU mask, ...): no resident batches on this handle any more
             (void)hipGetLastError();
@@ -2284,8 +2301,9 @@ int option_ok(int key, long long v) {
         case ELLHIP_OPT_APPLY_KERNEL:
             return (v >= -1 && v <= 2) ? 0 : fail(ELLHIP_E_INVALID, "option value must be -1, 0, 1 or 2");
         case ELLHIP_OPT_AUTO_DEFER: case ELLHIP_OPT_SYMV: case ELLHIP_OPT_APPLY_LOWER:
-        case ELLHIP_OPT_FUSE_DOTS: case ELLHIP_OPT_RESIDENT:
+        case ELLHIP_OPT_FUSE_DOTS:
             return (v == 0 || v == 1) ? 0 : fail(ELLHIP_E_INVALID, "option value must be 0 or 1");
+        case ELLHIP_OPT_RESIDENT: return (v >= 0 && v <= 2) ? 0 : fail(ELLHIP_E_INVALID, "ELLHIP_OPT_RESIDENT: 0, 1 or 2");
         case ELLHIP_OPT_OVERLAP: return (v >= 0 && v <= 2) ? 0 : fail(ELLHIP_E_INVALID, "ELLHIP_OPT_OVERLAP: 0, 1 or 2");
         case ELLHIP_OPT_LOOKAHEAD: return (v >= 1 && v <= 16) ? 0 : fail(ELLHIP_E_INVALID, "ELLHIP_OPT_LOOKAHEAD: 1 .. 16");
         case ELLHIP_OPT_QUEUE_DEPTH: return (v == 0 || v == 48) ? 0 : fail(ELLHIP_E_INVALID, "ELLHIP_OPT_QUEUE_DEPTH: 0 or 48");

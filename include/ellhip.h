@@ -221,11 +221,13 @@ int ellhip_set_shard_symmetric(ellhip_space *s, int flag);
  *                                                    reference has two -- inside the 1e-10 contract, not bit-identical to 0 / 1),
  *                                                    1 = k_apply_lower (16-row tiles, the reference's roundings), 0 = k_sweep_apply (depth 8)
  *   ELLHIP_OPT_FUSE_DOTS         0 / 1      1        Ell: the scalar stage's dot products come out of the GEMV's launch
- *   ELLHIP_OPT_RESIDENT          0 / 1      1        Ell: ellhip_queue_run / _run_fused of >= 4 cuts park the lower triangle in the
+ *   ELLHIP_OPT_RESIDENT          0 / 1 / 2  1        Ell: ellhip_queue_run / _run_fused of >= 4 cuts park the lower triangle in the
  *                                                    chip's register files and run the whole batch in ONE persistent launch
  *                                                    (n <= 4224 on a 256-CU device: 9 us instead of 39 us per update at
  *                                                    n = 4096); 0 = always the streamed schedules.  The launch is
- *                                                    cooperative (the grid is co-resident or the launch is refused) and
+ *                                                    cooperative (1: the grid is co-resident or the launch is refused; 2: a
+ *                                                    plain launch, same kernel), the batches of one process are serialised
+ *                                                    per device, and
  *                                                    one batch is synchronous: a refused launch or an in-launch wait that
  *                                                    gave up leaves Q, xc and the scalars at their pre-batch values, the
  *                                                    batch is rerun on the streamed schedule inside the same call and the
