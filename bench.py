@@ -573,9 +573,10 @@ def brief_config(pkg, synth, torch, workload: str, K: int, W: int, P: int, devic
     qd = space.get_option(pkg.capi.OPT_QUEUE_DEPTH) if (variant == "ell" and symv_mode) else 0
     dep_eff = qd if (variant == "ell" and symv_mode and lower_apply and look > 3 and n % 64 == 0 and depth == 24 and qd > depth) else depth
     if variant != "ell" and space.get_option(pkg.capi.OPT_STABLE_MIRRORED):
-        alg["stable_fwd"], alg["stable_bwd"], alg["stable_factor"] = 8.0 * n2, 8.0 * n2, 0.0
-        bytes_update, model = 16.0 * n2, ("16*n^2 B per update (EllStable, mirrored layout: each solve reads its triangle and stores "
-                                          "it back with the previous cut's factor update applied, 8 + 8)")
+        alg["stable_fwd"], alg["stable_bwd"], alg["stable_factor"] = 4.0 * n2, 4.0 * n2, 0.0
+        bytes_update, model = 8.0 * n2, ("8*n^2 B per update (EllStable, mirrored layout: the forward solve reads the factor's upper "
+                                         "triangle, the backward solve its mirrored copy, 4 + 4; nothing is rewritten -- the factor update "
+                                         "is one running scale per row; the reference moves 24*n^2, the eager kernels 20*n^2)")
     elif variant != "ell":
         fb = 8.0 if space.get_option(pkg.capi.OPT_STABLE_FACTOR) != 0 else 12.0
         alg["stable_factor"] = fb * n2
@@ -1015,9 +1016,9 @@ def main() -> None:
         if prof and prof.get("stable_factor", (0.0, 0))[1] == 0:
             alg["stable_bwd"] = 4.0 * n * n + alg["stable_factor"]
         if space.get_option(pkg.capi.OPT_STABLE_MIRRORED):
-            # mirrored layout: each solve reads its triangle and stores it back with the previous cut's factor update applied
-            # (4 + 4), nothing else moves: no scratch triangle, no factor pass
-            alg["stable_fwd"], alg["stable_bwd"], alg["stable_factor"] = 8.0 * n * n, 8.0 * n * n, 0.0
+            # mirrored layout: each solve reads its triangle of the (never rewritten) base factor once, 4 n^2, and stores
+            # nothing but vectors: no scratch triangle, no factor pass (the factor update is one running scale per row)
+            alg["stable_fwd"], alg["stable_bwd"], alg["stable_factor"] = 4.0 * n * n, 4.0 * n * n, 0.0
 
     lookahead, queue_depth = 1, 0
     if variant == "ell" and symv_mode and not sharded:
@@ -1054,8 +1055,9 @@ def main() -> None:
     # nothing is credited against the 24*n^2 two-pass model)
     resident_run = variant == "ell" and bool(prof) and prof.get("resident", (0.0, 0))[1] > 0
     if variant != "ell" and space.get_option(pkg.capi.OPT_STABLE_MIRRORED):
-        bytes_update, model = 16.0 * n * n, ("16*n^2 B per update (EllStable, mirrored layout: each solve reads its triangle and "
-                                             "stores it back with the previous cut's factor update applied, 8 + 8)")
+        bytes_update, model = 8.0 * n * n, ("8*n^2 B per update (EllStable, mirrored layout: the forward solve reads the factor's upper "
+                                            "triangle, the backward solve its mirrored copy, 4 + 4; nothing is rewritten -- the factor "
+                                            "update is one running scale per row; the reference moves 24*n^2, the eager kernels 20*n^2)")
     elif variant != "ell":
         fb = alg["stable_factor"] / (n * n)
         bytes_update, model = (12.0 + fb) * n * n, f"{12.0 + fb:g}*n^2 B per update (EllStable: fwd 8 + bwd 4 + factor {fb:g})"
