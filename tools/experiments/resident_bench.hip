@@ -113,6 +113,7 @@ int main(int argc, char** argv) {
         A.first = first; A.count = count; A.xc = dxc; A.st = dst; A.part = dpart; A.omega_part = dom; A.ctr = dctr;
         A.calc = EllCalcDev::make(n, 1);
         A.stamps = dstamps;
+        A.fault_at = -1;   // (the test hook of the failure contract: never)
         CK(hipMemsetAsync(dctr, 0, RS_BAR_WORDS * sizeof(unsigned), st));
         if (R == 1) hipLaunchKernelGGL(k_ell_resident<1>, dim3((unsigned)G), dim3(RS_THREADS), 0, st, A);
         else if (R == 2) hipLaunchKernelGGL(k_ell_resident<2>, dim3((unsigned)G), dim3(RS_THREADS), 0, st, A);
