@@ -20,7 +20,7 @@ NKERNEL_CLASSES = 14
 # option keys (include/ellhip.h, "options")
 (OPT_AUTO_DEFER, OPT_SYMV, OPT_SYMV_MIN_N, OPT_APPLY_LOWER, OPT_APPLY_KERNEL, OPT_FUSE_DOTS, OPT_STABLE_SOLVE,
  OPT_STABLE_FACTOR, OPT_PAD, OPT_LP_GRID, OPT_LP_WIDE, OPT_BATCH_THREADS, OPT_RESIDENT, OPT_OVERLAP,
- OPT_LOOKAHEAD, OPT_QUEUE_DEPTH, OPT_RESIDENT_FAULT, OPT_RESIDENT_ABANDONED, OPT_STABLE_MIRRORED) = range(1, 20)
+ OPT_LOOKAHEAD, OPT_QUEUE_DEPTH, OPT_RESIDENT_FAULT, OPT_RESIDENT_ABANDONED, OPT_STABLE_MIRRORED, OPT_STAGE_DIRECT) = range(1, 21)
 KERNEL_CLASS_NAMES = ("gemv", "scalar", "rank1", "stable_fwd", "stable_bwd", "stable_factor", "fused", "apply",
                       "apply_gemv", "symv", "symv_reduce", "lp_scan", "lp_final", "resident")
 

@@ -77,6 +77,7 @@ struct Defaults {
     int lp_grid = 0;           // ELLHIP_OPT_LP_GRID: workgroups per LowpassOracle scan launch; 0 = by size
     int lp_wide = -1;          // ELLHIP_OPT_LP_WIDE: column-split scan kernel; -1 = by size
     int batch_threads = 0;     // ELLHIP_OPT_BATCH_THREADS: threads per workgroup of the batched engine; 0 = by size
+    int stage_direct = 1;      // ELLHIP_OPT_STAGE_DIRECT: on large-BAR systems the host writes gradients straight into device memory
 };
 Defaults g_defaults;
 
@@ -97,6 +98,7 @@ struct ellhip_space {
     double* d_Q = nullptr;           // nrows * ld
     double* d_xc = nullptr;          // n
     double* d_stage[2] = {nullptr, nullptr};   // gradient of slot 0 / 1 (n doubles)
+    bool stage_direct = false;       // d_stage is fine-grained device memory the HOST writes through the PCIe BAR (large-BAR systems)
     double* d_gt_own[2] = {nullptr, nullptr};  // Q*g of slot 0 / 1 (n doubles)
     double* d_gt[2] = {nullptr, nullptr};      // buffers in use (own or caller's)
     double* d_work = nullptr;        // EllStable vectors: w, z, gg, q, beta2
@@ -968,6 +970,13 @@ int live_wait(ellhip_space* s) {
 int stage_grad(ellhip_space* s, const double* grad, int slot) {
     if (!grad) return fail(ELLHIP_E_INVALID, "grad is NULL");
     const size_t bytes = (size_t)s->n * sizeof(double);
+    if (s->stage_direct) {
+        // Nothing in flight reads this slot: every reader of a staged gradient (the GEMV, the scalar stage, EllStable's forward
+        // solve) has finished before the call that consumed it returned, and the other slot is the one a primed gradient holds.
+        memcpy(s->d_stage[slot], grad, bytes);
+        __atomic_thread_fence(__ATOMIC_SEQ_CST);   // (write-combined stores drained before the launch's doorbell)
+        return 0;
+    }
     memcpy(s->h_stage[slot], grad, bytes);
     // (the chip pulls the staging buffer over PCIe itself: no copy engine, no cross-engine hand-over in front of the GEMV)
     const unsigned wgs = (unsigned)std::max<long long>(1, std::min<long long>(STAGE_WGS, s->n / 512));
@@ -1055,8 +1064,30 @@ int alloc_common(ellhip_space* s) {
     s->stream = s->own_stream;
     HIPCHK(hipMalloc(&s->d_Q, (size_t)s->nrows * (size_t)s->ld * sizeof(double)));
     HIPCHK(hipMalloc(&s->d_xc, vbytes));
+    {   // Large-BAR systems: the host writes a gradient straight into device memory (fine-grained allocation: 3 us for 128 KiB)
+        // instead of into a pinned buffer that a kernel then pulls over PCIe (0.8 + 7.6 us and a launch on the live loop's
+        // critical path, tools/experiments/bar_write.hip).
+        int large_bar = 0;
+        if (hipDeviceGetAttribute(&large_bar, hipDeviceAttributeIsLargeBar, s->device) != hipSuccess) large_bar = 0;
+        (void)hipGetLastError();
+        s->stage_direct = large_bar != 0 && g_defaults.stage_direct != 0;
+    }
+    if (s->stage_direct) {
+        for (int k = 0; k < 2 && s->stage_direct; ++k)
+            if (hipExtMallocWithFlags(reinterpret_cast<void**>(&s->d_stage[k]), vbytes, hipDeviceMallocFinegrained) != hipSuccess) {
+                (void)hipGetLastError();
+                s->d_stage[k] = nullptr;
+                s->stage_direct = false;
+            }
+        if (!s->stage_direct)
+            for (int k = 0; k < 2; ++k) {
+                if (s->d_stage[k]) (void)hipFree(s->d_stage[k]);
+                s->d_stage[k] = nullptr;
+            }
+    }
+    if (!s->stage_direct)
+        for (int k = 0; k < 2; ++k) HIPCHK(hipMalloc(&s->d_stage[k], vbytes));
     for (int k = 0; k < 2; ++k) {
-        HIPCHK(hipMalloc(&s->d_stage[k], vbytes));
         HIPCHK(hipMalloc(&s->d_gt_own[k], vbytes));
         s->d_gt[k] = s->d_gt_own[k];
         HIPCHK(hipHostMalloc(&s->h_stage[k], vbytes, hipHostMallocCoherent | hipHostMallocMapped));  // (k_stage reads it from the device)
@@ -2300,6 +2331,7 @@ int option_ok(int key, long long v) {
     switch (key) {
         case ELLHIP_OPT_APPLY_KERNEL:
             return (v >= -1 && v <= 2) ? 0 : fail(ELLHIP_E_INVALID, "option value must be -1, 0, 1 or 2");
+        case ELLHIP_OPT_STAGE_DIRECT: return (v == 0 || v == 1) ? 0 : fail(ELLHIP_E_INVALID, "option value must be 0 or 1");
         case ELLHIP_OPT_AUTO_DEFER: case ELLHIP_OPT_SYMV: case ELLHIP_OPT_APPLY_LOWER:
         case ELLHIP_OPT_FUSE_DOTS:
             return (v == 0 || v == 1) ? 0 : fail(ELLHIP_E_INVALID, "option value must be 0 or 1");
@@ -2342,6 +2374,7 @@ int ellhip_set_default_option(int key, int64_t value) {
         case ELLHIP_OPT_LP_GRID: g_defaults.lp_grid = (int)value; break;
         case ELLHIP_OPT_LP_WIDE: g_defaults.lp_wide = (int)value; break;
         case ELLHIP_OPT_BATCH_THREADS: g_defaults.batch_threads = (int)value; break;
+        case ELLHIP_OPT_STAGE_DIRECT: g_defaults.stage_direct = (int)value; break;
     }
     return 0;
 }
@@ -2365,6 +2398,7 @@ int ellhip_default_option(int key, int64_t* value) {
         case ELLHIP_OPT_LP_GRID: *value = g_defaults.lp_grid; break;
         case ELLHIP_OPT_LP_WIDE: *value = g_defaults.lp_wide; break;
         case ELLHIP_OPT_BATCH_THREADS: *value = g_defaults.batch_threads; break;
+        case ELLHIP_OPT_STAGE_DIRECT: *value = g_defaults.stage_direct; break;
         default: return fail(ELLHIP_E_INVALID, "unknown option key");
     }
     return 0;
@@ -2450,6 +2484,7 @@ int ellhip_get_option(const ellhip_space* s, int key, int64_t* value) {
         case ELLHIP_OPT_STABLE_SOLVE: *value = s->stable_solve; break;
         case ELLHIP_OPT_STABLE_FACTOR: *value = s->stable_factor; break;
         case ELLHIP_OPT_STABLE_MIRRORED: *value = s->st_mirrored ? 1 : 0; break;
+        case ELLHIP_OPT_STAGE_DIRECT: *value = s->stage_direct ? 1 : 0; break;
         case ELLHIP_OPT_PAD: *value = s->ld - s->n; break;
         default: return fail(ELLHIP_E_INVALID, "not a per-handle option");
     }

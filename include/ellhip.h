@@ -297,6 +297,9 @@ int ellhip_set_shard_symmetric(ellhip_space *s, int flag);
 #define ELLHIP_OPT_RESIDENT_FAULT 17
 #define ELLHIP_OPT_RESIDENT_ABANDONED 18
 #define ELLHIP_OPT_STABLE_MIRRORED 19   /* read only, EllStable: 1 while the handle's buffer is in the mirrored layout */
+#define ELLHIP_OPT_STAGE_DIRECT 20      /* default only (0 / 1, default 1; per handle: read only): on a large-BAR system the host
+                                           writes each gradient straight into (fine-grained) device memory instead of into a
+                                           pinned buffer a kernel then pulls over PCIe */
 int ellhip_set_option(ellhip_space *s, int key, int64_t value);
 int ellhip_get_option(const ellhip_space *s, int key, int64_t *value);
 int ellhip_set_default_option(int key, int64_t value);
