@@ -779,7 +779,10 @@ def main() -> None:
             alts.insert(0, ("pipelined, lookahead 1", depth))
     # (a second profiled region, kernels one at a time, where the default run overlaps them: see prof_iso below)
     P_iso = P if (variant == "ell" and not sharded and args.schedule == "pipelined" and n % 64 == 0 and n >= symv_min_n and lower_ok) else 0
-    total = W + K + P + P_iso + 2 * C2 * len(alts) + C3 + H
+    # a second, longer region of the SAME schedule when the contract's K is short (the driver runs --steps 20: a 1.25 ms
+    # single shot whose one apply pass is a third of it): `config.steady_state_updates_per_s`, never `value`
+    S2 = 192 if (variant == "ell" and not sharded and K < 192) else 0
+    total = W + K + P + P_iso + 2 * C2 * len(alts) + C3 + S2 + H
     if sharded and n % world and not shard_sym:
         raise SystemExit(f"n={n} is not divisible by {world} ranks")
 
@@ -841,7 +844,7 @@ def main() -> None:
             space = ShardedEll.new_with_scalar(1.0, np.zeros(n), device=local_rank, symmetric=shard_sym,
                                               defer_depth=depth if shard_sym else 8)
             sharded_via = "torch.distributed"
-    nq = W + K + P + P_iso + 2 * C2 * len(alts) + C3
+    nq = W + K + P + P_iso + 2 * C2 * len(alts) + C3 + S2
     if variant == "ell" and not shard_sym:   # always explicit: a new unsharded handle may start at depth 16 by itself
         space.set_defer_depth(depth) if sharded else setattr(space, "defer_depth", depth)
     space.queue_upload(kinds[:nq], grads[:nq], b0[:nq], b1[:nq])
@@ -949,6 +952,18 @@ def main() -> None:
                     "schedule": "pipelined, one all-reduce(Q g) of n doubles per update (ELLHIP_OPT_LOOKAHEAD = 1 on the shard handle): "
                                 "the form BASELINE config 4 names; what a live cutting-plane loop over a sharded space can reach"}
         pos += C3
+
+    steady = None
+    if S2 > 0:
+        space.defer_depth = depth
+        space.flush()
+        fence()
+        t2 = time.perf_counter()
+        run(pos, S2)
+        space.flush()
+        fence()
+        steady = S2 / (time.perf_counter() - t2)
+        pos += S2
 
     status, tsqs = space.queue_results()
     ran = nq if per_iter or C3 == 0 else nq - C3
@@ -1196,6 +1211,11 @@ def main() -> None:
         if o["schedule"] == "two-pass" and o["defer_depth"] == 1:
             roofline["canonical_24n2_updates_per_s"] = o["updates_per_s"]
             roofline["canonical_24n2_frac"] = o["whole_update"]["frac"]
+    if steady:
+        reach["steady_state_updates_per_s"] = steady
+        reach["steady_state_note"] = (f"the timed schedule over {S2} more steps of the same queue (same fences, recorded updates applied inside): "
+                                      f"`value` is the contract's {K}-step region, {ms_per_step * K:.2f} ms long, whose closing apply pass "
+                                      "is a large part of it")
     out["config"].update(reach)
     if world == 1 and not args.no_cpu_baseline:
         log("[rank 0] timing the CPU oracle (bounded sample) ...")

@@ -58,6 +58,7 @@ def test_headline_workload_contract():
     assert cfg["value_requires_future_gradients"] == 16 and cfg["live_loop_updates_per_s"] == ll["plain_iterations_per_s"]
     assert cfg["host_call_updates_per_s"] == d["host_call_path"]["updates_per_s_depth24"]
     assert cfg["live_loop_updates_per_s"] < d["value"]
+    assert cfg["steady_state_updates_per_s"] > 0.8 * d["value"]      # (192 more steps of the timed schedule beside a 16-step region)
     assert r["traffic_measured_in_this_run"] is False and r["per_kernel"]["symv"]["avg_ms"] > 0
     # the as-run figure (the next group's products overlap this group's stage) and the kernel by itself
     assert r["isolated"]["kernel"] == "k_symm_mfma" and 0.3 < r["isolated"]["frac"] < 1.0
