@@ -1924,7 +1924,7 @@ int ellhip_device_count(void) {
 
 const char* ellhip_last_error(void) { return g_last_error.c_str(); }
 
-const char* ellhip_version(void) { return "ellhip 0.3.0 gfx950"; }
+const char* ellhip_version(void) { return "ellhip 0.4.0 gfx950"; }
 
 int ellhip_create(ellhip_space** out, int variant, int64_t n, double kappa, const double* mq, const double* diag,
                   const double* xc, int device) {
