@@ -191,6 +191,8 @@ struct ellhip_space {
     unsigned long long live_seq = 0;
     unsigned* d_pub_arrived = nullptr;        // k_publish: workgroups that have pushed their slice of the centre
     bool xc_host_valid = false;               // h_xc equals d_xc (nothing has written the centre on the device since)
+    bool live_arm = false;                    // the do_cut in progress belongs to a live update: the scalar stage may publish itself
+    bool live_done = false;                   // ... and did (live_publish has nothing left to launch)
 
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
@@ -837,6 +839,15 @@ int do_cut(ellhip_space* s, const double* g_dev, const CutParams* cp_dev, CutPar
         const bool have_dots = dots_np_now == s->defer;
         const bool gy_inside = have_dots && s->dots_need_gy;
         const int npart = (have_dots && !gy_inside) ? (int)((s->n + 127) / 128) : (int)G;
+        // a live update: the stage's own workgroups push the centre and the state to the host (live_tail) -- no k_publish launch
+        LiveMirror* lm = nullptr;
+        unsigned long long lseq = 0;
+        if (s->live_arm && queue_mode == 0) {
+            s->live_seq += 1;
+            lm = s->h_live;
+            lseq = s->live_seq;
+            s->live_done = true;
+        }
 #define SCALAR_DEF(NPV)                                                                                           \
     if (!have_dots)                                                                                               \
         hipLaunchKernelGGL(k_scalar_dot_def<NPV>, dim3(G), dim3(256), 0, s->stream, s->n, g_dev, gt,               \
@@ -844,11 +855,11 @@ int do_cut(ellhip_space* s, const double* g_dev, const CutParams* cp_dev, CutPar
     if (gy_inside)                                                                                                \
         hipLaunchKernelGGL((k_scalar_apply_def<NPV, true>), dim3(G), dim3(256), 0, s->stream, s->n, gt, s->d_xc,   \
                            s->d_pend, s->d_cpend, (const double*)s->d_partial, s->d_st, calc, cp_dev, cp_val,     \
-                           s->npend, queue_mode, qst, qtsq, npart, g_dev);                                        \
+                           s->npend, queue_mode, qst, qtsq, npart, g_dev, lm, s->h_xc, lseq, s->d_pub_arrived);   \
     else                                                                                                          \
         hipLaunchKernelGGL(k_scalar_apply_def<NPV>, dim3(G), dim3(256), 0, s->stream, s->n, gt, s->d_xc, s->d_pend, \
                            s->d_cpend, (const double*)s->d_partial, s->d_st, calc, cp_dev, cp_val, s->npend,      \
-                           queue_mode, qst, qtsq, npart, (const double*)nullptr)
+                           queue_mode, qst, qtsq, npart, (const double*)nullptr, lm, s->h_xc, lseq, s->d_pub_arrived)
         if (s->defer == 24) { SCALAR_DEF(24); } else if (s->defer == 16) { SCALAR_DEF(16); } else { SCALAR_DEF(8); }
 #undef SCALAR_DEF
         HIPCHK(hipGetLastError());
@@ -933,6 +944,10 @@ int read_back(ellhip_space* s) {
 // rank-1 pass, an apply pass of the recorded schedule) keeps running: the next call on the handle is ordered after it by
 // the stream.  Same observable contract as read_back (h_result, kappa, tsq, the solve_err protocol).
 int live_publish(ellhip_space* s) {
+    if (s->live_done) {   // the scalar stage has published itself (live_tail)
+        s->live_done = false;
+        return 0;
+    }
     s->live_seq += 1;
     const unsigned wgs = (unsigned)std::max<long long>(1, std::min<long long>(PUB_WGS, s->n / 1024));
     hipLaunchKernelGGL(k_publish, dim3(wgs), dim3(256), 0, s->stream, (const DevState*)s->d_st, (const double*)s->d_xc, s->n,
@@ -2112,7 +2127,10 @@ int ellhip_cut(ellhip_space* s, int kind, double beta0, int has_beta1, double be
     CutParams cp;
     int rc = make_params(kind, beta0, has_beta1, beta1, cp);
     if (rc) return rc;
+    s->live_arm = true;
     rc = do_cut(s, s->g_cur, nullptr, cp, 0, nullptr, nullptr);
+    s->live_arm = false;
+    if (rc) s->live_done = false;
     if (!rc) rc = live_publish(s);
     if (!rc) rc = live_wait(s);
     if (rc) return rc;
@@ -2169,8 +2187,13 @@ int ellhip_update_end(ellhip_space* s) {
     if (!s->in_two_phase) return fail(ELLHIP_E_STATE, "update_end without update_begin");
     DeviceGuard guard(s->device);
     s->in_two_phase = false;
+    s->live_arm = true;
     int rc = do_cut(s, s->g_cur, nullptr, s->two_phase_cp, 0, nullptr, nullptr);
-    if (rc) return rc;
+    s->live_arm = false;
+    if (rc) {
+        s->live_done = false;
+        return rc;
+    }
     // status, tsq, kappa and the new centre are final after the scalar stage: they go to the host from there
     rc = live_publish(s);
     if (rc) return rc;
