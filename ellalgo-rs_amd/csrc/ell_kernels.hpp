@@ -1075,9 +1075,11 @@ __global__ __launch_bounds__(256) void k_apply_mfma(double* __restrict__ Q, long
 constexpr int SMM_NV = 16;
 constexpr int SMM_PITCH = 17;
 
+// (k_pack_grads also rewinds the tile queue of the pass that follows it on the same stream: k_symm_mfma_q)
 __global__ __launch_bounds__(256) void k_pack_grads(const double* __restrict__ g, long long g_stride, int lv, long long n,
-                                                    double* __restrict__ gT) {
+                                                    double* __restrict__ gT, unsigned* __restrict__ queue = nullptr) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;  // element of gT: c = i / 16, v = i % 16
+    if (i == 0 && queue) *queue = 0u;
     if (i >= n * SMM_NV) return;
     const long long c = i / SMM_NV;
     const int v = (int)(i % SMM_NV);
@@ -1088,24 +1090,21 @@ __global__ __launch_bounds__(256) void k_pack_grads(const double* __restrict__ g
 // b, wave-uniform row addresses through the scalar unit): at two waves per SIMD the 256 registers do not hold a second 8 KiB
 // block beside gr / dr / the LDS reads in flight -- 336-490 bytes of scratch per lane, 0.65 ms per pass against 0.31
 // (profiles/r04/symm_mfma_pipeline_attempt.txt).  The apply pass (k_apply_mfma), whose per-step state is 16 registers, took the
-// same change and gained 15 %.
+// same change and gained 15 %.  An LDS-DMA ring per wave, and loader / consumer waves, followed (tools/experiments/symm_glds.hip,
+// symm_lc_kernel.hpp, profiles/r04/symm_mfma_overlap_probes.txt): same bits, no gain -- on a SIMD that executes f64 MFMAs every
+// vector-memory instruction costs the matrix pipe ~70 cycles whichever wave issues it, so the two phases add up however the
+// loads are buffered.  What did pay is how the tiles reach the CUs: k_symm_mfma_q below.
+//
+// One tile: strip I of the shard (rows r0 = row0 + 64 I ...), column segment J; sh = the workgroup's 4 x 64 x 17 doubles.
 template <bool NT, int SEG>
-__global__ __launch_bounds__(256) void k_symm_mfma(const double* __restrict__ Q, long long ld, long long n, long long row0,
-                                                   long long nrows, const double* __restrict__ gT, int lv,
-                                                   double* __restrict__ rowpart,
-                                                   double* __restrict__ colpart, long long rowpart_stride,
-                                                   long long colpart_stride, const DevState* __restrict__ st) {
-    __shared__ double sh[4][SYMV_H * SMM_PITCH];
-    if (st->halted) return;
+__device__ __forceinline__ void symm_tile(const double* __restrict__ Q, long long ld, long long n, long long row0, long long I,
+                                          long long J, const double* __restrict__ gT, int lv, double* __restrict__ rowpart,
+                                          double* __restrict__ colpart, long long rowpart_stride, long long colpart_stride,
+                                          double (*sh)[SYMV_H * SMM_PITCH]) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int lr = lane >> 4, lc = lane & 15;
-    const long long I = (long long)gridDim.x - 1 - blockIdx.x, J = (long long)blockIdx.y;
-    // a symmetric row shard holds the rows [row0, row0 + nrows) (both multiples of 64): I counts its local strips, row and
-    // column indices are global, the result is this shard's PARTIAL sums (as k_symv's for a shard)
     const long long r0 = row0 + I * SYMV_H;
     const long long c0 = J * SEG;
-    if (r0 >= row0 + nrows || c0 > r0 + SYMV_H - 1) return;
-    Q -= row0 * ld;
     const bool full = c0 + SEG - 1 < r0;
     // A operand of the column product: gT rows of the strip
     double gr[16];
@@ -1174,6 +1173,57 @@ __global__ __launch_bounds__(256) void k_symm_mfma(const double* __restrict__ Q,
         const double s0 = red[((0 * 4 + jj) * 4 + i) * 64 + lane], s1 = red[((1 * 4 + jj) * 4 + i) * 64 + lane];
         const double s2 = red[((2 * 4 + jj) * 4 + i) * 64 + lane], s3 = red[((3 * 4 + jj) * 4 + i) * 64 + lane];
         if (v < lv) rowpart[(long long)v * rowpart_stride + J * n + r0 + 16 * jj + lc] = ((s0 + s1) + s2) + s3;
+    }
+}
+
+// One workgroup per tile of k_symv's grid (the form round 3 shipped; the experiments and the queue form's check use it).
+template <bool NT, int SEG>
+__global__ __launch_bounds__(256) void k_symm_mfma(const double* __restrict__ Q, long long ld, long long n, long long row0,
+                                                   long long nrows, const double* __restrict__ gT, int lv,
+                                                   double* __restrict__ rowpart,
+                                                   double* __restrict__ colpart, long long rowpart_stride,
+                                                   long long colpart_stride, const DevState* __restrict__ st) {
+    __shared__ double sh[4][SYMV_H * SMM_PITCH];
+    if (st->halted) return;
+    const long long I = (long long)gridDim.x - 1 - blockIdx.x, J = (long long)blockIdx.y;
+    // a symmetric row shard holds the rows [row0, row0 + nrows) (both multiples of 64): I counts its local strips, row and
+    // column indices are global, the result is this shard's PARTIAL sums (as k_symv's for a shard)
+    const long long r0 = row0 + I * SYMV_H;
+    if (r0 >= row0 + nrows || J * SEG > r0 + SYMV_H - 1) return;
+    symm_tile<NT, SEG>(Q - row0 * ld, ld, n, row0, I, J, gT, lv, rowpart, colpart, rowpart_stride, colpart_stride, sh);
+}
+
+// The same tiles handed out from a QUEUE.  A 64 x 2048 tile keeps its workgroup ~100 us and a card holds 512 such workgroups,
+// so the grid form's pass lasts whole workgroup lifetimes: 1152 tiles (n = 16384; 1028 full ones' worth of work) take three.
+// Here 3 workgroups per CU are launched once, each draws tile after tile from a counter -- largest first, the host-built table
+// `tiles` -- until none is left, and the pass ends with the smallest tiles: 0.272-0.275 ms against 0.306-0.317 (interleaved
+// rounds in one process, tools/experiments/symm_glds.hip).  Same tiles, same arithmetic per tile: the partial sums are
+// bit-identical to the grid form's.  The counter is rewound by the k_pack_grads launch ahead of the pass.
+struct SymmTile {
+    int I, J;  // strip of the shard, column segment
+};
+template <bool NT, int SEG>
+__global__ __launch_bounds__(256) void k_symm_mfma_q(const double* __restrict__ Q, long long ld, long long n, long long row0,
+                                                     const double* __restrict__ gT, int lv, double* __restrict__ rowpart,
+                                                     double* __restrict__ colpart, long long rowpart_stride,
+                                                     long long colpart_stride, const DevState* __restrict__ st,
+                                                     const SymmTile* __restrict__ tiles, int ntiles,
+                                                     unsigned* __restrict__ queue) {
+    __shared__ double sh[4][SYMV_H * SMM_PITCH];
+    __shared__ int s_t;
+    if (st->halted) return;
+    Q -= row0 * ld;
+    for (;;) {
+        __syncthreads();  // (everybody has read the previous index and is done with the tile's LDS)
+        if (threadIdx.x == 0) {
+            const unsigned t = atomicAdd(queue, 1u);
+            s_t = t < (unsigned)ntiles ? (int)t : -1;
+        }
+        __syncthreads();
+        const int t = s_t;
+        if (t < 0) return;  // (uniform)
+        symm_tile<NT, SEG>(Q, ld, n, row0, (long long)tiles[t].I, (long long)tiles[t].J, gT, lv, rowpart, colpart, rowpart_stride,
+                           colpart_stride, sh);
     }
 }
 

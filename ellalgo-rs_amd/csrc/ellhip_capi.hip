@@ -140,6 +140,9 @@ struct ellhip_space {
     double* d_rowpart_m = nullptr;   // [MULTI_MAX][nsegs][n]
     double* d_colpart_m = nullptr;   // [MULTI_MAX][nstrips][n]
     double* d_gT = nullptr;          // [n][16]: a group's gradients side by side (operand layout of k_symm_mfma)
+    SymmTile* d_symm_tiles = nullptr;  // k_symm_mfma_q's tiles, largest first
+    unsigned* d_symm_queue = nullptr;  // its two counters (one per half of the partial-sum sets), 128 bytes apart
+    int symm_ntiles = 0, symm_wgs = 0;
     // ... and the group's scalar stage (group_kernels.hpp)
     double* d_grpY = nullptr;        // [GRP_MAX][n]: y_l = Q_base g_l of the group's cuts
     double* d_gpart = nullptr;       // [GRP_MAX][ceil(n/128)][MAXPEND + 1]
@@ -1527,6 +1530,11 @@ void multi_free(ellhip_space* s) {
     }
     if (s->d_gout) (void)hipFree(s->d_gout);
     s->d_gout = nullptr;
+    if (s->d_symm_tiles) (void)hipFree(s->d_symm_tiles);
+    s->d_symm_tiles = nullptr;
+    if (s->d_symm_queue) (void)hipFree(s->d_symm_queue);
+    s->d_symm_queue = nullptr;
+    s->symm_ntiles = 0;
 }
 
 // The group runs' buffers: 2 x 16 sets of partial sums are 2.2 n^2 / 64 x 32 = 1.1 n^2 doubles-worth of memory beside
@@ -1547,6 +1555,22 @@ int multi_setup(ellhip_space* s) {
     if (e == hipSuccess) e = hipMalloc(&s->d_cpart, nb * GRP_MAX * GRP_MAX * sizeof(double));
     if (e == hipSuccess) e = hipMalloc(&s->d_gout, sizeof(GroupOut));
     if (e == hipSuccess) e = hipMalloc(&s->d_gsums, (size_t)(GRP_MAX * (MAXPEND + 1) + GRP_MAX * GRP_MAX) * sizeof(double));
+    // the matrix-core pass draws its tiles from a queue, largest first (k_symm_mfma_q)
+    std::vector<SymmTile> tiles;
+    if ((s->n % 64) == 0 && (s->row0 % 64) == 0) {  // (whatever the lookahead is right now: the option may change)
+        const long long seg = s->symv_seg;
+        const long long nstrips = (s->nrows + SYMV_H - 1) / SYMV_H, nsegs = (s->n + seg - 1) / seg;
+        auto blocks_of = [&](const SymmTile& t) {
+            const long long r0 = s->row0 + (long long)t.I * SYMV_H, c0 = (long long)t.J * seg;
+            return (std::min(c0 + seg, r0 + SYMV_H) - c0) / 16;
+        };
+        for (long long I = nstrips - 1; I >= 0; --I)
+            for (long long J = 0; J < nsegs; ++J)
+                if (J * seg <= s->row0 + I * SYMV_H + SYMV_H - 1) tiles.push_back({(int)I, (int)J});
+        std::stable_sort(tiles.begin(), tiles.end(), [&](const SymmTile& a, const SymmTile& b) { return blocks_of(a) > blocks_of(b); });
+        if (e == hipSuccess) e = hipMalloc(&s->d_symm_tiles, tiles.size() * sizeof(SymmTile));
+        if (e == hipSuccess) e = hipMalloc(&s->d_symm_queue, 256);
+    }
     if (e == hipErrorOutOfMemory) {
         (void)hipGetLastError();
         multi_free(s);
@@ -1560,6 +1584,15 @@ int multi_setup(ellhip_space* s) {
     HIPCHK(hipMemsetAsync(s->d_rowpart_m, 0, rbytes, s->stream));
     HIPCHK(hipMemsetAsync(s->d_colpart_m, 0, cbytes, s->stream));
     HIPCHK(hipMemsetAsync(s->d_gout, 0, sizeof(GroupOut), s->stream));
+    if (!tiles.empty()) {
+        HIPCHK(hipMemcpyAsync(s->d_symm_tiles, tiles.data(), tiles.size() * sizeof(SymmTile), hipMemcpyHostToDevice, s->stream));
+        HIPCHK(hipMemsetAsync(s->d_symm_queue, 0, 256, s->stream));
+        HIPCHK(hipStreamSynchronize(s->stream));  // (`tiles` is pageable host memory going out of scope)
+        hipDeviceProp_t prop;
+        HIPCHK(hipGetDeviceProperties(&prop, s->device));
+        s->symm_ntiles = (int)tiles.size();
+        s->symm_wgs = (int)std::min<size_t>(tiles.size(), (size_t)3 * (size_t)prop.multiProcessorCount);
+    }
     return 0;
 }
 
@@ -1609,20 +1642,19 @@ int group_stage_go(ellhip_space* s, long long i, int g, int half) {
 
 template <int SEG>
 void symm_mfma_go(ellhip_space* s, const double* g_dev, int lv, hipStream_t st, int half) {
-    const unsigned nstrips = (unsigned)((s->nrows + SYMV_H - 1) / SYMV_H);
-    const unsigned nsegs = (unsigned)((s->n + SEG - 1) / SEG);
     double* gT = s->d_gT + (size_t)half * (size_t)s->n * SMM_NV;
     double* rowp = s->d_rowpart_m + (size_t)half * MULTI_MAX * rowpart_elems(s);
     double* colp = s->d_colpart_m + (size_t)half * MULTI_MAX * colpart_elems(s);
-    hipLaunchKernelGGL(k_pack_grads, dim3((unsigned)((s->n * SMM_NV + 255) / 256)), dim3(256), 0, st, g_dev, s->n, lv, s->n, gT);
+    unsigned* queue = s->d_symm_queue + 32 * half;
+    hipLaunchKernelGGL(k_pack_grads, dim3((unsigned)((s->n * SMM_NV + 255) / 256)), dim3(256), 0, st, g_dev, s->n, lv, s->n, gT, queue);
     if (s->sh_gemv.nt != 0)
-        hipLaunchKernelGGL((k_symm_mfma<true, SEG>), dim3(nstrips, nsegs), dim3(256), 0, st, (const double*)s->d_Q, s->ld, s->n,
-                           s->row0, s->nrows, (const double*)gT, lv, rowp, colp, (long long)rowpart_elems(s), (long long)colpart_elems(s),
-                           (const DevState*)s->d_st);
+        hipLaunchKernelGGL((k_symm_mfma_q<true, SEG>), dim3((unsigned)s->symm_wgs), dim3(256), 0, st, (const double*)s->d_Q, s->ld, s->n,
+                           s->row0, (const double*)gT, lv, rowp, colp, (long long)rowpart_elems(s), (long long)colpart_elems(s),
+                           (const DevState*)s->d_st, (const SymmTile*)s->d_symm_tiles, s->symm_ntiles, queue);
     else
-        hipLaunchKernelGGL((k_symm_mfma<false, SEG>), dim3(nstrips, nsegs), dim3(256), 0, st, (const double*)s->d_Q, s->ld, s->n,
-                           s->row0, s->nrows, (const double*)gT, lv, rowp, colp, (long long)rowpart_elems(s), (long long)colpart_elems(s),
-                           (const DevState*)s->d_st);
+        hipLaunchKernelGGL((k_symm_mfma_q<false, SEG>), dim3((unsigned)s->symm_wgs), dim3(256), 0, st, (const double*)s->d_Q, s->ld, s->n,
+                           s->row0, (const double*)gT, lv, rowp, colp, (long long)rowpart_elems(s), (long long)colpart_elems(s),
+                           (const DevState*)s->d_st, (const SymmTile*)s->d_symm_tiles, s->symm_ntiles, queue);
 }
 int symm_go(ellhip_space* s, const double* g_dev, int lv, hipStream_t st, int half) {
     ProfScope ps(s, CLS_SYMV, st);
@@ -1997,6 +2029,8 @@ void ellhip_destroy(ellhip_space* s) {
     if (s->d_cpart) (void)hipFree(s->d_cpart);
     if (s->d_gout) (void)hipFree(s->d_gout);
     if (s->d_gsums) (void)hipFree(s->d_gsums);
+    if (s->d_symm_tiles) (void)hipFree(s->d_symm_tiles);
+    if (s->d_symm_queue) (void)hipFree(s->d_symm_queue);
     if (s->ev_symv) (void)hipEventDestroy(s->ev_symv);
     if (s->ev_side_go) (void)hipEventDestroy(s->ev_side_go);
     if (s->symv_stream) (void)hipStreamDestroy(s->symv_stream);
