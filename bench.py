@@ -420,8 +420,8 @@ def gemv_passes(steps: int, dep: int, lookahead: int) -> int:
     while i < steps:
         rem = min(steps - i, dep - npend)
         g = min(lookahead, rem)
-        if lookahead > 3 and lookahead < rem < 2 * lookahead:
-            g = (rem + 1) // 2   # (two even groups rather than a full and a small one: queue_run_multi)
+        if 3 < lookahead <= 16 and lookahead < rem < 2 * lookahead:
+            g = (rem + 1) // 2   # (16-wide passes only: two even groups rather than a full and a small one: group_size)
         passes += 1
         i += g
         npend = (npend + g) % dep

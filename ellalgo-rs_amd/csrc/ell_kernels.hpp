@@ -1075,14 +1075,16 @@ __global__ __launch_bounds__(256) void k_apply_mfma(double* __restrict__ Q, long
 constexpr int SMM_NV = 16;
 constexpr int SMM_PITCH = 17;
 
-// (k_pack_grads also rewinds the tile queue of the pass that follows it on the same stream: k_symm_mfma_q)
+// (k_pack_grads also rewinds the tile queue of the pass that follows it on the same stream: k_symm_mfma_q.  nvw = 16 or 32: the
+// gradients side by side, gT[c][v], zero-padded to the width the pass multiplies)
 __global__ __launch_bounds__(256) void k_pack_grads(const double* __restrict__ g, long long g_stride, int lv, long long n,
-                                                    double* __restrict__ gT, unsigned* __restrict__ queue = nullptr) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;  // element of gT: c = i / 16, v = i % 16
+                                                    double* __restrict__ gT, unsigned* __restrict__ queue = nullptr,
+                                                    int nvw = SMM_NV) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;  // element of gT: c = i / nvw, v = i % nvw
     if (i == 0 && queue) *queue = 0u;
-    if (i >= n * SMM_NV) return;
-    const long long c = i / SMM_NV;
-    const int v = (int)(i % SMM_NV);
+    if (i >= n * nvw) return;
+    const long long c = i / nvw;
+    const int v = (int)(i % nvw);
     gT[i] = v < lv ? g[(long long)v * g_stride + c] : 0.0;
 }
 
@@ -1224,6 +1226,130 @@ __global__ __launch_bounds__(256) void k_symm_mfma_q(const double* __restrict__ 
         if (t < 0) return;  // (uniform)
         symm_tile<NT, SEG>(Q, ld, n, row0, (long long)tiles[t].I, (long long)tiles[t].J, gT, lv, rowpart, colpart, rowpart_stride,
                            colpart_stride, sh);
+    }
+}
+
+// Up to 32 gradients per pass: two 16-wide column tiles of the MFMA over the same block of Q (gT[c][32]).  The A operands of the
+// column product (the gT rows of the strip, 64 x 32) live in LDS, shared by the four waves -- 64 registers per lane would not fit
+// beside the block and the eight row-sum accumulators at two waves per SIMD; every accumulator takes its MFMAs back to back (the
+// pipe forwards the accumulator it has just written: 68 cycles per MFMA against 74-83 in rotation).  Per vector the arithmetic is
+// k_symm_mfma's: the partial sums of 32 gradients are bit-identical to those of two 16-wide passes, in 0.445 ms against 0.55-0.62
+// (n = 16384, tools/experiments/symm32_queue.hip).
+constexpr int SMM_NV2 = 2 * SMM_NV;
+template <bool NT, int SEG>
+__device__ __forceinline__ void symm_tile2(const double* __restrict__ Q, long long ld, long long n, long long row0, long long I,
+                                           long long J, const double* __restrict__ gT, int lv, double* __restrict__ rowpart,
+                                           double* __restrict__ colpart, long long rowpart_stride, long long colpart_stride,
+                                           double (*sh)[SYMV_H * SMM_PITCH], double (*sgr)[SMM_NV2 + 1]) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lr = lane >> 4, lc = lane & 15;
+    const long long r0 = row0 + I * SYMV_H;
+    const long long c0 = J * SEG;
+    const bool full = c0 + SEG - 1 < r0;
+    for (int k = threadIdx.x; k < SYMV_H * SMM_NV2; k += 256) sgr[k / SMM_NV2][k % SMM_NV2] = gT[(r0 + k / SMM_NV2) * SMM_NV2 + k % SMM_NV2];
+    __syncthreads();
+    double4_t dr[2][4];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) dr[t][jj] = double4_t{0.0, 0.0, 0.0, 0.0};
+    const long long cend = (c0 + SEG < r0 + SYMV_H) ? c0 + SEG : r0 + SYMV_H;
+    const int nblk = (int)((cend - c0) / 16);
+    double* mysh = sh[wave];
+    const double* qbase = Q + (r0 + lr) * ld + lc;
+    for (int b = wave; b < nblk; b += 4) {
+        const long long cb = c0 + 16 * (long long)b;
+        double x[16], gc[2][4];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) x[j] = ld_stream<NT, double>(qbase + (long long)(4 * j) * ld + cb);
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) gc[t][kb] = gT[(cb + 4 * kb + lr) * SMM_NV2 + 16 * t + lc];
+        const bool diag = !full && cb + 15 >= r0;
+        double4_t dc[2] = {double4_t{0.0, 0.0, 0.0, 0.0}, double4_t{0.0, 0.0, 0.0, 0.0}};
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const long long r = r0 + 4 * j + lr, c = cb + lc;
+                const double below = (!diag || c < r) ? x[j] : 0.0;  // column sums: strictly below the diagonal
+                dc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(sgr[4 * j + lr][16 * t + lc], below, dc[t], 0, 0, 0);
+            }
+        if (diag) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const long long r = r0 + 4 * j + lr, c = cb + lc;
+                x[j] = (c <= r) ? x[j] : 0.0;  // row sums: the diagonal counts once, here
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 16; ++j) mysh[(4 * j + lr) * SMM_PITCH + lc] = x[j];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+                for (int kb = 0; kb < 4; ++kb) {
+                    const double tv = mysh[(16 * jj + lc) * SMM_PITCH + 4 * kb + lr];
+                    dr[t][jj] = __builtin_amdgcn_mfma_f64_16x16x4f64(gc[t][kb], tv, dr[t][jj], 0, 0, 0);
+                }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const double o[4] = {dc[t].x, dc[t].y, dc[t].z, dc[t].w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int v = 16 * t + lr + 4 * i;
+                if (v < lv) colpart[(long long)v * colpart_stride + I * n + cb + lc] = o[i];
+            }
+        }
+    }
+    __syncthreads();
+    double* red = &sh[0][0];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            const double o[4] = {dr[t][jj].x, dr[t][jj].y, dr[t][jj].z, dr[t][jj].w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) red[((wave * 4 + jj) * 4 + i) * 64 + lane] = o[i];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int v = 16 * t + lr + 4 * i;
+            const int jj = wave;
+            const double s0 = red[((0 * 4 + jj) * 4 + i) * 64 + lane], s1 = red[((1 * 4 + jj) * 4 + i) * 64 + lane];
+            const double s2 = red[((2 * 4 + jj) * 4 + i) * 64 + lane], s3 = red[((3 * 4 + jj) * 4 + i) * 64 + lane];
+            if (v < lv) rowpart[(long long)v * rowpart_stride + J * n + r0 + 16 * jj + lc] = ((s0 + s1) + s2) + s3;
+        }
+        __syncthreads();
+    }
+}
+
+template <bool NT, int SEG>
+__global__ __launch_bounds__(256, 2) void k_symm_mfma_q2(const double* __restrict__ Q, long long ld, long long n, long long row0,
+                                                         const double* __restrict__ gT, int lv, double* __restrict__ rowpart,
+                                                         double* __restrict__ colpart, long long rowpart_stride,
+                                                         long long colpart_stride, const DevState* __restrict__ st,
+                                                         const SymmTile* __restrict__ tiles, int ntiles,
+                                                         unsigned* __restrict__ queue) {
+    __shared__ double sh[4][SYMV_H * SMM_PITCH];
+    __shared__ double sgr[SYMV_H][SMM_NV2 + 1];  // the gT rows of the strip (odd pitch)
+    __shared__ int s_t;
+    if (st->halted) return;
+    Q -= row0 * ld;
+    for (;;) {
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const unsigned t = atomicAdd(queue, 1u);
+            s_t = t < (unsigned)ntiles ? (int)t : -1;
+        }
+        __syncthreads();
+        const int t = s_t;
+        if (t < 0) return;
+        symm_tile2<NT, SEG>(Q, ld, n, row0, (long long)tiles[t].I, (long long)tiles[t].J, gT, lv, rowpart, colpart, rowpart_stride,
+                            colpart_stride, sh, sgr);
     }
 }
 

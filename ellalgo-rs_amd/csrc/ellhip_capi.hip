@@ -69,7 +69,7 @@ struct Defaults {
     int fuse_dots = 1;         // ELLHIP_OPT_FUSE_DOTS
     int resident = 1;          // ELLHIP_OPT_RESIDENT
     int overlap = 1;           // ELLHIP_OPT_OVERLAP
-    int lookahead = 16;        // ELLHIP_OPT_LOOKAHEAD
+    int lookahead = 32;        // ELLHIP_OPT_LOOKAHEAD
     int queue_depth = 48;      // ELLHIP_OPT_QUEUE_DEPTH
     int stable_solve = 3;      // ELLHIP_OPT_STABLE_SOLVE
     int stable_factor = 2;     // ELLHIP_OPT_STABLE_FACTOR
@@ -135,7 +135,7 @@ struct ellhip_space {
     hipStream_t symv_stream = nullptr;
     // ... and with the GEMVs of up to `lookahead` consecutive queued cuts computed in ONE pass over Q_base (k_symv_multi,
     // ELLHIP_OPT_LOOKAHEAD): vector l of a group writes partial-sum set 2 + l (slices of one allocation)
-    int lookahead = 16;
+    int lookahead = 32;
     int queue_depth = 48;            // recorded updates a queue run on the group stage lets pile up before an apply pass (0: the handle's depth)
     double* d_rowpart_m = nullptr;   // [MULTI_MAX][nsegs][n]
     double* d_colpart_m = nullptr;   // [MULTI_MAX][nstrips][n]
@@ -537,6 +537,44 @@ int stable_mirror_leave(ellhip_space* s) {
 }
 
 // EllStable::update_core as a fixed sequence of launches (ellstable_kernels.hpp).
+// ---- one co-residency grid at a time per device ------------------------------------------------------------------------
+// Two kinds of launches here consist of workgroups that WAIT for one another inside the launch and therefore assume all of
+// them are on the device at once: a resident batch (k_ell_resident, one grid barrier per cut) and EllStable's persistent solves
+// (chain / helper workgroups).  Two such grids at the same time -- two handles, two host threads -- can each hold part of the
+// CUs and wait for workgroups of its own that the other keeps out: nothing hangs (every wait is bounded) but both time out.
+// So within this process they are chained per device: whoever issues one waits, ON THE DEVICE, for the event the previous one
+// left behind (hipStreamWaitEvent: no host synchronisation), and leaves its own.  Kernels that merely run long (the
+// matrix-core passes draw tiles from a queue and keep their CUs for a whole pass) delay such a grid, they cannot lock it.
+constexpr int CORES_MAX_DEVICES = 16;
+constexpr int CORES_RING = 64;
+struct CoresToken {
+    std::mutex m;
+    hipEvent_t ring[CORES_RING] = {};
+    unsigned next = 0;
+    hipEvent_t last = nullptr;
+};
+CoresToken g_cores[CORES_MAX_DEVICES];
+
+struct CoresScope {  // from before the first such launch of an API call until after the last one has been enqueued
+    CoresToken* t;
+    hipStream_t stream;
+    CoresScope(ellhip_space* s) : t(&g_cores[s->device & (CORES_MAX_DEVICES - 1)]), stream(s->stream) {
+        t->m.lock();
+        if (t->last) (void)hipStreamWaitEvent(stream, t->last, 0);
+    }
+    ~CoresScope() {
+        hipEvent_t& e = t->ring[t->next % CORES_RING];
+        if (!e && hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) e = nullptr;
+        if (e && hipEventRecord(e, stream) == hipSuccess) {
+            t->last = e;
+            t->next += 1;
+        }
+        t->m.unlock();
+    }
+    CoresScope(const CoresScope&) = delete;
+    CoresScope& operator=(const CoresScope&) = delete;
+};
+
 int ellstable_issue(ellhip_space* s, const double* g_dev, const CutParams* cp_dev, CutParams cp_val, int queue_mode,
                     int* qst, double* qtsq) {
     const long long n = s->n, ld = s->ld;
@@ -561,6 +599,9 @@ int ellstable_issue(ellhip_space* s, const double* g_dev, const CutParams* cp_de
     // (sentinel until stored, like the backward solve's qpub), everybody else the block's flag.  The published
     // vector therefore has to be all-sentinel when a solve starts: two buffers alternate by launch parity, and the
     // mid stage of every update re-arms the one the NEXT solve will use (whatever this update's status).
+    // (one co-residency grid at a time on the device: chained behind the previous one, CoresScope)
+    std::unique_ptr<CoresScope> alone;
+    if (persist) alone.reset(new CoresScope(s));
     if (persist) ++s->epoch;
     double* w = (persist && (s->epoch & 1)) ? w1 : w0;
     double* w_next = (persist && (s->epoch & 1)) ? w0 : w1;
@@ -727,7 +768,7 @@ int symv_alloc(ellhip_space* s) {
 
 // partial-sum sets of the lower-triangle GEMV: 0 = the handle's own, 1 = the second set of overlapped queue runs,
 // 2 + l = vector l of a k_symv_multi group
-constexpr int MULTI_MAX = 16;  // = SMM_NV
+constexpr int MULTI_MAX = 32;  // = GRP_MAX = 2 * SMM_NV: gradients per matrix-core pass at most
 constexpr int MULTI_VALU_MAX = 3;  // largest group k_symv_multi takes (vector ALU, bit-identical to k_symv)
 size_t rowpart_elems(const ellhip_space* s) { return (size_t)((s->n + s->symv_seg - 1) / s->symv_seg) * (size_t)s->n; }
 size_t colpart_elems(const ellhip_space* s) { return (size_t)((s->nrows + SYMV_H - 1) / SYMV_H) * (size_t)s->n; }
@@ -1537,7 +1578,7 @@ void multi_free(ellhip_space* s) {
     s->symm_ntiles = 0;
 }
 
-// The group runs' buffers: 2 x 16 sets of partial sums are 2.2 n^2 / 64 x 32 = 1.1 n^2 doubles-worth of memory beside
+// The group runs' buffers: 2 x 32 sets of partial sums (n^2 / 64 + n^2 / 2048 doubles each) are about n^2 doubles beside
 // the matrix' n^2 (4.4 GB at n = 32768).  When they do not fit, the handle continues with one product per pass
 // (returns MULTI_NO_MEMORY once; ELLHIP_OPT_LOOKAHEAD reads 1 afterwards): slower, not an error.
 int multi_setup(ellhip_space* s) {
@@ -1549,7 +1590,7 @@ int multi_setup(ellhip_space* s) {
     const size_t cbytes = (size_t)2 * MULTI_MAX * colpart_elems(s) * sizeof(double);
     hipError_t e = hipMalloc(&s->d_rowpart_m, rbytes);
     if (e == hipSuccess) e = hipMalloc(&s->d_colpart_m, cbytes);
-    if (e == hipSuccess) e = hipMalloc(&s->d_gT, (size_t)2 * s->n * SMM_NV * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc(&s->d_gT, (size_t)2 * s->n * MULTI_MAX * sizeof(double));
     if (e == hipSuccess) e = hipMalloc(&s->d_grpY, (size_t)GRP_MAX * (size_t)s->n * sizeof(double));
     if (e == hipSuccess) e = hipMalloc(&s->d_gpart, (size_t)GRP_MAX * nb * (MAXPEND + 1) * sizeof(double));
     if (e == hipSuccess) e = hipMalloc(&s->d_cpart, nb * GRP_MAX * GRP_MAX * sizeof(double));
@@ -1591,7 +1632,30 @@ int multi_setup(ellhip_space* s) {
         hipDeviceProp_t prop;
         HIPCHK(hipGetDeviceProperties(&prop, s->device));
         s->symm_ntiles = (int)tiles.size();
-        s->symm_wgs = (int)std::min<size_t>(tiles.size(), (size_t)3 * (size_t)prop.multiProcessorCount);
+        // two workgroups per CU is what the registers allow; more would only wait for the first ones to drain the queue
+        s->symm_wgs = (int)std::min<size_t>(tiles.size(), (size_t)2 * (size_t)prop.multiProcessorCount);
+        // The runtime loads a kernel at its first launch (~250 us for these): a short queue run must not meet that inside its
+        // own 20 cuts because the runs before it happened to stay below 17 cuts per group.  One empty launch each (no tiles).
+        const bool nt = s->sh_gemv.nt != 0, wide = s->symv_seg == SYMV_SEG;
+#define ELLHIP_SYMM_WARM(...)                                                                                                        \
+    hipLaunchKernelGGL((__VA_ARGS__), dim3(1), dim3(256), 0, s->stream, (const double*)s->d_Q, s->ld, s->n, s->row0,                 \
+                       (const double*)s->d_gT, 0, s->d_rowpart_m, s->d_colpart_m, (long long)rowpart_elems(s),                      \
+                       (long long)colpart_elems(s), (const DevState*)s->d_st, (const SymmTile*)s->d_symm_tiles, 0, s->d_symm_queue)
+        if (wide && nt) {
+            ELLHIP_SYMM_WARM(k_symm_mfma_q<true, SYMV_SEG>);
+            ELLHIP_SYMM_WARM(k_symm_mfma_q2<true, SYMV_SEG>);
+        } else if (wide) {
+            ELLHIP_SYMM_WARM(k_symm_mfma_q<false, SYMV_SEG>);
+            ELLHIP_SYMM_WARM(k_symm_mfma_q2<false, SYMV_SEG>);
+        } else if (nt) {
+            ELLHIP_SYMM_WARM(k_symm_mfma_q<true, SYMV_SEG_SMALL>);
+            ELLHIP_SYMM_WARM(k_symm_mfma_q2<true, SYMV_SEG_SMALL>);
+        } else {
+            ELLHIP_SYMM_WARM(k_symm_mfma_q<false, SYMV_SEG_SMALL>);
+            ELLHIP_SYMM_WARM(k_symm_mfma_q2<false, SYMV_SEG_SMALL>);
+        }
+#undef ELLHIP_SYMM_WARM
+        HIPCHK(hipGetLastError());
     }
     return 0;
 }
@@ -1629,7 +1693,7 @@ int group_stage_go(ellhip_space* s, long long i, int g, int half) {
     ProfScope ps(s, CLS_SCALAR);
     hipLaunchKernelGGL(k_group_gram, dim3(nb), dim3(256), 0, s->stream, s->n, g, (const double*)s->d_grpY, grads, s->n,
                        s->d_cpart, (const DevState*)s->d_st);
-    hipLaunchKernelGGL(k_group_sums<NP>, dim3((unsigned)g + 1), dim3(256), 0, s->stream, g, (int)nb, (const double*)s->d_gpart,
+    hipLaunchKernelGGL(k_group_sums<NP>, dim3((unsigned)g + GRP_MAX * GRP_MAX / 256), dim3(256), 0, s->stream, g, (int)nb, (const double*)s->d_gpart,
                        (const double*)s->d_cpart, s->d_gsums, (const DevState*)s->d_st);
     hipLaunchKernelGGL(k_group_scalar<NP>, dim3(1), dim3(64), 0, s->stream, g, (const double*)s->d_gsums, s->d_cpend, s->d_st,
                        EllCalcDev::make(s->n, s->use_parallel_cut), (const CutParams*)(s->d_qparams + i), s->npend,
@@ -1642,20 +1706,37 @@ int group_stage_go(ellhip_space* s, long long i, int g, int half) {
 
 template <int SEG>
 void symm_mfma_go(ellhip_space* s, const double* g_dev, int lv, hipStream_t st, int half) {
-    double* gT = s->d_gT + (size_t)half * (size_t)s->n * SMM_NV;
+    double* gT = s->d_gT + (size_t)half * (size_t)s->n * MULTI_MAX;
     double* rowp = s->d_rowpart_m + (size_t)half * MULTI_MAX * rowpart_elems(s);
     double* colp = s->d_colpart_m + (size_t)half * MULTI_MAX * colpart_elems(s);
     unsigned* queue = s->d_symm_queue + 32 * half;
-    hipLaunchKernelGGL(k_pack_grads, dim3((unsigned)((s->n * SMM_NV + 255) / 256)), dim3(256), 0, st, g_dev, s->n, lv, s->n, gT, queue);
-    if (s->sh_gemv.nt != 0)
-        hipLaunchKernelGGL((k_symm_mfma_q<true, SEG>), dim3((unsigned)s->symm_wgs), dim3(256), 0, st, (const double*)s->d_Q, s->ld, s->n,
-                           s->row0, (const double*)gT, lv, rowp, colp, (long long)rowpart_elems(s), (long long)colpart_elems(s),
-                           (const DevState*)s->d_st, (const SymmTile*)s->d_symm_tiles, s->symm_ntiles, queue);
-    else
-        hipLaunchKernelGGL((k_symm_mfma_q<false, SEG>), dim3((unsigned)s->symm_wgs), dim3(256), 0, st, (const double*)s->d_Q, s->ld, s->n,
-                           s->row0, (const double*)gT, lv, rowp, colp, (long long)rowpart_elems(s), (long long)colpart_elems(s),
-                           (const DevState*)s->d_st, (const SymmTile*)s->d_symm_tiles, s->symm_ntiles, queue);
+    const int nvw = lv > SMM_NV ? SMM_NV2 : SMM_NV;  // one or two 16-wide column tiles
+    hipLaunchKernelGGL(k_pack_grads, dim3((unsigned)((s->n * nvw + 255) / 256)), dim3(256), 0, st, g_dev, s->n, lv, s->n, gT, queue, nvw);
+    const bool nt = s->sh_gemv.nt != 0;
+#define ELLHIP_SYMM_Q(...)                                                                                                          \
+    hipLaunchKernelGGL((__VA_ARGS__), dim3((unsigned)s->symm_wgs), dim3(256), 0, st, (const double*)s->d_Q, s->ld, s->n, s->row0,        \
+                       (const double*)gT, lv, rowp, colp, (long long)rowpart_elems(s), (long long)colpart_elems(s),                 \
+                       (const DevState*)s->d_st, (const SymmTile*)s->d_symm_tiles, s->symm_ntiles, queue)
+    if (nvw == SMM_NV) {
+        if (nt) ELLHIP_SYMM_Q(k_symm_mfma_q<true, SEG>);
+        else ELLHIP_SYMM_Q(k_symm_mfma_q<false, SEG>);
+    } else {
+        if (nt) ELLHIP_SYMM_Q(k_symm_mfma_q2<true, SEG>);
+        else ELLHIP_SYMM_Q(k_symm_mfma_q2<false, SEG>);
+    }
+#undef ELLHIP_SYMM_Q
 }
+// How many of the `rem` cuts up to the next apply pass (or the end of the run) go into the next group, `cap` = what the handle's
+// lookahead and the kernels allow.  A matrix-core pass costs about the same for 4 gradients as for 16 (0.27 ms at n = 16384) and
+// 0.40-0.45 for 17-32 (two column tiles over the same block of Q), so: as many as fit; and where only the 16-wide pass is allowed
+// and more than one but less than two full groups are left, two even groups rather than a full one and a small one (the first
+// group's stage then overlaps a pass that carries its share).
+long long group_size(const ellhip_space* s, long long cap, long long rem) {
+    long long g = std::min(cap, rem);
+    if (multi_mfma(s) && cap <= SMM_NV && rem > cap && rem < 2 * cap) g = (rem + 1) / 2;
+    return g;
+}
+
 int symm_go(ellhip_space* s, const double* g_dev, int lv, hipStream_t st, int half) {
     ProfScope ps(s, CLS_SYMV, st);
     if (s->symv_seg == SYMV_SEG) symm_mfma_go<SYMV_SEG>(s, g_dev, lv, st, half);
@@ -1712,10 +1793,7 @@ int queue_run_multi(ellhip_space* s, long long first, long long count) {
             const long long room = (long long)qdepth - s->npend;  // cuts that can still be recorded before the apply pass
             const long long cap = std::min<long long>(s->lookahead, multi_mfma(s) ? MULTI_MAX : MULTI_VALU_MAX);
             const long long rem = std::min(end - i, room);  // cuts up to the next apply pass or the end of the run
-            g = std::min(cap, rem);
-            // a matrix-core pass costs the same for 4 gradients as for 16: what is left goes into two even groups rather
-            // than a full one and a small one (the first group's stage then overlaps a pass that carries its share)
-            if (multi_mfma(s) && rem > cap && rem < 2 * cap) g = (rem + 1) / 2;
+            g = group_size(s, cap, rem);
         }
         if (g <= 1 && !s->sharded) {  // a cut primed earlier, the last one before an apply pass, the last one of the run
             if (s->npend >= s->defer) {  // (the per-cut kernels hold `depth` recorded updates)
@@ -1744,8 +1822,7 @@ int queue_run_multi(ellhip_space* s, long long first, long long count) {
             long long g2 = 0;
             if (i2 < end && room2 > 0) {
                 const long long cap2 = std::min<long long>(s->lookahead, cap), rem2 = std::min(end - i2, room2);
-                g2 = std::min(cap2, rem2);
-                if (rem2 > cap2 && rem2 < 2 * cap2) g2 = (rem2 + 1) / 2;  // (the rule the next trip of the loop applies)
+                g2 = group_size(s, cap2, rem2);  // (the rule the next trip of the loop applies)
             }
             if (use_side && g2 >= 2) {
                 rc = side_fork(s);  // after this group's products, the last reader of the other half, every writer of Q so far
@@ -1848,10 +1925,7 @@ bool resident_ok(ellhip_space* s, long long count) {
     return s->rs_R > 0;
 }
 
-// one resident grid per device at a time within this process (two of them cannot both be co-resident: each wants a workgroup
-// on nearly every CU and would wait for the other's to leave); held from the launch until the batch has finished
-constexpr int RS_MAX_DEVICES = 16;
-std::mutex g_resident_mutex[RS_MAX_DEVICES];
+// (one resident grid per device at a time within this process, and none beside an EllStable persistent solve: CoresScope)
 constexpr int RS_FALLBACK = 1;  // resident_run: the batch did not run (or was abandoned and undone): take the streamed schedule
 
 // One batch = one cooperative launch.  The call returns when the batch has finished (one stream synchronisation per
@@ -1895,7 +1969,7 @@ int resident_run(ellhip_space* s, long long first, long long count) {
     A.calc = EllCalcDev::make(s->n, s->use_parallel_cut);
     A.fault_at = s->rs_fault_at;
     const unsigned G = (unsigned)(s->rs_S * (s->rs_S + 1) / 2);
-    std::lock_guard<std::mutex> one_resident_grid_per_device(g_resident_mutex[s->device & (RS_MAX_DEVICES - 1)]);
+    CoresScope alone(s);  // (held until the batch has finished: the function synchronises the stream before it returns)
     hipLaunchKernelGGL(k_rs_prepare, dim3((unsigned)std::max<long long>(1, std::min<long long>(32, s->n / 256))), dim3(256), 0, s->stream,
                        (const double*)s->d_xc, s->d_rs_xc0, s->n, (const DevState*)s->d_st, s->d_rs_st0, s->d_rs_bar);
     HIPCHK(hipGetLastError());
@@ -1906,7 +1980,7 @@ int resident_run(ellhip_space* s, long long first, long long count) {
         // ELLHIP_OPT_RESIDENT = 1 (default): a cooperative launch -- the runtime refuses a grid that cannot be co-resident and
         // runs one cooperative grid at a time, across processes too; measured at the plain launch's speed (n = 4096, 200 cuts
         // per batch: 1.84 vs 1.87 ms).  2: a plain launch, for a stack without cooperative launches.  Either way the batches
-        // of this process are serialised per device by g_resident_mutex (held by the caller until the batch has finished),
+        // of this process are serialised per device by CoresScope (held here until the batch has finished),
         // and whatever still keeps workgroups out ends in the bounded waits giving up: the batch is abandoned as a whole
         // and rerun on the streamed schedule (below).
         hipError_t e;
@@ -2394,7 +2468,7 @@ int option_ok(int key, long long v) {
             return (v == 0 || v == 1) ? 0 : fail(ELLHIP_E_INVALID, "option value must be 0 or 1");
         case ELLHIP_OPT_RESIDENT: return (v >= 0 && v <= 2) ? 0 : fail(ELLHIP_E_INVALID, "ELLHIP_OPT_RESIDENT: 0, 1 or 2");
         case ELLHIP_OPT_OVERLAP: return (v >= 0 && v <= 2) ? 0 : fail(ELLHIP_E_INVALID, "ELLHIP_OPT_OVERLAP: 0, 1 or 2");
-        case ELLHIP_OPT_LOOKAHEAD: return (v >= 1 && v <= 16) ? 0 : fail(ELLHIP_E_INVALID, "ELLHIP_OPT_LOOKAHEAD: 1 .. 16");
+        case ELLHIP_OPT_LOOKAHEAD: return (v >= 1 && v <= 32) ? 0 : fail(ELLHIP_E_INVALID, "ELLHIP_OPT_LOOKAHEAD: 1 .. 32");
         case ELLHIP_OPT_QUEUE_DEPTH: return (v == 0 || v == 48) ? 0 : fail(ELLHIP_E_INVALID, "ELLHIP_OPT_QUEUE_DEPTH: 0 or 48");
         case ELLHIP_OPT_RESIDENT_FAULT: return v >= -1 ? 0 : fail(ELLHIP_E_INVALID, "ELLHIP_OPT_RESIDENT_FAULT: -1 or a cut index");
         case ELLHIP_OPT_SYMV_MIN_N: return v >= 512 ? 0 : fail(ELLHIP_E_INVALID, "ELLHIP_OPT_SYMV_MIN_N must be >= 512");

@@ -21,7 +21,7 @@
 
 namespace ellhip {
 
-constexpr int GRP_MAX = 16;  // cuts per group (= SMM_NV)
+constexpr int GRP_MAX = 32;  // cuts per group (= 2 * SMM_NV: one k_symm_mfma_q<.., .., 2> pass carries two 16-wide column tiles)
 
 struct GroupOut {
     double cd[GRP_MAX][MAXPEND];  // cd[l][j] = c_j d_jl: the correction factors of cut l (0 for empty slots)
@@ -79,35 +79,56 @@ __global__ __launch_bounds__(256) void k_group_dots(long long n, const double* _
     }
 }
 
-// cpart[b][m][l] = slice (128 columns) of y_m . g_l, m < l
+// cpart[b][m][l] = slice (128 columns) of y_m . g_l, m < l.  The slice passes through LDS in two halves of 64 columns (32 cuts x 128
+// columns x 2 arrays would not fit the 64 KiB a kernel may declare); every (m, l) keeps ONE running sum over the 128 columns in
+// ascending order, so the bits do not depend on the halves.
 __global__ __launch_bounds__(256) void k_group_gram(long long n, int G, const double* __restrict__ Y,
                                                     const double* __restrict__ g, long long g_stride,
                                                     double* __restrict__ cpart, const DevState* __restrict__ st) {
-    __shared__ double sy[GRP_MAX][128];
-    __shared__ double sg[GRP_MAX][129];  // (odd pitch: the threads of one m read 16 different l at the same column)
+    __shared__ double sy[GRP_MAX][64];
+    __shared__ double sg[GRP_MAX][65];  // (odd pitch: the threads of one m read different l at the same column)
     if (st->halted) return;
     const int tid = threadIdx.x;
-    const long long base = (long long)blockIdx.x * 128;
-    for (int idx = tid; idx < G * 128; idx += 256) {
-        const int l = idx >> 7, c = idx & 127;
-        const long long i = base + c;
-        sy[l][c] = i < n ? Y[(long long)l * n + i] : 0.0;
-        sg[l][c] = i < n ? g[(long long)l * g_stride + i] : 0.0;
-    }
-    __syncthreads();
-    for (int t = tid; t < G * G; t += 256) {
-        const int m = t / G, l = t - m * G;
-        double s = 0.0;
-        if (m < l) {
-#pragma unroll 8
-            for (int c = 0; c < 128; ++c) s += sy[m][c] * sg[l][c];
+    constexpr int PAIRS = GRP_MAX * GRP_MAX / 256;  // (m, l) pairs per thread at most
+    double acc[PAIRS];
+#pragma unroll
+    for (int q = 0; q < PAIRS; ++q) acc[q] = 0.0;
+    for (int h = 0; h < 2; ++h) {
+        const long long base = (long long)blockIdx.x * 128 + 64 * h;
+        if (h) __syncthreads();
+        for (int idx = tid; idx < G * 64; idx += 256) {
+            const int l = idx >> 6, c = idx & 63;
+            const long long i = base + c;
+            sy[l][c] = i < n ? Y[(long long)l * n + i] : 0.0;
+            sg[l][c] = i < n ? g[(long long)l * g_stride + i] : 0.0;
         }
-        cpart[(long long)blockIdx.x * (GRP_MAX * GRP_MAX) + m * GRP_MAX + l] = s;
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < PAIRS; ++q) {
+            const int t = tid + 256 * q;
+            if (t < G * G) {
+                const int m = t / G, l = t - m * G;
+                if (m < l) {
+                    double s = acc[q];
+#pragma unroll 8
+                    for (int c = 0; c < 64; ++c) s += sy[m][c] * sg[l][c];
+                    acc[q] = s;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < PAIRS; ++q) {
+        const int t = tid + 256 * q;
+        if (t < G * G) {
+            const int m = t / G, l = t - m * G;
+            cpart[(long long)blockIdx.x * (GRP_MAX * GRP_MAX) + m * GRP_MAX + l] = acc[q];
+        }
     }
 }
 
-// Column sums of the slices: workgroup l < G adds gpart[l][0 .. nb)[0 .. NP] (contiguous: coalesced), workgroup G adds
-// cpart[0 .. nb)[m][l'].  sums: [G][NP + 1] then [GRP_MAX][GRP_MAX].  Thread (c, q) adds rows q, q + R, ... of column c in
+// Column sums of the slices: workgroup l < G adds gpart[l][0 .. nb)[0 .. NP] (contiguous: coalesced), workgroups G .. G + 3 add
+// cpart[0 .. nb)[m][l'], 256 of its GRP_MAX^2 columns each (grid = G + GRP_MAX^2 / 256).  sums: [G][NP + 1] then [GRP_MAX][GRP_MAX].  Thread (c, q) adds rows q, q + R, ... of column c in
 // ascending order, the R partial sums are combined in index order.
 template <int NP>
 __global__ __launch_bounds__(256) void k_group_sums(int G, int nb, const double* __restrict__ gpart,
@@ -132,23 +153,29 @@ __global__ __launch_bounds__(256) void k_group_sums(int G, int nb, const double*
             for (int r = 1; r < R; ++r) sum += red[r * W + tid];
             sums[l * W + tid] = sum;
         }
-    } else {  // the Gram slices: 256 columns (m, l'), one per thread, rows in ascending order, four running sums
-        const double* p = cpart + tid;
+    } else {  // the Gram slices: one column (m, l') per thread, rows in ascending order, four running sums
+        constexpr int W2 = GRP_MAX * GRP_MAX;
+        const int col = (l - G) * 256 + tid;
+        if (col / GRP_MAX >= G || col % GRP_MAX >= G) {  // (beyond the group: nobody reads it)
+            sums[G * (NP + 1) + col] = 0.0;
+            return;
+        }
+        const double* p = cpart + col;
         double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
         int b = 0;
         for (; b + 3 < nb; b += 4) {
-            const double v0 = p[(long long)b * 256], v1 = p[(long long)(b + 1) * 256];
-            const double v2 = p[(long long)(b + 2) * 256], v3 = p[(long long)(b + 3) * 256];
+            const double v0 = p[(long long)b * W2], v1 = p[(long long)(b + 1) * W2];
+            const double v2 = p[(long long)(b + 2) * W2], v3 = p[(long long)(b + 3) * W2];
             a0 += v0, a1 += v1, a2 += v2, a3 += v3;
         }
-        for (; b < nb; ++b) a0 += p[(long long)b * 256];
-        sums[G * (NP + 1) + tid] = (a0 + a1) + (a2 + a3);
+        for (; b < nb; ++b) a0 += p[(long long)b * W2];
+        sums[G * (NP + 1) + col] = (a0 + a1) + (a2 + a3);
     }
 }
 
 // One wave: cut by cut omega, EllCalc (src/ell_calc.rs:627-931 through EllCalcDev::dispatch), the correction factors and
 // the dot products of the vector the cut records with the gradients still to come.  Lane j looks after recorded slot j
-// (NP + GRP_MAX <= 64).  Queue semantics as k_scalar_apply_def: the first cut that is not Success halts the queue,
+// (slot0 + G <= the run's depth <= MAXPEND <= 64: a group never reaches across an apply pass), lane t < G after cut t.  Queue semantics as k_scalar_apply_def: the first cut that is not Success halts the queue,
 // every later one reports ELLHIP_UNKNOWN (src/cutting_plane.rs:222,308).
 template <int NP>
 __global__ __launch_bounds__(64) void k_group_scalar(int G, const double* __restrict__ sums, double* __restrict__ cpend,
@@ -156,7 +183,7 @@ __global__ __launch_bounds__(64) void k_group_scalar(int G, const double* __rest
                                                      const CutParams* __restrict__ cp_dev, int slot0,
                                                      int* __restrict__ q_status, double* __restrict__ q_tsq,
                                                      GroupOut* __restrict__ out) {
-    static_assert(NP + GRP_MAX <= 64, "one lane per recorded slot");
+    static_assert(MAXPEND <= 64 && GRP_MAX <= 64 && NP <= MAXPEND, "one lane per recorded slot, one per cut of the group");
     __shared__ double A[GRP_MAX];
     __shared__ double B[NP][GRP_MAX];
     __shared__ double C[GRP_MAX][GRP_MAX];

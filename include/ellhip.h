@@ -240,16 +240,19 @@ int ellhip_set_shard_symmetric(ellhip_space *s, int flag);
  *                                                    they read Q_base, which the cuts being taken do not change -- are issued
  *                                                    on a second stream beside the current reduction + scalar stage; same
  *                                                    results as 0 to the bit (same kernels, operands and summation order)
- *   ELLHIP_OPT_LOOKAHEAD         1 .. 16    16       Ell, ellhip_queue_run_fused on the lower-triangle schedule: the GEMVs of up to
+ *   ELLHIP_OPT_LOOKAHEAD         1 .. 32    32       Ell, ellhip_queue_run_fused on the lower-triangle schedule: the GEMVs of up to
  *                                                    this many consecutive QUEUED cuts are formed in one pass over Q_base
  *                                                    (they all refer to the same matrix until the next apply pass):
  *                                                    (4 / L) n^2 bytes per update instead of 4 n^2.  L <= 3: vector-ALU
  *                                                    kernel, bit-identical to 1; L > 3 (n a multiple of 64): FP64 matrix
  *                                                    cores, y differs by a few ulp from the other schedules (own
- *                                                    association; inside the 1e-10 contract).  Only a queue knows the
+ *                                                    association; inside the 1e-10 contract); groups of 17 .. 32 ride on
+ *                                                    ONE pass with two 16-wide column tiles (the products are those of
+ *                                                    two 16-wide passes to the bit).  Only a queue knows the
  *                                                    next gradients: ellhip_update and the prime / cut / commit calls are
- *                                                    unaffected.  The group runs need 1.1 n^2 doubles of extra device
- *                                                    memory (2 x 16 sets of partial sums); a handle for which that does not
+ *                                                    unaffected.  The group runs need about n^2 doubles of extra device
+ *                                                    memory -- as much as the matrix (2 x 32 sets of partial sums of
+ *                                                    n^2 / 62 doubles each); a handle for which that does not
  *                                                    fit continues with 1 (and reports 1 here)
  *   ELLHIP_OPT_QUEUE_DEPTH       0 / 48     48       Ell, depth 24, LOOKAHEAD > 3: inside one ellhip_queue_run_fused call the
  *                                                    recorded updates may pile up to 48 before an apply pass (the group

@@ -45,7 +45,7 @@ def orc():
 
 
 FACTORY_DEFAULTS = {"AUTO_DEFER": 1, "SYMV": 1, "SYMV_MIN_N": 5120, "APPLY_LOWER": 1, "APPLY_KERNEL": -1, "FUSE_DOTS": 1,
-                    "STABLE_SOLVE": 3, "STABLE_FACTOR": 2, "PAD": -1, "LP_GRID": 0, "LP_WIDE": -1, "BATCH_THREADS": 0, "RESIDENT": 1, "OVERLAP": 1, "LOOKAHEAD": 16, "QUEUE_DEPTH": 48, "STAGE_DIRECT": 1}
+                    "STABLE_SOLVE": 3, "STABLE_FACTOR": 2, "PAD": -1, "LP_GRID": 0, "LP_WIDE": -1, "BATCH_THREADS": 0, "RESIDENT": 1, "OVERLAP": 1, "LOOKAHEAD": 32, "QUEUE_DEPTH": 48, "STAGE_DIRECT": 1}
 
 
 @pytest.fixture(autouse=True)

@@ -98,7 +98,7 @@ static int queue_replay() {
     a.queue_run(17, k - 17);
     auto [st, ts] = a.queue_results();
     double worst = 0.0;
-    bool ok = a.option(ELLHIP_OPT_LOOKAHEAD) == 16 && a.defer_depth() == 24;
+    bool ok = a.option(ELLHIP_OPT_LOOKAHEAD) == 32 && a.defer_depth() == 24;
     for (size_t i = 0; i < k; ++i) {
         Arr g(grads.begin() + i * n, grads.begin() + (i + 1) * n);
         CutStatus s = (i % 2) ? b.update_bias_cut(std::make_pair(g, ParallelCut{b0[i], std::optional<double>(b1[i])}))

@@ -22,6 +22,12 @@ def test_passes_over_q_with_lookahead():
     assert g(24, 24, 16) == 2          # 12 + 12 rather than 16 + 8
     assert g(100, 24, 1) == 100        # one product per pass
     assert g(10, 24, 3) == 4           # vector-ALU groups: 3 3 3 1 (no even split below lookahead 4)
+    # lookahead 32 (the default): groups of 17 .. 32 ride on one pass with two column tiles
+    assert g(20, 48, 32) == 1          # the driver's 20 steps: one pass
+    assert g(48, 48, 32) == 2          # 32 + 16
+    assert g(200, 48, 32) == 9         # 4 x (32 16) + 8
+    assert g(96, 48, 32) == 4
+    assert g(33, 48, 32) == 2          # 32 + 1
 
 
 def test_bytes_per_update():

@@ -43,7 +43,7 @@ def test_headline_workload_contract():
     assert d["config"]["workload"] == "n16384-parallel" and d["scaling"] == "strong"
     assert abs(d["value"] - 1e3 / d["ms_per_step"]) < 1e-6 * d["value"]
     r = d["roofline"]
-    assert r["kernel"] == "k_symm_mfma" and r["traffic"] and 0.2 < r["frac"] < 1.0 and d["config"]["lookahead"] == 16 and d["config"]["queue_depth"] == 48
+    assert r["kernel"] == "k_symm_mfma" and r["traffic"] and 0.2 < r["frac"] < 1.0 and d["config"]["lookahead"] == 32 and d["config"]["queue_depth"] == 48
     assert abs(r["alg_bytes_per_launch"] - 4.0 * 16384 ** 2) < 1.0     # lower triangle: 4 n^2 bytes
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] == 1 and c["unit"] == "updates/s" and c["value"] > 0 and c["sample"]
@@ -55,7 +55,7 @@ def test_headline_workload_contract():
     assert ll["steps"] == 30 and ll["rc"] == 0 and ll["plain_niter"] == ll["pipelined_niter"] == 78
     assert ll["plain_iterations_per_s"] > 1000 and ll["pipelined_iterations_per_s"] > 1000 and ll["defer_depth"] == 24
     cfg = d["config"]
-    assert cfg["value_requires_future_gradients"] == 16 and cfg["live_loop_updates_per_s"] == ll["plain_iterations_per_s"]
+    assert cfg["value_requires_future_gradients"] == 32 and cfg["live_loop_updates_per_s"] == ll["plain_iterations_per_s"]
     assert cfg["host_call_updates_per_s"] == d["host_call_path"]["updates_per_s_depth24"]
     assert cfg["live_loop_updates_per_s"] < d["value"]
     assert cfg["steady_state_updates_per_s"] > 0.8 * d["value"]      # (192 more steps of the timed schedule beside a 16-step region)
@@ -63,7 +63,7 @@ def test_headline_workload_contract():
     # the as-run figure (the next group's products overlap this group's stage) and the kernel by itself
     assert r["isolated"]["kernel"] == "k_symm_mfma" and 0.3 < r["isolated"]["frac"] < 1.0
     assert r["per_kernel_isolated"]["symv"]["avg_ms"] > 0
-    # 16 timed steps, lookahead 16: ONE pass over Q (a group of 16) and ONE apply pass (the flush at the end):
+    # 16 timed steps, lookahead 32: ONE pass over Q (a group of 16) and ONE apply pass (the flush at the end):
     # (1 * 4 n^2 + 1 * 8 n^2) / 16 = 0.75 n^2 per update
     assert abs(r["whole_update"]["alg_bytes_per_gpu"] - 0.75 * 16384 ** 2) < 1.0
     # the default invocation carries BASELINE.json's other configurations in the same line
@@ -74,9 +74,9 @@ def test_headline_workload_contract():
         ro = o["roofline"]
         assert 0.0 < ro["frac"] < 1.0 and ro["kernel"] and 0.0 < ro["whole_update"]["frac"] < 1.0
     assert oc["n32768-deep"]["defer_depth"] == 24 and oc["n4096-deep"]["defer_depth"] == 8
-    # 96 steps, lookahead 16, up to 48 recorded inside a run: groups 16 16 16 | 16 16 16 and two apply passes,
-    # (6 * 4 + 2 * 8) / 96 = 0.41667
-    assert abs(oc["n32768-deep"]["roofline"]["whole_update"]["alg_bytes"] - (40.0 / 96.0) * 32768 ** 2) < 4.0
+    # 96 steps, lookahead 32, up to 48 recorded inside a run: groups 32 16 | 32 16 and two apply passes,
+    # (4 * 4 + 2 * 8) / 96 = 0.33333
+    assert abs(oc["n32768-deep"]["roofline"]["whole_update"]["alg_bytes"] - (32.0 / 96.0) * 32768 ** 2) < 4.0
 
 
 @pytest.mark.parametrize("workload,args", [("n4096-deep", ("--steps", "40", "--warmup", "8", "--compare-steps", "0")),

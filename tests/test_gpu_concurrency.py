@@ -1,7 +1,8 @@
 """GPU: several handles driven from several host threads at once on one card -- what BSearchAdaptor's clone per probe
 (src/cutting_plane.rs:409-418) turns into when probes run in parallel.  Every kernel family that waits inside a launch is in the
 mix: resident batches (a grid barrier per cut: cooperative launch, one grid at a time, commit-or-abandon), EllStable's persistent
-solves (workgroups wait for workgroups dispatched before them), and the streamed queue runs with their second stream.  Whatever the
+solves (workgroups wait for workgroups dispatched before them; two handles of them), and the streamed queue runs whose matrix-core
+passes keep every CU for a whole pass (k_symm_mfma_q).  Grids that wait inside a launch are chained per device (CoresScope).  Whatever the
 interleaving, every handle must end in the state the oracle's plain sequence of updates gives (1e-10); a resident batch may be
 abandoned and rerun (counted), nothing may fail."""
 import threading
@@ -15,7 +16,7 @@ from util import TOL, assert_state_close, oracle_update, random_factor
 pytestmark = pytest.mark.gpu
 
 
-def test_four_threads_four_kernel_families(gpu, orc):
+def test_five_threads_four_kernel_families(gpu, orc):
     from ellalgo_rs_amd import synth
     jobs = []
 
@@ -77,6 +78,7 @@ def test_four_threads_four_kernel_families(gpu, orc):
     jobs.append(resident_job(4096, 72, 12, 11))
     jobs.append(resident_job(2048, 96, 8, 12))
     jobs.append(stable_job(4096, 40, 13))
+    jobs.append(stable_job(3072, 50, 15))   # (two EllStable handles: two sets of persistent solves -- chained per device, CoresScope)
     jobs.append(queue_job(8192, 60, 14))
     start = threading.Barrier(len(jobs))
     errs = []

@@ -68,14 +68,14 @@ def _drive(gpu, orc, n, cuts, make_cut, seed):
         # pass on the matrix cores, and their dot products with the vectors the group itself records through the Gram-matrix
         # recurrence (csrc/group_kernels.hpp) -- the cancellation-prone place, were there one.
         eq = gpu.Ell.new_with_scalar(1.0, np.zeros(n))
-        assert eq.defer_depth == 24 and eq.get_option(gpu.capi.OPT_LOOKAHEAD) == 16
+        assert eq.defer_depth == 24 and eq.get_option(gpu.capi.OPT_LOOKAHEAD) == 32
         eq.queue_upload(np.array(rec["kinds"], dtype=np.int32), np.array(rec["grads"]), np.array(rec["b0"]), np.array(rec["b1"]))
         eq.queue_run(0, cuts, fused=True)
         st, ts = eq.queue_results()
         assert list(st) == rec["status"]
         aq = _errs(eq, o)
         aq["tsq"] = float(np.max(np.abs(ts - np.array(rec["tsq"])) / np.abs(np.array(rec["tsq"]))))
-        print(f"  {'':>{len(str(n)) + 9}}queue run, lookahead 16: errors {aq}")
+        print(f"  {'':>{len(str(n)) + 9}}queue run, lookahead 32: errors {aq}")
         for key in a1:
             assert aq[key] <= max(FACTOR_QUEUE * a1[key], FLOOR), ("queue", key, aq[key], a1[key])
     return a1, ad

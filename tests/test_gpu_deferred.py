@@ -541,7 +541,7 @@ def test_every_per_handle_option_round_trips(gpu):
     APPLY_LOWER and APPLY_KERNEL were silently stored into QUEUE_DEPTH, unvalidated)."""
     capi = gpu.capi
     ell_keys = {"SYMV": [0, 1], "SYMV_MIN_N": [512, 4096, 5120], "APPLY_LOWER": [0, 1], "APPLY_KERNEL": [0, 1, 2, -1],
-                "FUSE_DOTS": [0, 1], "RESIDENT": [0, 1], "OVERLAP": [0, 1], "LOOKAHEAD": [1, 3, 16], "QUEUE_DEPTH": [0, 48]}
+                "FUSE_DOTS": [0, 1], "RESIDENT": [0, 1], "OVERLAP": [0, 1], "LOOKAHEAD": [1, 3, 16, 32], "QUEUE_DEPTH": [0, 48]}
     e = gpu.Ell.new_with_scalar(1.0, np.zeros(640))
     snapshot = lambda s, keys: {k: s.get_option(getattr(capi, "OPT_" + k)) for k in keys}
     for name, values in ell_keys.items():
@@ -551,7 +551,7 @@ def test_every_per_handle_option_round_trips(gpu):
             after = snapshot(e, ell_keys)
             before[name] = v
             assert after == before, (name, v)
-    for name, bad in (("QUEUE_DEPTH", 4096), ("LOOKAHEAD", 17), ("APPLY_KERNEL", 3), ("SYMV_MIN_N", 8), ("SYMV", 2)):
+    for name, bad in (("QUEUE_DEPTH", 4096), ("LOOKAHEAD", 33), ("APPLY_KERNEL", 3), ("SYMV_MIN_N", 8), ("SYMV", 2)):
         with pytest.raises(Exception):
             e.set_option(getattr(capi, "OPT_" + name), bad)
     # the handle still works, on the schedule the options describe

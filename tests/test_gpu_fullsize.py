@@ -57,7 +57,7 @@ def test_first_update_closed_form_and_symmetry(gpu, orc, cuts):
     assert abs(e.tsq() - want_tsq) <= 1e-11 * abs(want_tsq)
 
 
-@pytest.mark.parametrize("lookahead", [3, 16])
+@pytest.mark.parametrize("lookahead", [3, 16, 32])
 def test_pipelined_equals_two_pass_at_full_size(gpu, cuts, lookahead):
     """The pipelined queue run forms the products of up to `lookahead` queued cuts in one pass over Q: up to 3 on the
     vector ALU with k_symv's arithmetic (bit-identical to the two-pass run), the default 16 on the matrix cores with the
@@ -142,8 +142,8 @@ def _close_in_blocks(qg, qo, tol, what):
 
 def test_ell_default_schedule_matches_oracle_at_full_size(gpu, orc):
     """The timed configuration itself (n = 16384, parallel cuts, a depth-24 handle's pipelined queue run: the products of
-    16 queued cuts per pass over the lower triangle on the matrix cores, the group stage, up to 48 recorded updates applied
-    as one rank-48 update) against the CPU oracle on the same 60 cuts -- groups of 16, 16, 16, an apply pass at cut 48,
+    up to 32 queued cuts per pass over the lower triangle on the matrix cores, the group stage, up to 48 recorded updates applied
+    as one rank-48 update) against the CPU oracle on the same 60 cuts -- groups of 32, 16, an apply pass at cut 48,
     a group of 12 still recorded when the state is read.  Whole state to the north-star tolerance.
     (The checker is the oracle's row-parallel loop `update_rowwise_mt`, used here for speed only: the reference's loop
     order takes seconds per update at this size; tests/test_oracle_pins.py ties it bit for bit to the reference loop
@@ -154,7 +154,7 @@ def test_ell_default_schedule_matches_oracle_at_full_size(gpu, orc):
     kinds, grads, b0, b1 = synth.parallel_cuts(N, k)
     e = gpu.Ell.new_with_scalar(1.0, np.zeros(N))
     assert e.defer_depth == 24          # what a new handle of this size starts with
-    assert e.get_option(gpu.capi.OPT_LOOKAHEAD) == 16 and e.get_option(gpu.capi.OPT_QUEUE_DEPTH) == 48
+    assert e.get_option(gpu.capi.OPT_LOOKAHEAD) == 32 and e.get_option(gpu.capi.OPT_QUEUE_DEPTH) == 48
     e.queue_upload(kinds, grads, b0, b1)
     e.queue_run(0, k, fused=True)
     st, ts = e.queue_results()
@@ -235,8 +235,8 @@ def test_ell_n32768_matches_oracle(gpu, orc):
 
 def test_ell_n32768_default_queue_run_matches_oracle(gpu, orc):
     """The configuration bench.py times as `n32768-deep` (BASELINE config 4's size on ONE GPU, Q = 8 GiB): 56 deep cuts
-    through `queue_run(fused=True)` at the defaults of a new handle of this size -- depth 24, lookahead 16, 48 recorded
-    updates per apply pass: groups of 16, 16, 16 on the matrix cores (k_symm_mfma on its 512 x 16 grid), the group stage
+    through `queue_run(fused=True)` at the defaults of a new handle of this size -- depth 24, lookahead 32, 48 recorded
+    updates per apply pass: groups of 32, 16 on the matrix cores (k_symm_mfma_q2 / k_symm_mfma_q drawing the 64 x 2048 tiles from their queue), the group stage
     sized for 48 slots, the in-run rank-48 apply pass (k_apply_mfma<48> on 512 x 32), a group of 8 left recorded when the
     state is read -- against the oracle's row-parallel loop (tests/test_oracle_pins.py ties it bit for bit to the reference
     loop order): every cut's tsq, xc, kappa, and three 512-row bands of Q (8 GiB each side: bands bound the temporaries)."""
@@ -245,13 +245,13 @@ def test_ell_n32768_default_queue_run_matches_oracle(gpu, orc):
     n, k = 32768, 56
     kinds, grads, b0, _ = synth.deep_cuts(n, k)
     e = gpu.Ell.new_with_scalar(1.0, np.zeros(n))
-    assert e.defer_depth == 24 and e.get_option(gpu.capi.OPT_LOOKAHEAD) == 16 and e.get_option(gpu.capi.OPT_QUEUE_DEPTH) == 48
+    assert e.defer_depth == 24 and e.get_option(gpu.capi.OPT_LOOKAHEAD) == 32 and e.get_option(gpu.capi.OPT_QUEUE_DEPTH) == 48
     e.profile_enable(True)
     e.queue_upload(kinds, grads, b0)
     e.queue_run(0, k, fused=True)
     st, ts = e.queue_results()
     prof = e.profile_read()
-    assert prof["symv"][1] == 4 and prof["apply"][1] == 1, prof     # groups of 16, 16, 16 | 8; ONE apply pass, at cut 48
+    assert prof["symv"][1] == 3 and prof["apply"][1] == 1, prof     # groups of 32, 16 | 8; ONE apply pass, at cut 48
     assert np.all(st == 0)
     o = orc.OracleEll.new_with_scalar(1.0, np.zeros(n))
     for i in range(k):

@@ -1,7 +1,7 @@
 """GPU: pipelined queue runs on the lower-triangle schedule that use what a QUEUE knows -- the next gradients.
 The GEMV y = Q_base g of a queued cut reads a matrix the cuts before it do not change until the next apply pass (recorded
 schedule: src/ell.rs:117-128 is deferred), so
-  * ELLHIP_OPT_LOOKAHEAD = L (default 16; csrc/ellhip_capi.hip queue_run_multi): the products of L consecutive queued cuts
+  * ELLHIP_OPT_LOOKAHEAD = L (default 32; csrc/ellhip_capi.hip queue_run_multi): the products of L consecutive queued cuts
     are formed in ONE pass over the lower triangle -- L <= 3 on the vector ALU (k_symv_multi, per vector k_symv's
     arithmetic), L > 3 on the FP64 matrix cores (k_symm_mfma, n a multiple of 64; own association: a few ulp) with the
     group's scalar stage in four launches (group_kernels.hpp) and, at depth 24, up to ELLHIP_OPT_QUEUE_DEPTH = 48
@@ -27,7 +27,7 @@ def _beta(b0, b1, i):
 
 
 # (OVERLAP, LOOKAHEAD, QUEUE_DEPTH); the first is the serial reference
-MODES = [(0, 1, 0), (1, 1, 48), (0, 2, 0), (1, 3, 48), (0, 4, 0), (1, 12, 0), (0, 12, 48), (0, 16, 48)]
+MODES = [(0, 1, 0), (1, 1, 48), (0, 2, 0), (1, 3, 48), (0, 4, 0), (1, 12, 0), (0, 12, 48), (0, 16, 48), (1, 21, 48), (1, 32, 48)]
 EXACT = 4                                                            # the first four: bit-identical to one another
 RTOL = 1e-12                                                         # the matrix-core groups against them
 
@@ -88,8 +88,8 @@ def test_overlapped_runs_equal_the_serial_issue_order_to_the_bit(gpu, orc, n, de
         if i != 43:
             assert abs(b[1][i] - o.tsq) <= TOL * abs(o.tsq), i
     assert_state_close(b[5], o, what=f"overlapped n={n} depth={depth} dense={dense}")
-    if dense:   # ... and the default mode (the last one: lookahead 16, 48 per apply pass) as well
-        assert_state_close(outs[-1][5], o, what=f"lookahead 16 n={n} depth={depth} dense start")
+    if dense:   # ... and the default mode (the last one: lookahead 32, 48 per apply pass) as well
+        assert_state_close(outs[-1][5], o, what=f"lookahead 32 n={n} depth={depth} dense start")
 
 
 @pytest.mark.parametrize("depth", [8, 24])
@@ -121,13 +121,13 @@ def test_failing_cut_halts_the_overlapped_run(gpu, orc, depth):
 
 
 def test_overlapped_run_at_the_default_size_and_depth(gpu):
-    """n = 8192: the smallest size that takes the lower-triangle schedule (depth 24, groups of 16 on the matrix cores) by
+    """n = 8192: the smallest size that takes the lower-triangle schedule (depth 24, groups of up to 32 on the matrix cores) by
     itself; a clone taken between two runs continues serially and must stay equal to 1e-12."""
     from ellalgo_rs_amd import synth
     n, k = 8192, 60
     kinds, grads, b0, b1 = synth.parallel_cuts(n, k)
     e = gpu.Ell.new_with_scalar(1.0, np.zeros(n))
-    assert e.defer_depth == 24 and e.get_option(gpu.capi.OPT_OVERLAP) == 1 and e.get_option(gpu.capi.OPT_LOOKAHEAD) == 16
+    assert e.defer_depth == 24 and e.get_option(gpu.capi.OPT_OVERLAP) == 1 and e.get_option(gpu.capi.OPT_LOOKAHEAD) == 32
     e.profile_enable(True)
     e.queue_upload(kinds, grads, b0, b1)
     e.queue_run(0, 31, fused=True)
@@ -143,9 +143,9 @@ def test_overlapped_run_at_the_default_size_and_depth(gpu):
     assert _same(ts_e[31:], ts_c[31:], False) and _same(e.xc(), c.xc(), False) and _same([e.kappa], [c.kappa], False)
     assert _same(e.mq, c.mq, False)
     prof = e.profile_read()
-    # one pass over Q and one batched reduction per group of up to sixteen cuts (a run's end closes a group early):
-    # (16, 15) + (16, 13); both runs end with more than 24 recorded and apply them before they return
-    assert prof["symv_reduce"][1] == 4 and prof["symv"][1] == 4 and prof["apply"][1] == 2
+    # one pass over Q and one batched reduction per group of up to 32 cuts (a run's end closes a group):
+    # (31) + (29); both runs end with more than 24 recorded and apply them before they return
+    assert prof["symv_reduce"][1] == 2 and prof["symv"][1] == 2 and prof["apply"][1] == 2
 
 
 # Seeds the 400-seed soak of round 3 failed on with the library as it was before 957140e (products issued ahead on the second
@@ -169,7 +169,7 @@ def _option_walk(gpu, seed, serial):
     e.defer_depth = depth
 
     def reroll():
-        e.set_option(gpu.capi.OPT_LOOKAHEAD, int(rng.choice([1, 2, 3, 4, 7, 12, 16])))
+        e.set_option(gpu.capi.OPT_LOOKAHEAD, int(rng.choice([1, 2, 3, 4, 7, 12, 16, 21, 32])))
         e.set_option(gpu.capi.OPT_QUEUE_DEPTH, int(rng.choice([0, 48])))
         ov = int(rng.integers(0, 2))
         e.set_option(gpu.capi.OPT_OVERLAP, 2 if (serial and ov) else ov)

@@ -281,7 +281,7 @@ int main(int argc, char** argv) {
             int* d_err2;
             CK(hipMalloc(&d_err2, 4));
             CK(hipMemset(d_err2, 0, 4));
-            const int NVAR = 6, ROUNDS = 25;
+            const int NVAR = 9, ROUNDS = 25;
             std::vector<std::vector<float>> tms(NVAR);
             auto go = [&](int v) {
                 switch (v) {
@@ -308,6 +308,15 @@ int main(int argc, char** argv) {
                 case 5:
                     launch_glds<SEG, 2>((const double*)Q, 0, n, gT, 16, rp[1], cp[1], rs, cs, st);
                     break;
+                case 6:
+                case 7:
+                case 8: {
+                    const int budget = v == 6 ? 1 : (v == 7 ? 2 : 3);
+                    CK(hipMemsetAsync(d_cnt, 0, 4, 0));
+                    hipLaunchKernelGGL((k_symm_q_reg<true, SEG>), dim3((unsigned)((ntiles + budget - 1) / budget + 64)), dim3(256), 0, 0, (const double*)Q, ld, n, 0LL, n,
+                                       (const double*)gT, 16, rp[1], cp[1], rs, cs, (const DevState*)st, (const SymmTile*)d_tl, ntiles, d_cnt, budget);
+                    break;
+                }
                 }
             };
             for (int r = 0; r < ROUNDS + 2; ++r)
@@ -321,7 +330,8 @@ int main(int argc, char** argv) {
                     if (r >= 2) tms[v].push_back(tm);
                 }
             const char* names[NVAR] = {"k_symm_mfma (grid of tiles)", "k_symm_q_reg, 512 workgroups", "k_symm_q_reg, 768 workgroups",
-                                       "k_symm_q_glds<D=2>, 512 workgroups", "k_symm_lc, 256 workgroups", "k_symm_glds<D=2> (grid of tiles)"};
+                                       "k_symm_q_glds<D=2>, 512 workgroups", "k_symm_lc, 256 workgroups", "k_symm_glds<D=2> (grid of tiles)",
+                                       "queue, ONE tile per workgroup (largest first)", "queue, at most 2 tiles per workgroup", "queue, at most 3 tiles per workgroup"};
             printf("interleaved, %d rounds, 16 gradients (the queue forms include the 4-byte memset of their counter):\n", ROUNDS);
             for (int v = 0; v < NVAR; ++v) {
                 std::sort(tms[v].begin(), tms[v].end());

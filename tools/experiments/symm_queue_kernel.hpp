@@ -31,14 +31,14 @@ __global__ __launch_bounds__(256) void k_symm_q_reg(const double* __restrict__ Q
                                                     double* __restrict__ rowpart, double* __restrict__ colpart,
                                                     long long rowpart_stride, long long colpart_stride,
                                                     const DevState* __restrict__ st, const SymmTile* __restrict__ tiles,
-                                                    int ntiles, unsigned* __restrict__ counter) {
+                                                    int ntiles, unsigned* __restrict__ counter, int budget = 1 << 30) {
     __shared__ double sh[4][SYMV_H * SMM_PITCH];
     __shared__ int s_t;
     if (st->halted) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int lr = lane >> 4, lc = lane & 15;
     Q -= row0 * ld;
-    for (;;) {
+    for (int done_tiles = 0; done_tiles < budget; ++done_tiles) {
         const int t = symm_next_tile(counter, ntiles, &s_t);
         if (t < 0) break;
         const long long I = tiles[t].I, J = tiles[t].J;
