@@ -593,7 +593,9 @@ __device__ __forceinline__ void symv_reduce_block(long long blk, long long n, lo
                                                   long long seg, const double* __restrict__ rowpart,
                                                   const double* __restrict__ colpart, double* __restrict__ y,
                                                   const double* __restrict__ g, const double* __restrict__ pend,
-                                                  double* __restrict__ partial, double2_t (*part)[64]) {
+                                                  double* __restrict__ partial, double2_t (*part)[64], int np_used = NP) {
+    // (np_used: the recorded slots that hold a vector right now; the dot products with the empty ones are not formed -- nobody
+    // reads them -- and their 8 n bytes per slot not loaded: a group stage right after an apply pass has none)
     auto ldp = [](const double* p) -> double2_t {
         if constexpr (HANDOFF) return double2_t{ho_load(p), ho_load(p + 1)};
         else return *reinterpret_cast<const double2_t*>(p);
@@ -611,8 +613,8 @@ __device__ __forceinline__ void symv_reduce_block(long long blk, long long n, lo
 #pragma unroll
         for (int k = 0; k < NPW; ++k) {
             const int j = wave + 4 * k;
-            pv[k] = (i < n && j < NP) ? *reinterpret_cast<const double2_t*>(pend + (long long)j * n + i)
-                                      : double2_t{0.0, 0.0};
+            pv[k] = (i < n && j < NP && j < np_used) ? *reinterpret_cast<const double2_t*>(pend + (long long)j * n + i)
+                                                     : double2_t{0.0, 0.0};
         }
     }
     // A row shard yields its PARTIAL sums for every column (zeros right of its last row); the ranks' partial

@@ -1676,7 +1676,7 @@ int group_stage_go(ellhip_space* s, long long i, int g, int half) {
         else
             hipLaunchKernelGGL(k_group_reduce<NP>, dim3(nb, (unsigned)g), dim3(256), 0, s->stream, s->n, s->row0, s->nrows,
                                (long long)s->symv_seg, rowp, colp, (long long)rowpart_elems(s), (long long)colpart_elems(s),
-                               s->d_grpY, grads, s->n, (const double*)s->d_pend, s->d_gpart, (const DevState*)s->d_st);
+                               s->d_grpY, grads, s->n, (const double*)s->d_pend, s->d_gpart, (const DevState*)s->d_st, s->npend);
         HIPCHK(hipGetLastError());
     }
     if (s->sharded) {
@@ -1687,7 +1687,7 @@ int group_stage_go(ellhip_space* s, long long i, int g, int half) {
         if (xrc) return xrc;
         ProfScope ps(s, CLS_SYMV_REDUCE);
         hipLaunchKernelGGL(k_group_dots<NP>, dim3(nb, (unsigned)g), dim3(256), 0, s->stream, s->n, (const double*)s->d_grpY, grads,
-                           s->n, (const double*)s->d_pend, s->d_gpart, (const DevState*)s->d_st);
+                           s->n, (const double*)s->d_pend, s->d_gpart, (const DevState*)s->d_st, s->npend);
         HIPCHK(hipGetLastError());
     }
     ProfScope ps(s, CLS_SCALAR);

@@ -38,13 +38,14 @@ __global__ __launch_bounds__(256) void k_group_reduce(long long n, long long row
                                                       long long colpart_stride, double* __restrict__ Y,
                                                       const double* __restrict__ g, long long g_stride,
                                                       const double* __restrict__ pend, double* __restrict__ gpart,
-                                                      const DevState* __restrict__ st) {
+                                                      const DevState* __restrict__ st, int slot0 = NP) {
     __shared__ double2_t part[4][64];
     if (st->halted) return;
     const long long l = blockIdx.y, nb = gridDim.x;
     // (NP = 0, a row shard: its partial y_l only -- the dot products wait for the all-reduce, k_group_dots)
+    // (slot0: the slots recorded before the group; k_group_scalar reads B[j][l] for j < slot0 only)
     symv_reduce_block<NP, false>((long long)blockIdx.x, n, row0, nrows, seg, rowpart + l * rowpart_stride,
-                                 colpart + l * colpart_stride, Y + l * n, g + l * g_stride, pend, gpart + l * nb * (NP + 1), part);
+                                 colpart + l * colpart_stride, Y + l * n, g + l * g_stride, pend, gpart + l * nb * (NP + 1), part, slot0);
 }
 
 // The same for a symmetric row shard: k_group_reduce<0> yields the shard's PARTIAL y_l, the owner's ONE all-reduce of
@@ -53,7 +54,7 @@ __global__ __launch_bounds__(256) void k_group_reduce(long long n, long long row
 template <int NP>
 __global__ __launch_bounds__(256) void k_group_dots(long long n, const double* __restrict__ Y, const double* __restrict__ g,
                                                     long long g_stride, const double* __restrict__ pend,
-                                                    double* __restrict__ gpart, const DevState* __restrict__ st) {
+                                                    double* __restrict__ gpart, const DevState* __restrict__ st, int slot0 = NP) {
     if (st->halted) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long long l = blockIdx.y, nb = gridDim.x, blk = blockIdx.x;
@@ -71,7 +72,7 @@ __global__ __launch_bounds__(256) void k_group_dots(long long n, const double* _
     }
     for (int j = wave; j < NP; j += 4) {
         double2_t pv = {0.0, 0.0};
-        if (i < n) pv = *reinterpret_cast<const double2_t*>(pend + (long long)j * n + i);
+        if (i < n && j < slot0) pv = *reinterpret_cast<const double2_t*>(pend + (long long)j * n + i);
         double sv = pv.x * gi.x;
         sv += pv.y * gi.y;
         sv = wave_allreduce_sum(sv);
