@@ -1661,11 +1661,13 @@ int multi_setup(ellhip_space* s) {
 }
 
 // the scalar stage of a group whose products sit in the partial-sum sets 2 .. 2 + g - 1 (group_kernels.hpp)
+// phase 0: the reductions (they read the pass' partial sums at HBM rate and want the whole card); phase 1: the rest (Gram slices,
+// sums, the one-wave recurrence, the vectors: short kernels that run beside the NEXT group's pass on the CU slots it leaves free)
 template <int NP>
-int group_stage_go(ellhip_space* s, long long i, int g, int half) {
+int group_stage_go(ellhip_space* s, long long i, int g, int half, int phase) {
     const unsigned nb = (unsigned)((s->n + 127) / 128);
     const double* grads = qgrad(s, i);
-    {
+    if (phase == 0) {
         ProfScope ps(s, CLS_SYMV_REDUCE);
         const double* rowp = s->d_rowpart_m + (size_t)half * MULTI_MAX * rowpart_elems(s);
         const double* colp = s->d_colpart_m + (size_t)half * MULTI_MAX * colpart_elems(s);
@@ -1678,8 +1680,9 @@ int group_stage_go(ellhip_space* s, long long i, int g, int half) {
                                (long long)s->symv_seg, rowp, colp, (long long)rowpart_elems(s), (long long)colpart_elems(s),
                                s->d_grpY, grads, s->n, (const double*)s->d_pend, s->d_gpart, (const DevState*)s->d_st, s->npend);
         HIPCHK(hipGetLastError());
+        if (!s->sharded) return 0;
     }
-    if (s->sharded) {
+    if (phase == 0) {
         // the shards' partial products become the products: ONE collective for the whole group, then the dot products from
         // the complete vectors (every rank forms the same ones)
         if (!s->grp_exchange) return fail(ELLHIP_E_STATE, "group run of a row shard without the owner's collective");
@@ -1689,6 +1692,7 @@ int group_stage_go(ellhip_space* s, long long i, int g, int half) {
         hipLaunchKernelGGL(k_group_dots<NP>, dim3(nb, (unsigned)g), dim3(256), 0, s->stream, s->n, (const double*)s->d_grpY, grads,
                            s->n, (const double*)s->d_pend, s->d_gpart, (const DevState*)s->d_st, s->npend);
         HIPCHK(hipGetLastError());
+        return 0;
     }
     ProfScope ps(s, CLS_SCALAR);
     hipLaunchKernelGGL(k_group_gram, dim3(nb), dim3(256), 0, s->stream, s->n, g, (const double*)s->d_grpY, grads, s->n,
@@ -1705,7 +1709,7 @@ int group_stage_go(ellhip_space* s, long long i, int g, int half) {
 }
 
 template <int SEG>
-void symm_mfma_go(ellhip_space* s, const double* g_dev, int lv, hipStream_t st, int half) {
+void symm_mfma_go(ellhip_space* s, const double* g_dev, int lv, hipStream_t st, int half, int wgs) {
     double* gT = s->d_gT + (size_t)half * (size_t)s->n * MULTI_MAX;
     double* rowp = s->d_rowpart_m + (size_t)half * MULTI_MAX * rowpart_elems(s);
     double* colp = s->d_colpart_m + (size_t)half * MULTI_MAX * colpart_elems(s);
@@ -1714,7 +1718,7 @@ void symm_mfma_go(ellhip_space* s, const double* g_dev, int lv, hipStream_t st, 
     hipLaunchKernelGGL(k_pack_grads, dim3((unsigned)((s->n * nvw + 255) / 256)), dim3(256), 0, st, g_dev, s->n, lv, s->n, gT, queue, nvw);
     const bool nt = s->sh_gemv.nt != 0;
 #define ELLHIP_SYMM_Q(...)                                                                                                          \
-    hipLaunchKernelGGL((__VA_ARGS__), dim3((unsigned)s->symm_wgs), dim3(256), 0, st, (const double*)s->d_Q, s->ld, s->n, s->row0,        \
+    hipLaunchKernelGGL((__VA_ARGS__), dim3((unsigned)wgs), dim3(256), 0, st, (const double*)s->d_Q, s->ld, s->n, s->row0,                \
                        (const double*)gT, lv, rowp, colp, (long long)rowpart_elems(s), (long long)colpart_elems(s),                 \
                        (const DevState*)s->d_st, (const SymmTile*)s->d_symm_tiles, s->symm_ntiles, queue)
     if (nvw == SMM_NV) {
@@ -1737,10 +1741,13 @@ long long group_size(const ellhip_space* s, long long cap, long long rem) {
     return g;
 }
 
-int symm_go(ellhip_space* s, const double* g_dev, int lv, hipStream_t st, int half) {
+// beside: the pass is issued next to the previous group's stage -- it leaves one workgroup slot free on a sixteenth of the CUs, where
+// that stage's short kernels run (a pass that draws its tiles from a queue keeps every slot it gets until it ends)
+int symm_go(ellhip_space* s, const double* g_dev, int lv, hipStream_t st, int half, bool beside = false) {
     ProfScope ps(s, CLS_SYMV, st);
-    if (s->symv_seg == SYMV_SEG) symm_mfma_go<SYMV_SEG>(s, g_dev, lv, st, half);
-    else symm_mfma_go<SYMV_SEG_SMALL>(s, g_dev, lv, st, half);
+    const int wgs = beside ? std::max(1, s->symm_wgs - std::max(1, (s->symm_wgs * 3) / 32)) : s->symm_wgs;
+    if (s->symv_seg == SYMV_SEG) symm_mfma_go<SYMV_SEG>(s, g_dev, lv, st, half, wgs);
+    else symm_mfma_go<SYMV_SEG_SMALL>(s, g_dev, lv, st, half, wgs);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -1824,22 +1831,30 @@ int queue_run_multi(ellhip_space* s, long long first, long long count) {
                 const long long cap2 = std::min<long long>(s->lookahead, cap), rem2 = std::min(end - i2, room2);
                 g2 = group_size(s, cap2, rem2);  // (the rule the next trip of the loop applies)
             }
+            // the whole group's scalar stage: the cuts' omegas and coefficients from dot products that exist when the group
+            // starts, then the vectors in one elementwise pass.  First its reductions (they stream the pass' partial sums and want
+            // the whole card) ...
+            drop_prime(s);
+            s->dots_np = 0;
+            s->xc_host_valid = false;
+#define ELLHIP_STAGE(PHASE)                                                                                          \
+    (qdepth == MAXPEND ? group_stage_go<MAXPEND>(s, i, (int)g, half, PHASE)                                          \
+     : qdepth == 24    ? group_stage_go<24>(s, i, (int)g, half, PHASE)                                               \
+     : qdepth == 16    ? group_stage_go<16>(s, i, (int)g, half, PHASE) : group_stage_go<8>(s, i, (int)g, half, PHASE))
+            rc = ELLHIP_STAGE(0);
+            if (rc) return rc;
+            // ... then the NEXT group's products on the second stream, behind those reductions and beside the rest of this
+            // stage (short kernels, one of them a single wave: they run on the slots the pass leaves free)
             if (use_side && g2 >= 2) {
-                rc = side_fork(s);  // after this group's products, the last reader of the other half, every writer of Q so far
-                if (!rc) rc = symm_go(s, qgrad(s, i2), (int)g2, side_stream(s), half ^ 1);
+                rc = side_fork(s);  // after this group's reductions: the last reader of the other half, every writer of Q so far
+                if (!rc) rc = symm_go(s, qgrad(s, i2), (int)g2, side_stream(s), half ^ 1, true);
                 if (!rc) rc = side_mark(s);
                 if (rc) return rc;
                 ahead_i = i2;
                 ahead_g = g2;
             }
-            // the whole group's scalar stage: the cuts' omegas and coefficients from dot products that exist when the group
-            // starts, then the vectors in one elementwise pass
-            drop_prime(s);
-            s->dots_np = 0;
-            s->xc_host_valid = false;
-            rc = qdepth == MAXPEND ? group_stage_go<MAXPEND>(s, i, (int)g, half)
-               : qdepth == 24 ? group_stage_go<24>(s, i, (int)g, half)
-               : qdepth == 16 ? group_stage_go<16>(s, i, (int)g, half) : group_stage_go<8>(s, i, (int)g, half);
+            rc = ELLHIP_STAGE(1);
+#undef ELLHIP_STAGE
             if (rc) return rc;
             s->npend += (int)g;       // (optimistic, as after every queue cut: ellhip_queue_results settles it after a halt)
             s->scalars_stale = true;

@@ -144,9 +144,20 @@ __global__ __launch_bounds__(256) void k_group_sums(int G, int nb, const double*
         constexpr int R = 256 / W;  // row classes (NP = 48: 5, 24: 10, 16: 15, 8: 28)
         const double* p = gpart + (long long)l * nb * W;
         const int c = tid % W, q = tid / W;
+        // (eight loads in flight, added in the order of the plain loop: beside the next group's pass -- which saturates HBM -- a
+        // load takes microseconds, and one load per trip made this launch last 300 us instead of 14)
         double a = 0.0;
-        if (q < R)
-            for (int b = q; b < nb; b += R) a += p[(long long)b * W + c];
+        if (q < R) {
+            int b = q;
+            for (; b + 7 * R < nb; b += 8 * R) {
+                double v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = p[(long long)(b + u * R) * W + c];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) a += v[u];
+            }
+            for (; b < nb; b += R) a += p[(long long)b * W + c];
+        }
         red[tid] = a;
         __syncthreads();
         if (tid < W) {
@@ -164,6 +175,13 @@ __global__ __launch_bounds__(256) void k_group_sums(int G, int nb, const double*
         const double* p = cpart + col;
         double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
         int b = 0;
+        for (; b + 15 < nb; b += 16) {  // (sixteen loads in flight; the four running sums take them in the order of the loop below)
+            double v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) v[u] = p[(long long)(b + u) * W2];
+#pragma unroll
+            for (int u = 0; u < 16; u += 4) a0 += v[u], a1 += v[u + 1], a2 += v[u + 2], a3 += v[u + 3];
+        }
         for (; b + 3 < nb; b += 4) {
             const double v0 = p[(long long)b * W2], v1 = p[(long long)(b + 1) * W2];
             const double v2 = p[(long long)(b + 2) * W2], v3 = p[(long long)(b + 3) * W2];
@@ -202,12 +220,34 @@ __global__ __launch_bounds__(64) void k_group_scalar(int G, const double* __rest
     if (lane < G) s_cp[lane] = cp_dev[lane];
     const double tol = st->tol;
     if (!was_halted) {
-        for (int k = lane; k < G * (NP + 1); k += 64) {
-            const int l = k / (NP + 1), c = k - l * (NP + 1);
-            if (c == 0) A[l] = sums[k];
-            else B[c - 1][l] = sums[k];
+        // (eight loads in flight per trip: this wave runs beside the next group's pass, where a load takes microseconds)
+        for (int k0 = 0; k0 < G * (NP + 1); k0 += 8 * 64) {
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int k = k0 + 64 * u + lane;
+                v[u] = k < G * (NP + 1) ? sums[k] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int k = k0 + 64 * u + lane;
+                if (k < G * (NP + 1)) {
+                    const int l = k / (NP + 1), c = k - l * (NP + 1);
+                    if (c == 0) A[l] = v[u];
+                    else B[c - 1][l] = v[u];
+                }
+            }
         }
-        for (int k = lane; k < GRP_MAX * GRP_MAX; k += 64) C[k / GRP_MAX][k % GRP_MAX] = sums[G * (NP + 1) + k];
+        for (int k0 = 0; k0 < GRP_MAX * GRP_MAX; k0 += 8 * 64) {
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = sums[G * (NP + 1) + k0 + 64 * u + lane];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int k = k0 + 64 * u + lane;
+                C[k / GRP_MAX][k % GRP_MAX] = v[u];
+            }
+        }
     }
     double cc = (lane < NP && !was_halted) ? cpend[lane] : 0.0;  // c_j of this lane's slot
     if (lane == 0) {
