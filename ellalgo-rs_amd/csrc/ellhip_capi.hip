@@ -1781,9 +1781,10 @@ int queue_run_multi(ellhip_space* s, long long first, long long count) {
     const int qdepth = deep_ok ? s->queue_depth : s->defer;
     if (qdepth != 8 && qdepth != 16 && qdepth != 24 && qdepth != MAXPEND)  // (the group kernels' slot counts; pend / cpend hold MAXPEND)
         return fail(ELLHIP_E_STATE, "queue run: recorded-update depth must be 8, 16, 24 or 48");
-    // (measured: +1.5 % / +8 % at n = 16384 for 200 / 20 cuts per run, -3 % at n = 32768, where stretching a 1.1 ms pass
-    // costs more than hiding a 0.4 ms stage saves)
-    const bool use_side = multi_mfma(s) && s->overlap != 0 && s->n <= 24576 && !s->sharded;
+    // (round 3, the pass beside the whole stage: +1.5 % / +8 % at n = 16384 for 200 / 20 cuts per run, -3 % at n = 32768, so the
+    // second stream stopped at n = 24576.  Round 4, the pass behind the stage's reductions and beside the rest of it on the slots
+    // it leaves free: +6 % at n = 16384 (200 cuts), +1.5 % at n = 32768 -- used at every size)
+    const bool use_side = multi_mfma(s) && s->overlap != 0 && !s->sharded;
     if (use_side) {
         rc = side_setup(s);
         if (rc) return rc;
