@@ -588,17 +588,7 @@ __global__ __launch_bounds__(256) void k_symv_multi(const double* __restrict__ Q
 // by other workgroups of THIS launch (k_symv_tail): they are read with agent-scope loads.
 // WT: y and the partial dot products are stored write-through (agent scope): other workgroups of the SAME launch read
 // them after an in-launch wait (k_symv_reduce_scalar).
-// Where the column partial sum of strip I (of the shard) at column c lives inside one set.  Row-major [I][n]: what k_symv /
-// k_symv_multi write (their waves store runs of a strip's row).  Block-major [c / 128][I][128] (CBLK): what the matrix-core passes
-// write for the group stage -- a reducing workgroup owns 128 columns and adds over ALL strips, so in this layout it reads ONE
-// contiguous run (nstrips KiB) instead of nstrips pieces of 1 KiB that are 8 n bytes apart (k_group_reduce: 151 -> 1xx us for 32 cuts
-// at n = 16384); the pass still stores whole 128-byte lines.  A set holds nstrips * round_up(n, 128) doubles either way.
-template <bool CBLK>
-__device__ __forceinline__ long long colpart_index(long long I, long long c, long long n, long long nstrips) {
-    return CBLK ? ((c >> 7) * nstrips + I) * 128 + (c & 127) : I * n + c;
-}
-
-template <int NP, bool HANDOFF, bool WT = false, bool CBLK = false>
+template <int NP, bool HANDOFF, bool WT = false>
 __device__ __forceinline__ void symv_reduce_block(long long blk, long long n, long long row0, long long nrows,
                                                   long long seg, const double* __restrict__ rowpart,
                                                   const double* __restrict__ colpart, double* __restrict__ y,
@@ -638,7 +628,7 @@ __device__ __forceinline__ void symv_reduce_block(long long blk, long long n, lo
             for (; I + 60 < nstrips; I += 64) {
                 double2_t v[16];
 #pragma unroll
-                for (int u = 0; u < 16; ++u) v[u] = ldp(colpart + colpart_index<CBLK>(I + 4 * u, i, n, nstrips));
+                for (int u = 0; u < 16; ++u) v[u] = ldp(colpart + (I + 4 * u) * n + i);
 #pragma unroll
                 for (int u = 0; u < 16; ++u) {
                     s.x += v[u].x;
@@ -649,7 +639,7 @@ __device__ __forceinline__ void symv_reduce_block(long long blk, long long n, lo
         for (; I + 28 < nstrips; I += 32) {
             double2_t v[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = ldp(colpart + colpart_index<CBLK>(I + 4 * u, i, n, nstrips));
+            for (int u = 0; u < 8; ++u) v[u] = ldp(colpart + (I + 4 * u) * n + i);
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 s.x += v[u].x;
@@ -657,7 +647,7 @@ __device__ __forceinline__ void symv_reduce_block(long long blk, long long n, lo
             }
         }
         for (; I < nstrips; I += 4) {
-            const double2_t v = ldp(colpart + colpart_index<CBLK>(I, i, n, nstrips));
+            const double2_t v = ldp(colpart + I * n + i);
             s.x += v.x;
             s.y += v.y;
         }
@@ -1110,11 +1100,11 @@ __global__ __launch_bounds__(256) void k_pack_grads(const double* __restrict__ g
 // loads are buffered.  What did pay is how the tiles reach the CUs: k_symm_mfma_q below.
 //
 // One tile: strip I of the shard (rows r0 = row0 + 64 I ...), column segment J; sh = the workgroup's 4 x 64 x 17 doubles.
-template <bool NT, int SEG, bool CBLK>
+template <bool NT, int SEG>
 __device__ __forceinline__ void symm_tile(const double* __restrict__ Q, long long ld, long long n, long long row0, long long I,
                                           long long J, const double* __restrict__ gT, int lv, double* __restrict__ rowpart,
                                           double* __restrict__ colpart, long long rowpart_stride, long long colpart_stride,
-                                          double (*sh)[SYMV_H * SMM_PITCH], long long nstrips) {
+                                          double (*sh)[SYMV_H * SMM_PITCH]) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int lr = lane >> 4, lc = lane & 15;
     const long long r0 = row0 + I * SYMV_H;
@@ -1166,7 +1156,7 @@ __device__ __forceinline__ void symm_tile(const double* __restrict__ Q, long lon
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int v = lr + 4 * i;
-            if (v < lv) colpart[(long long)v * colpart_stride + colpart_index<CBLK>(I, cb + lc, n, nstrips)] = o[i];
+            if (v < lv) colpart[(long long)v * colpart_stride + I * n + cb + lc] = o[i];
         }
     }
     // row sums of the four waves, in wave order
@@ -1191,7 +1181,7 @@ __device__ __forceinline__ void symm_tile(const double* __restrict__ Q, long lon
 }
 
 // One workgroup per tile of k_symv's grid (the form round 3 shipped; the experiments and the queue form's check use it).
-template <bool NT, int SEG, bool CBLK = false>
+template <bool NT, int SEG>
 __global__ __launch_bounds__(256) void k_symm_mfma(const double* __restrict__ Q, long long ld, long long n, long long row0,
                                                    long long nrows, const double* __restrict__ gT, int lv,
                                                    double* __restrict__ rowpart,
@@ -1204,8 +1194,7 @@ __global__ __launch_bounds__(256) void k_symm_mfma(const double* __restrict__ Q,
     // column indices are global, the result is this shard's PARTIAL sums (as k_symv's for a shard)
     const long long r0 = row0 + I * SYMV_H;
     if (r0 >= row0 + nrows || J * SEG > r0 + SYMV_H - 1) return;
-    symm_tile<NT, SEG, CBLK>(Q - row0 * ld, ld, n, row0, I, J, gT, lv, rowpart, colpart, rowpart_stride, colpart_stride, sh,
-                             (long long)gridDim.x);
+    symm_tile<NT, SEG>(Q - row0 * ld, ld, n, row0, I, J, gT, lv, rowpart, colpart, rowpart_stride, colpart_stride, sh);
 }
 
 // The same tiles handed out from a QUEUE.  A 64 x 2048 tile keeps its workgroup ~100 us and a card holds 512 such workgroups,
@@ -1217,13 +1206,13 @@ __global__ __launch_bounds__(256) void k_symm_mfma(const double* __restrict__ Q,
 struct SymmTile {
     int I, J;  // strip of the shard, column segment
 };
-template <bool NT, int SEG, bool CBLK = false>
+template <bool NT, int SEG>
 __global__ __launch_bounds__(256) void k_symm_mfma_q(const double* __restrict__ Q, long long ld, long long n, long long row0,
                                                      const double* __restrict__ gT, int lv, double* __restrict__ rowpart,
                                                      double* __restrict__ colpart, long long rowpart_stride,
                                                      long long colpart_stride, const DevState* __restrict__ st,
                                                      const SymmTile* __restrict__ tiles, int ntiles,
-                                                     unsigned* __restrict__ queue, long long nstrips = 0) {
+                                                     unsigned* __restrict__ queue) {
     __shared__ double sh[4][SYMV_H * SMM_PITCH];
     __shared__ int s_t;
     if (st->halted) return;
@@ -1237,8 +1226,8 @@ __global__ __launch_bounds__(256) void k_symm_mfma_q(const double* __restrict__ 
         __syncthreads();
         const int t = s_t;
         if (t < 0) return;  // (uniform)
-        symm_tile<NT, SEG, CBLK>(Q, ld, n, row0, (long long)tiles[t].I, (long long)tiles[t].J, gT, lv, rowpart, colpart, rowpart_stride,
-                                 colpart_stride, sh, nstrips);
+        symm_tile<NT, SEG>(Q, ld, n, row0, (long long)tiles[t].I, (long long)tiles[t].J, gT, lv, rowpart, colpart, rowpart_stride,
+                           colpart_stride, sh);
     }
 }
 
@@ -1249,11 +1238,11 @@ __global__ __launch_bounds__(256) void k_symm_mfma_q(const double* __restrict__ 
 // k_symm_mfma's: the partial sums of 32 gradients are bit-identical to those of two 16-wide passes, in 0.445 ms against 0.55-0.62
 // (n = 16384, tools/experiments/symm32_queue.hip).
 constexpr int SMM_NV2 = 2 * SMM_NV;
-template <bool NT, int SEG, bool CBLK>
+template <bool NT, int SEG>
 __device__ __forceinline__ void symm_tile2(const double* __restrict__ Q, long long ld, long long n, long long row0, long long I,
                                            long long J, const double* __restrict__ gT, int lv, double* __restrict__ rowpart,
                                            double* __restrict__ colpart, long long rowpart_stride, long long colpart_stride,
-                                           double (*sh)[SYMV_H * SMM_PITCH], double (*sgr)[SMM_NV2 + 1], long long nstrips) {
+                                           double (*sh)[SYMV_H * SMM_PITCH], double (*sgr)[SMM_NV2 + 1]) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int lr = lane >> 4, lc = lane & 15;
     const long long r0 = row0 + I * SYMV_H;
@@ -1313,7 +1302,7 @@ __device__ __forceinline__ void symm_tile2(const double* __restrict__ Q, long lo
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int v = 16 * t + lr + 4 * i;
-                if (v < lv) colpart[(long long)v * colpart_stride + colpart_index<CBLK>(I, cb + lc, n, nstrips)] = o[i];
+                if (v < lv) colpart[(long long)v * colpart_stride + I * n + cb + lc] = o[i];
             }
         }
     }
@@ -1340,13 +1329,13 @@ __device__ __forceinline__ void symm_tile2(const double* __restrict__ Q, long lo
     }
 }
 
-template <bool NT, int SEG, bool CBLK = false>
+template <bool NT, int SEG>
 __global__ __launch_bounds__(256, 2) void k_symm_mfma_q2(const double* __restrict__ Q, long long ld, long long n, long long row0,
                                                          const double* __restrict__ gT, int lv, double* __restrict__ rowpart,
                                                          double* __restrict__ colpart, long long rowpart_stride,
                                                          long long colpart_stride, const DevState* __restrict__ st,
                                                          const SymmTile* __restrict__ tiles, int ntiles,
-                                                         unsigned* __restrict__ queue, long long nstrips = 0) {
+                                                         unsigned* __restrict__ queue) {
     __shared__ double sh[4][SYMV_H * SMM_PITCH];
     __shared__ double sgr[SYMV_H][SMM_NV2 + 1];  // the gT rows of the strip (odd pitch)
     __shared__ int s_t;
@@ -1361,8 +1350,8 @@ __global__ __launch_bounds__(256, 2) void k_symm_mfma_q2(const double* __restric
         __syncthreads();
         const int t = s_t;
         if (t < 0) return;
-        symm_tile2<NT, SEG, CBLK>(Q, ld, n, row0, (long long)tiles[t].I, (long long)tiles[t].J, gT, lv, rowpart, colpart, rowpart_stride,
-                                  colpart_stride, sh, sgr, nstrips);
+        symm_tile2<NT, SEG>(Q, ld, n, row0, (long long)tiles[t].I, (long long)tiles[t].J, gT, lv, rowpart, colpart, rowpart_stride,
+                            colpart_stride, sh, sgr);
     }
 }
 

@@ -771,8 +771,7 @@ int symv_alloc(ellhip_space* s) {
 constexpr int MULTI_MAX = 32;  // = GRP_MAX = 2 * SMM_NV: gradients per matrix-core pass at most
 constexpr int MULTI_VALU_MAX = 3;  // largest group k_symv_multi takes (vector ALU, bit-identical to k_symv)
 size_t rowpart_elems(const ellhip_space* s) { return (size_t)((s->n + s->symv_seg - 1) / s->symv_seg) * (size_t)s->n; }
-// (columns rounded up to 128: the block-major layout of the matrix-core passes, colpart_index<true>, holds whole 128-column blocks)
-size_t colpart_elems(const ellhip_space* s) { return (size_t)((s->nrows + SYMV_H - 1) / SYMV_H) * (size_t)((s->n + 127) / 128 * 128); }
+size_t colpart_elems(const ellhip_space* s) { return (size_t)((s->nrows + SYMV_H - 1) / SYMV_H) * (size_t)s->n; }
 double* rowpart_of(const ellhip_space* s, int set) {
     return set == 0 ? s->d_rowpart : set == 1 ? s->d_rowpart2 : s->d_rowpart_m + (size_t)(set - 2) * rowpart_elems(s);
 }
@@ -1643,17 +1642,17 @@ int multi_setup(ellhip_space* s) {
                        (const double*)s->d_gT, 0, s->d_rowpart_m, s->d_colpart_m, (long long)rowpart_elems(s),                      \
                        (long long)colpart_elems(s), (const DevState*)s->d_st, (const SymmTile*)s->d_symm_tiles, 0, s->d_symm_queue)
         if (wide && nt) {
-            ELLHIP_SYMM_WARM(k_symm_mfma_q<true, SYMV_SEG, true>);
-            ELLHIP_SYMM_WARM(k_symm_mfma_q2<true, SYMV_SEG, true>);
+            ELLHIP_SYMM_WARM(k_symm_mfma_q<true, SYMV_SEG>);
+            ELLHIP_SYMM_WARM(k_symm_mfma_q2<true, SYMV_SEG>);
         } else if (wide) {
-            ELLHIP_SYMM_WARM(k_symm_mfma_q<false, SYMV_SEG, true>);
-            ELLHIP_SYMM_WARM(k_symm_mfma_q2<false, SYMV_SEG, true>);
+            ELLHIP_SYMM_WARM(k_symm_mfma_q<false, SYMV_SEG>);
+            ELLHIP_SYMM_WARM(k_symm_mfma_q2<false, SYMV_SEG>);
         } else if (nt) {
-            ELLHIP_SYMM_WARM(k_symm_mfma_q<true, SYMV_SEG_SMALL, true>);
-            ELLHIP_SYMM_WARM(k_symm_mfma_q2<true, SYMV_SEG_SMALL, true>);
+            ELLHIP_SYMM_WARM(k_symm_mfma_q<true, SYMV_SEG_SMALL>);
+            ELLHIP_SYMM_WARM(k_symm_mfma_q2<true, SYMV_SEG_SMALL>);
         } else {
-            ELLHIP_SYMM_WARM(k_symm_mfma_q<false, SYMV_SEG_SMALL, true>);
-            ELLHIP_SYMM_WARM(k_symm_mfma_q2<false, SYMV_SEG_SMALL, true>);
+            ELLHIP_SYMM_WARM(k_symm_mfma_q<false, SYMV_SEG_SMALL>);
+            ELLHIP_SYMM_WARM(k_symm_mfma_q2<false, SYMV_SEG_SMALL>);
         }
 #undef ELLHIP_SYMM_WARM
         HIPCHK(hipGetLastError());
@@ -1721,15 +1720,13 @@ void symm_mfma_go(ellhip_space* s, const double* g_dev, int lv, hipStream_t st, 
 #define ELLHIP_SYMM_Q(...)                                                                                                          \
     hipLaunchKernelGGL((__VA_ARGS__), dim3((unsigned)wgs), dim3(256), 0, st, (const double*)s->d_Q, s->ld, s->n, s->row0,                \
                        (const double*)gT, lv, rowp, colp, (long long)rowpart_elems(s), (long long)colpart_elems(s),                 \
-                       (const DevState*)s->d_st, (const SymmTile*)s->d_symm_tiles, s->symm_ntiles, queue,                          \
-                       (long long)((s->nrows + SYMV_H - 1) / SYMV_H))
-    // (CBLK = true: the column partial sums in the block-major layout k_group_reduce reads in one run, colpart_index)
+                       (const DevState*)s->d_st, (const SymmTile*)s->d_symm_tiles, s->symm_ntiles, queue)
     if (nvw == SMM_NV) {
-        if (nt) ELLHIP_SYMM_Q(k_symm_mfma_q<true, SEG, true>);
-        else ELLHIP_SYMM_Q(k_symm_mfma_q<false, SEG, true>);
+        if (nt) ELLHIP_SYMM_Q(k_symm_mfma_q<true, SEG>);
+        else ELLHIP_SYMM_Q(k_symm_mfma_q<false, SEG>);
     } else {
-        if (nt) ELLHIP_SYMM_Q(k_symm_mfma_q2<true, SEG, true>);
-        else ELLHIP_SYMM_Q(k_symm_mfma_q2<false, SEG, true>);
+        if (nt) ELLHIP_SYMM_Q(k_symm_mfma_q2<true, SEG>);
+        else ELLHIP_SYMM_Q(k_symm_mfma_q2<false, SEG>);
     }
 #undef ELLHIP_SYMM_Q
 }

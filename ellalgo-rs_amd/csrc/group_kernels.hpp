@@ -44,7 +44,7 @@ __global__ __launch_bounds__(256) void k_group_reduce(long long n, long long row
     const long long l = blockIdx.y, nb = gridDim.x;
     // (NP = 0, a row shard: its partial y_l only -- the dot products wait for the all-reduce, k_group_dots)
     // (slot0: the slots recorded before the group; k_group_scalar reads B[j][l] for j < slot0 only)
-    symv_reduce_block<NP, false, false, true>((long long)blockIdx.x, n, row0, nrows, seg, rowpart + l * rowpart_stride,
+    symv_reduce_block<NP, false>((long long)blockIdx.x, n, row0, nrows, seg, rowpart + l * rowpart_stride,
                                  colpart + l * colpart_stride, Y + l * n, g + l * g_stride, pend, gpart + l * nb * (NP + 1), part, slot0);
 }
 

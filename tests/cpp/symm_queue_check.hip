@@ -1,6 +1,5 @@
 // symm_queue_check.hip -- GPU test (built with hipcc by tests/test_gpu_symm_queue.py): the matrix-core product pass in its queue forms
-// (k_symm_mfma_q: tiles drawn from a counter, <= 16 gradients; k_symm_mfma_q2: two column tiles, <= 32; both with the block-major
-// layout of the column sums the product uses) against the grid form round 3
+// (k_symm_mfma_q: tiles drawn from a counter, <= 16 gradients; k_symm_mfma_q2: two column tiles, <= 32) against the grid form round 3
 // shipped (k_symm_mfma, one workgroup per tile), on a matrix whose upper triangle holds garbage (the kernels may read the lower
 // triangle only), for whole matrices and for a row shard, full and ragged groups.  Partial sums compared BIT FOR BIT: per vector the
 // arithmetic is the same, only who computes which tile (and when) differs.  Prints one JSON line per case.
@@ -27,7 +26,7 @@ __global__ void k_fill(double* p, long long m, unsigned long long salt) {
 template <int SEG>
 static bool run_case(long long n, long long row0, long long nrows, int lv, int wgs) {
     const long long ld = n + 16;
-    const long long nstrips = (nrows + SYMV_H - 1) / SYMV_H, nsegs = (n + SEG - 1) / SEG, rs = nsegs * n, cs = nstrips * ((n + 127) / 128 * 128);
+    const long long nstrips = (nrows + SYMV_H - 1) / SYMV_H, nsegs = (n + SEG - 1) / SEG, rs = nsegs * n, cs = nstrips * n;
     double *Q, *g, *gT16, *gT32, *rp[2], *cp[2];
     DevState* st;
     CK(hipMalloc(&Q, (size_t)nrows * ld * 8));
@@ -73,12 +72,12 @@ static bool run_case(long long n, long long row0, long long nrows, int lv, int w
     // the queue forms -> sets 1 (k_pack_grads rewinds the counter, as in the product)
     if (lv <= 16) {
         hipLaunchKernelGGL(k_pack_grads, dim3((unsigned)((n * 16 + 255) / 256)), dim3(256), 0, 0, (const double*)g, n, lv, n, gT16, d_q, 16);
-        hipLaunchKernelGGL((k_symm_mfma_q<true, SEG, true>), dim3((unsigned)wgs), dim3(256), 0, 0, (const double*)Q, ld, n, row0, (const double*)gT16, lv,
-                           rp[1], cp[1], rs, cs, (const DevState*)st, (const SymmTile*)d_tl, ntiles, d_q, nstrips);
+        hipLaunchKernelGGL((k_symm_mfma_q<true, SEG>), dim3((unsigned)wgs), dim3(256), 0, 0, (const double*)Q, ld, n, row0, (const double*)gT16, lv, rp[1],
+                           cp[1], rs, cs, (const DevState*)st, (const SymmTile*)d_tl, ntiles, d_q);
     } else {
         hipLaunchKernelGGL(k_pack_grads, dim3((unsigned)((n * 32 + 255) / 256)), dim3(256), 0, 0, (const double*)g, n, lv, n, gT32, d_q, 32);
-        hipLaunchKernelGGL((k_symm_mfma_q2<true, SEG, true>), dim3((unsigned)wgs), dim3(256), 0, 0, (const double*)Q, ld, n, row0, (const double*)gT32, lv,
-                           rp[1], cp[1], rs, cs, (const DevState*)st, (const SymmTile*)d_tl, ntiles, d_q, nstrips);
+        hipLaunchKernelGGL((k_symm_mfma_q2<true, SEG>), dim3((unsigned)wgs), dim3(256), 0, 0, (const double*)Q, ld, n, row0, (const double*)gT32, lv, rp[1],
+                           cp[1], rs, cs, (const DevState*)st, (const SymmTile*)d_tl, ntiles, d_q);
     }
     CK(hipDeviceSynchronize());
     std::vector<double> a((size_t)32 * std::max(rs, cs)), b((size_t)32 * std::max(rs, cs));
@@ -89,18 +88,7 @@ static bool run_case(long long n, long long row0, long long nrows, int lv, int w
     for (long long i = 0; i < 32 * rs; ++i) rsum += a[i] * a[i];
     CK(hipMemcpy(a.data(), cp[0], (size_t)32 * cs * 8, hipMemcpyDeviceToHost));
     CK(hipMemcpy(b.data(), cp[1], (size_t)32 * cs * 8, hipMemcpyDeviceToHost));
-    // (the grid form writes the column sums row-major [strip][n], the product's queue forms block-major [c / 128][strip][128]:
-    // colpart_index<true>; compared element by element through that map, bit for bit)
-    bool csame = true;
-    for (int v = 0; v < 32 && csame; ++v)
-        for (long long I = 0; I < nstrips && csame; ++I)
-            for (long long c = 0; c < n; ++c) {
-                const double x = a[(size_t)v * cs + I * n + c], y = b[(size_t)v * cs + ((c >> 7) * nstrips + I) * 128 + (c & 127)];
-                if (memcmp(&x, &y, 8) != 0) {
-                    csame = false;
-                    break;
-                }
-            }
+    const bool csame = memcmp(a.data(), b.data(), (size_t)32 * cs * 8) == 0;
     unsigned hq = 0;
     CK(hipMemcpy(&hq, d_q, 4, hipMemcpyDeviceToHost));
     printf("{\"n\": %lld, \"row0\": %lld, \"nrows\": %lld, \"seg\": %d, \"gradients\": %d, \"workgroups\": %d, \"tiles\": %d, \"rowpart_identical\": %s, "
