@@ -235,11 +235,14 @@ int ellhip_set_shard_symmetric(ellhip_space *s, int flag);
  *   ELLHIP_OPT_RESIDENT_FAULT    -1, >= 0   -1       Ell, per handle, TEST HOOK: one workgroup abandons every resident batch
  *                                                    at this cut of it as if its wait had timed out (exercises the above)
  *   ELLHIP_OPT_RESIDENT_ABANDONED  read only          Ell, per handle: resident batches abandoned and rerun so far
- *   ELLHIP_OPT_OVERLAP           0 / 1      1        Ell, ellhip_queue_run_fused on the lower-triangle schedule: the NEXT queued
+ *   ELLHIP_OPT_OVERLAP           0 / 1 / 2  1        Ell, ellhip_queue_run_fused on the lower-triangle schedule: the NEXT queued
  *                                                    cut's GEMV (LOOKAHEAD 1) or the next GROUP's products (LOOKAHEAD > 3) --
  *                                                    they read Q_base, which the cuts being taken do not change -- are issued
- *                                                    on a second stream beside the current reduction + scalar stage; same
- *                                                    results as 0 to the bit (same kernels, operands and summation order)
+ *                                                    on a second stream: beside the current reduction + scalar stage
+ *                                                    (LOOKAHEAD 1), behind the current group's reductions and beside the
+ *                                                    rest of its stage (LOOKAHEAD > 3); same results as 0 to the bit (same
+ *                                                    kernels, operands and summation order).  2: the same kernels in the
+ *                                                    same order on ONE stream (what the tests compare 1 against)
  *   ELLHIP_OPT_LOOKAHEAD         1 .. 32    32       Ell, ellhip_queue_run_fused on the lower-triangle schedule: the GEMVs of up to
  *                                                    this many consecutive QUEUED cuts are formed in one pass over Q_base
  *                                                    (they all refer to the same matrix until the next apply pass):
