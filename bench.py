@@ -747,7 +747,7 @@ def main() -> None:
             depth = 24 if (lower_ok and n >= symv_min_n) else 8
         else:
             # symmetric shards take the pipelined queue run in groups (one pass over the local trapezoid and ONE all-reduce
-            # per 16 queued cuts): the per-cut latency that made small trapezoids a loss is gone
+            # per group of up to 32 queued cuts): the per-cut latency that made small trapezoids a loss is gone
             sym = (n % 64 == 0 and n // 64 >= world and os.environ.get("ELLHIP_SHARD_SYMMETRIC", "1") != "0")
             depth = 24 if (lower_ok and sym) else 8
     C2 = args.compare_steps if variant == "ell" else 0
@@ -763,7 +763,7 @@ def main() -> None:
     if shard_sym:
         C2 = 0
     # symmetric shards: a second timed region on the schedule BASELINE config 4 names -- one all-reduce of Q g per ITERATION
-    # (the headline region takes the queue in groups: one all-reduce per group of up to 16 queued cuts, replay only)
+    # (the headline region takes the queue in groups: one all-reduce per group of up to 32 queued cuts, replay only)
     C3 = 48 if shard_sym else 0
     # alternatives measured after the main run, on the same handle: (schedule, depth)
     alts = []

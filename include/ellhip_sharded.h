@@ -93,7 +93,7 @@ int ellhip_sharded_queue_upload(ellhip_sharded *s, int64_t k, const int32_t *kin
                                 const double *beta0, const int32_t *has_beta1, const double *beta1);
 int ellhip_sharded_queue_run(ellhip_sharded *s, int64_t first, int64_t count);        /* two passes per cut */
 /* pipelined: one pass over the local rows per cut and one collective per cut -- or, for symmetric shards with n a multiple of
- * 64 (ELLHIP_OPT_LOOKAHEAD > 3, the default), per GROUP of up to 16 queued cuts: their products Q_base g are formed in one
+ * 64 (ELLHIP_OPT_LOOKAHEAD > 3, the default), per GROUP of up to 32 queued cuts: their products Q_base g are formed in one
  * pass over the local trapezoid on the matrix cores, the group's partial vectors are added by ONE all-reduce (cuts x n
  * doubles through the same ellhip_allreduce_fn / ncclAllReduce), and the group's scalar stage runs on every rank
  * (include/ellhip.h "options", DESIGN.md sections 3.6 and 7).  Results agree with the cut-by-cut schedule to ~1e-15. */
