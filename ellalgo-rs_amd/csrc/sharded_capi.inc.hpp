@@ -419,7 +419,7 @@ int ellhip_sharded_queue_run_fused(ellhip_sharded* s, int64_t first, int64_t cou
         groups = arc == 1;
     }
     if (groups) {
-        // Symmetric shards look ahead like the unsharded queue run: the products of up to 16 queued
+        // Symmetric shards look ahead like the unsharded queue run: the products of up to 32 queued
         // cuts in one pass over the local trapezoid, ONE all-reduce of the group's vectors, the group stage on every rank.
         DeviceGuard guard(s->sh->device);
         int64_t i = first;
