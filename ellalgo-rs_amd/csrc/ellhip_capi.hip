@@ -1741,11 +1741,12 @@ long long group_size(const ellhip_space* s, long long cap, long long rem) {
     return g;
 }
 
-// beside: the pass is issued next to the previous group's stage -- it leaves one workgroup slot free on a sixteenth of the CUs, where
-// that stage's short kernels run (a pass that draws its tiles from a queue keeps every slot it gets until it ends)
+// beside: the pass is issued next to the previous group's stage -- it leaves a sixteenth of its workgroup slots free, where that
+// stage's short kernels run (a pass that draws its tiles from a queue keeps every slot it gets until it ends; with a 32nd free
+// k_group_sums did not get on the card before the pass ended, with an eighth the pass itself lost more than the stage gained)
 int symm_go(ellhip_space* s, const double* g_dev, int lv, hipStream_t st, int half, bool beside = false) {
     ProfScope ps(s, CLS_SYMV, st);
-    const int wgs = beside ? std::max(1, s->symm_wgs - std::max(1, (s->symm_wgs * 3) / 32)) : s->symm_wgs;
+    const int wgs = beside ? std::max(1, s->symm_wgs - std::max(1, s->symm_wgs / 16)) : s->symm_wgs;
     if (s->symv_seg == SYMV_SEG) symm_mfma_go<SYMV_SEG>(s, g_dev, lv, st, half, wgs);
     else symm_mfma_go<SYMV_SEG_SMALL>(s, g_dev, lv, st, half, wgs);
     HIPCHK(hipGetLastError());
