@@ -34,6 +34,23 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+FP64_MFMA_PEAK_TF = 78.6  # v_mfma_f64_16x16x4_f64: 64 cycles per instruction and SIMD = the FP64 vector-FMA rate, 1024 SIMDs, 2.4 GHz
+                          # (measured back to back on one accumulator: 68 cycles, 71.6-75.2 TFLOP/s: profiles/r04/mfma_f64_rate.txt)
+
+
+def product_pass_roof(n2w: float, gradients_per_pass: float, avg_ms: float) -> dict:
+    """Which roof binds the matrix-core product pass (k_symm_mfma_q / _q2), and how far below it a launch of `avg_ms` is.
+    The pass multiplies every block of the lower triangle with the group's gradients twice (column and row product): 2 n^2 flop
+    per gradient for 4 n^2 bytes read, i.e. (gradients per pass) / 2 flop per byte, which crosses this card's ridge
+    (78.6 TFLOP/s / 8 TB/s = 9.8 flop/B) at 19.65 gradients per pass.  n2w: the matrix elements one GPU holds (n^2 / ranks).
+    Padding columns of the 16-wide MFMA tiles are NOT counted as flop."""
+    flop = 2.0 * n2w * gradients_per_pass
+    tf = flop / (avg_ms * 1e-3) / 1e12
+    gbps = 4.0 * n2w / (avg_ms * 1e-3) / 1e9
+    intensity = gradients_per_pass / 2.0
+    ridge = FP64_MFMA_PEAK_TF * 1e12 / (HBM_PEAK_GBS * 1e9)
+    return {"bound": "mfma" if intensity > ridge else "hbm", "flop_per_launch": flop, "flop_per_byte": intensity, "ridge": ridge,
+            "TFLOPs": tf, "mfma_frac": tf / FP64_MFMA_PEAK_TF, "GBps": gbps, "hbm_frac": gbps / HBM_PEAK_GBS}
 
 WORKLOADS = {
     # name: (n, variant, cut generator, description)
@@ -1112,30 +1129,25 @@ def main() -> None:
         pass
     upd_gbps = bytes_update / (ms_per_step * 1e-3) / 1e9
     roofline["per_kernel"] = per_kernel
-    FP64_MFMA_PEAK_TF = 78.6   # v_mfma_f64_16x16x4_f64: 64 cycles per instruction and SIMD = the FP64 vector-FMA rate, 1024 SIMDs,
-                               # 2.4 GHz (measured back to back on one accumulator: 68 cycles, 71.6-75.2 TFLOP/s: profiles/r04/mfma_f64_rate.txt)
     symm_width = None
     if roofline.get("kernel") == "k_symm_mfma":
-        # The pass multiplies every block of the lower triangle with the group's gradients twice (column and row product): 2 n^2 flop
-        # per gradient for 4 n^2 bytes, so its arithmetic intensity is (gradients per pass) / 2 flop per byte and crosses the ridge of
-        # this card (78.6 TFLOP/s / 8 TB/s = 9.8 flop/B) at 20 gradients per pass.  The profiled window's passes carry
-        # P / launches gradients on average (groups of 32 and 16 at the default lookahead): above the ridge the binding roof is the
-        # FP64 matrix pipe and `roofline` says so (bound "mfma", TFLOP/s of the gradients actually multiplied, padding not
-        # counted); the HBM view of the same launches stays beside it as `roofline.hbm_view`.
+        # The profiled window's passes carry P / launches gradients on average (groups of 32 and 16 at the default lookahead): above
+        # the ridge the binding roof is the FP64 matrix pipe and `roofline` says so (bound "mfma", TFLOP/s of the gradients actually
+        # multiplied); the HBM view of the same launches stays beside it as `roofline.hbm_view` (product_pass_roof).
         symm_width = P / max(per_kernel[dom]["launches"], 1)
-        mf = 2.0 * n2w * symm_width
-        tf = mf / (roofline["avg_launch_ms"] * 1e-3) / 1e12
-        roofline["matrix_pipe"] = {"flop_per_launch": mf, "gradients_per_pass": symm_width, "peak_TFLOPs": FP64_MFMA_PEAK_TF,
-                                   "achieved_TFLOPs": tf, "frac": tf / FP64_MFMA_PEAK_TF,
+        roof = product_pass_roof(n2w, symm_width, roofline["avg_launch_ms"])
+        roofline["matrix_pipe"] = {"flop_per_launch": roof["flop_per_launch"], "gradients_per_pass": symm_width,
+                                   "peak_TFLOPs": FP64_MFMA_PEAK_TF, "achieved_TFLOPs": roof["TFLOPs"], "frac": roof["mfma_frac"],
                                    "note": "HBM time and matrix-pipe time of this kernel add up rather than overlap "
                                            "(DESIGN.md 3.6): read the HBM fraction and matrix_pipe.frac together"}
-        if symm_width / 2.0 > FP64_MFMA_PEAK_TF * 1e12 / (HBM_PEAK_GBS * 1e9):
+        if roof["bound"] == "mfma":
             roofline["hbm_view"] = {"achieved": roofline["achieved"], "unit": "GB/s", "peak": HBM_PEAK_GBS, "frac": roofline["frac"],
                                     "alg_bytes_per_launch": roofline["alg_bytes_per_launch"]}
-            roofline.update({"bound": "mfma", "unit": "TFLOP/s", "peak": FP64_MFMA_PEAK_TF, "achieved": tf, "frac": tf / FP64_MFMA_PEAK_TF,
-                             "alg_flop_per_launch": mf,
-                             "bound_note": f"{symm_width:g} gradients per pass = {symm_width / 2:g} flop/B, above this card's ridge "
-                                           f"(9.8): priced against the FP64 matrix pipe; hbm_view has the same launches against HBM"})
+            roofline.update({"bound": "mfma", "unit": "TFLOP/s", "peak": FP64_MFMA_PEAK_TF, "achieved": roof["TFLOPs"],
+                             "frac": roof["mfma_frac"], "alg_flop_per_launch": roof["flop_per_launch"],
+                             "bound_note": f"{symm_width:g} gradients per pass = {roof['flop_per_byte']:g} flop/B, above this card's "
+                                           f"ridge ({roof['ridge']:.1f}): priced against the FP64 matrix pipe; hbm_view has the same "
+                                           f"launches against HBM"})
     if prof_iso:
         iso = kernel_table(prof_iso)
         roofline["per_kernel_isolated"] = iso
@@ -1145,9 +1157,9 @@ def main() -> None:
                                     "note": "the same kernel with nothing running beside it (ELLHIP_OPT_OVERLAP = 0 for these launches only)"}
             if roofline.get("bound") == "mfma" and symm_width:
                 w_iso = P_iso / max(iso[dom]["launches"], 1)
-                tf_iso = 2.0 * n2w * w_iso / (iso[dom]["avg_ms"] * 1e-3) / 1e12
-                roofline["isolated"].update({"hbm_frac": roofline["isolated"]["frac"], "achieved": tf_iso, "unit": "TFLOP/s",
-                                             "frac": tf_iso / FP64_MFMA_PEAK_TF, "gradients_per_pass": w_iso})
+                roof_iso = product_pass_roof(n2w, w_iso, iso[dom]["avg_ms"])
+                roofline["isolated"].update({"hbm_frac": roofline["isolated"]["frac"], "achieved": roof_iso["TFLOPs"], "unit": "TFLOP/s",
+                                             "frac": roof_iso["mfma_frac"], "gradients_per_pass": w_iso})
     roofline["whole_update"] = {"alg_bytes_per_gpu": bytes_update, "GBps_per_gpu": upd_gbps,
                                 "frac": upd_gbps / HBM_PEAK_GBS}
     if "achieved" not in roofline:

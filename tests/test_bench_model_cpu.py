@@ -44,3 +44,19 @@ def test_bytes_per_update():
     assert abs(b - (2 * 4.0 + 1 * 8.0) / 20 * n2) < 1.0        # the driver's form: 0.8 n^2 per update
     b, text = bench.ell_bytes_per_update(n2 / 4, "pipelined", 48, 96, True, True, True, 16)
     assert abs(b - (6 * 4.0 + 2 * 8.0) / 96 * n2 / 4) < 1.0 and "all-reduce" in text   # symmetric shards, per GPU
+
+
+def test_product_pass_roof_crosses_the_ridge_at_twenty_gradients():
+    """bench.py prices the matrix-core product pass against the FP64 matrix pipe when a pass carries enough gradients to sit above
+    the card's ridge (2 n^2 flop per gradient for 4 n^2 bytes: gradients / 2 flop per byte against 78.6 TFLOP/s / 8 TB/s = 9.8),
+    against HBM otherwise; the numbers of profiles/r04 as the example."""
+    n2 = 16384.0 ** 2
+    r16 = bench.product_pass_roof(n2, 16, 0.27)
+    assert r16["bound"] == "hbm" and abs(r16["flop_per_byte"] - 8.0) < 1e-12 and abs(r16["hbm_frac"] - 4 * n2 / 0.27e-3 / 8e12) < 1e-12
+    r19, r20 = bench.product_pass_roof(n2, 19.6, 0.4), bench.product_pass_roof(n2, 19.7, 0.4)
+    assert r19["bound"] == "hbm" and r20["bound"] == "mfma" and abs(r20["ridge"] - 9.825) < 1e-9
+    r32 = bench.product_pass_roof(n2, 32, 0.445)
+    assert r32["bound"] == "mfma" and abs(r32["TFLOPs"] - 2 * n2 * 32 / 0.445e-3 / 1e12) < 1e-9 and 0.48 < r32["mfma_frac"] < 0.50
+    assert abs(r32["hbm_frac"] - 0.3016) < 1e-3      # the same launch against HBM: 4 n^2 bytes in 0.445 ms
+    # a row shard: a quarter of the elements, a quarter of the flop and of the bytes, the same intensity
+    assert bench.product_pass_roof(n2 / 4, 32, 0.2)["flop_per_byte"] == 16.0
