@@ -29,7 +29,7 @@ int batch_alloc(ellhip_batch* h) {
     HIPCHK(hipMalloc(&h->d_xc, B * n * sizeof(double)));
     HIPCHK(hipMalloc(&h->d_kappa, B * sizeof(double)));
     HIPCHK(hipMalloc(&h->d_tsq, B * sizeof(double)));
-    HIPCHK(hipMemset(h->d_tsq, 0, B * sizeof(double)));
+    HIPCHK(fill_now(h->d_tsq, 0, B * sizeof(double), h->stream));
     return 0;
 }
 
@@ -150,7 +150,7 @@ int ellhip_batch_create(ellhip_batch** out, int64_t B, int64_t n, const double* 
     }
     if (e != hipSuccess) return bail(fail(ELLHIP_E_HIP, "batch create: matrix", e));
     if (xc) e = hipMemcpy(h->d_xc, xc, sB * sn * sizeof(double), hipMemcpyHostToDevice);
-    else e = hipMemset(h->d_xc, 0, sB * sn * sizeof(double));
+    else e = fill_now(h->d_xc, 0, sB * sn * sizeof(double), h->stream);
     if (e != hipSuccess) return bail(fail(ELLHIP_E_HIP, "batch create: xc", e));
     std::vector<double> ones;
     if (!kappa) {

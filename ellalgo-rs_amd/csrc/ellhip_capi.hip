@@ -53,6 +53,15 @@ int fail(int code, const char* what, hipError_t e = hipSuccess) {
         if (_e != hipSuccess) return fail(ELLHIP_E_HIP, #expr, _e); \
     } while (0)
 
+// hipMemset on device memory is enqueued on the null stream and may return before the fill has run, and every handle's stream is
+// non-blocking: a kernel launched right afterwards on the handle's stream can run BEFORE the fill and be overwritten by it (seen once in
+// 3600 state-machine walks: the first queued cut's tsq read back as 0 -- the fill of ellhip_queue_upload had landed behind the cut).
+// Fills therefore go on the handle's own stream and are waited for.
+hipError_t fill_now(void* p, int value, size_t bytes, hipStream_t st) {
+    const hipError_t e = hipMemsetAsync(p, value, bytes, st);
+    return e == hipSuccess ? hipStreamSynchronize(st) : e;
+}
+
 struct ProfEvent {
     hipEvent_t a, b;
     int cls;
@@ -2706,8 +2715,8 @@ int ellhip_queue_upload(ellhip_space* s, int64_t k, const int32_t* kinds, const 
     HIPCHK(hipMalloc(&s->d_qtsq, (size_t)k * sizeof(double)));
     HIPCHK(hipMemcpy(s->d_qparams, hp.data(), (size_t)k * sizeof(CutParams), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(s->d_qgrads, grads, (size_t)k * (size_t)n * sizeof(double), hipMemcpyHostToDevice));
-    HIPCHK(hipMemset(s->d_qstatus, 0xff, (size_t)k * sizeof(int)));  // -1 = not run yet
-    HIPCHK(hipMemset(s->d_qtsq, 0, (size_t)k * sizeof(double)));
+    HIPCHK(fill_now(s->d_qstatus, 0xff, (size_t)k * sizeof(int), s->stream));  // -1 = not run yet
+    HIPCHK(fill_now(s->d_qtsq, 0, (size_t)k * sizeof(double), s->stream));
     s->qk = k;
     return 0;
 }

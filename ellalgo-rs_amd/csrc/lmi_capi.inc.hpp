@@ -67,10 +67,10 @@ int ellhip_lmi_create(ellhip_lmi** out, int64_t n, int64_t m, const double* mat_
     if (e == hipSuccess) e = hipHostMalloc(&o->h_st, sizeof(LmiState), hipHostMallocDefault);
     if (e == hipSuccess && n > 0) e = hipMemcpy(o->d_F, mat_f, (size_t)n * mm, hipMemcpyHostToDevice);
     if (e == hipSuccess && mat_b) e = hipMemcpy(o->d_B, mat_b, mm, hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemset(o->d_S, 0, mm);
-    if (e == hipSuccess) e = hipMemset(o->d_A, 0, mm);
-    if (e == hipSuccess) e = hipMemset(o->d_v, 0, (size_t)m * sizeof(double));
-    if (e == hipSuccess) e = hipMemset(o->d_st, 0, sizeof(LmiState));
+    if (e == hipSuccess) e = fill_now(o->d_S, 0, mm, o->stream);
+    if (e == hipSuccess) e = fill_now(o->d_A, 0, mm, o->stream);
+    if (e == hipSuccess) e = fill_now(o->d_v, 0, (size_t)m * sizeof(double), o->stream);
+    if (e == hipSuccess) e = fill_now(o->d_st, 0, sizeof(LmiState), o->stream);
     if (e != hipSuccess) {
         ellhip_lmi_destroy(o);
         return fail(e == hipErrorOutOfMemory ? ELLHIP_E_NOMEM : ELLHIP_E_HIP, "lmi create", e);

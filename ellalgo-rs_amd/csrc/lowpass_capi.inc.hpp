@@ -277,9 +277,9 @@ int ellhip_lowpass_create(ellhip_lowpass** out, int64_t ndim, double wpass, doub
     if (e == hipSuccess) e = hipHostMalloc(&o->h_cp, sizeof(CutParams), hipHostMallocDefault);
     if (e == hipSuccess) e = hipHostMalloc(&o->h_vec, vbytes, hipHostMallocDefault);
     if (e != hipSuccess) return bail(fail(e == hipErrorOutOfMemory ? ELLHIP_E_NOMEM : ELLHIP_E_HIP, "lowpass allocation", e));
-    if (o->P.ld != ndim) e = hipMemset(o->d_A, 0, (size_t)mdim * (size_t)o->P.ld * sizeof(double));
-    if (e == hipSuccess) e = hipMemset(o->d_vals, 0, (size_t)mdim * sizeof(double));
-    if (e == hipSuccess) e = hipMemset(o->d_zero, 0, sizeof(int));
+    if (o->P.ld != ndim) e = fill_now(o->d_A, 0, (size_t)mdim * (size_t)o->P.ld * sizeof(double), o->stream);
+    if (e == hipSuccess) e = fill_now(o->d_vals, 0, (size_t)mdim * sizeof(double), o->stream);
+    if (e == hipSuccess) e = fill_now(o->d_zero, 0, sizeof(int), o->stream);
     if (e != hipSuccess) return bail(fail(ELLHIP_E_HIP, "lowpass memset", e));
     // the table: the caller's own (the reference's `spectrum` field, row-major mdim x ndim) or computed
     // here slab by slab with the host libm, exactly as LowpassOracle::new does
