@@ -56,10 +56,12 @@ int fail(int code, const char* what, hipError_t e = hipSuccess) {
 // hipMemset on device memory is enqueued on the null stream and may return before the fill has run, and every handle's stream is
 // non-blocking: a kernel launched right afterwards on the handle's stream can run BEFORE the fill and be overwritten by it (seen once in
 // 3600 state-machine walks: the first queued cut's tsq read back as 0 -- the fill of ellhip_queue_upload had landed behind the cut).
-// Fills therefore go on the handle's own stream and are waited for.
-hipError_t fill_now(void* p, int value, size_t bytes, hipStream_t st) {
-    const hipError_t e = hipMemsetAsync(p, value, bytes, st);
-    return e == hipSuccess ? hipStreamSynchronize(st) : e;
+// Fills are therefore waited for: the same null-stream hipMemset as before, then a wait for the null stream.  (Moving the fills to the
+// handle's own stream changed what the host threads of the multi-rank tests wait for and two suite runs in a row lost a rank case;
+// this form changes nothing but the missing wait.)
+hipError_t fill_now(void* p, int value, size_t bytes, hipStream_t /*the handle's stream: documentation only*/) {
+    const hipError_t e = hipMemset(p, value, bytes);
+    return e == hipSuccess ? hipStreamSynchronize(nullptr) : e;
 }
 
 struct ProfEvent {
