@@ -47,10 +47,14 @@ inline int allgather(Group& g, int rank, const double* send, double* recv, size_
     g.send[(size_t)rank] = send;
     g.recv[(size_t)rank] = recv;
     if (!g.barrier()) return 2;
+    // (on the caller's stream and waited for: a device-to-device hipMemcpy goes to the null stream and may return before it has run,
+    // while the caller's stream is non-blocking -- the kernels that read `recv` next, or a peer rewriting its part behind the barrier
+    // below, could overtake the copy)
     for (int r = 0; r < g.nranks; ++r) {
         if (r == rank) continue;
-        if (hipMemcpy(recv + (size_t)r * count, g.send[(size_t)r], count * sizeof(double), hipMemcpyDeviceToDevice) != hipSuccess) return 3;
+        if (hipMemcpyAsync(recv + (size_t)r * count, g.send[(size_t)r], count * sizeof(double), hipMemcpyDeviceToDevice, st) != hipSuccess) return 3;
     }
+    if (hipStreamSynchronize(st) != hipSuccess) return 3;
     if (!g.barrier()) return 2;  // nobody rewrites its part while a peer still reads it
     if (rank == 0) ++g.ncalls;
     return 0;
@@ -69,7 +73,8 @@ inline int allreduce(Group& g, int rank, const double* send, double* recv, size_
             for (size_t i = 0; i < count; ++i) acc[i] += tmp[i];
     }
     if (!g.barrier()) return 2;  // every rank has read every send buffer (recv aliases send)
-    if (hipMemcpy(recv, acc.data(), count * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) return 3;
+    if (hipMemcpyAsync(recv, acc.data(), count * sizeof(double), hipMemcpyHostToDevice, st) != hipSuccess) return 3;
+    if (hipStreamSynchronize(st) != hipSuccess) return 3;  // (`acc` leaves scope; and the caller's next kernel reads `recv`)
     if (rank == 0) ++g.ncalls;
     return 0;
 }
